@@ -1,0 +1,218 @@
+/*
+ * pepper_hip.h — C-ABI of the MI355X-native PEPPER hot path.
+ *
+ * Two operator families live behind this boundary:
+ *
+ *   1. the pileup summary-image builder ("make_images" hot loop), replacing the pybind11 class
+ *      PEPPER_VARIANT.RegionalSummaryGenerator
+ *        reference: pepper_variant/modules/cpp/pybind_api.h:55-62 (binding),
+ *                   pepper_variant/modules/cpp/region_summary.cpp:568-916 (generate_summary),
+ *                   pepper_variant/modules/cpp/region_summary.cpp:337-566 (populate_summary_matrix)
+ *   2. the recurrent-network inference step ("run_inference" hot loop), replacing
+ *        transducer_model(images, False)   pepper_variant/modules/python/models/predict_distributed_gpu.py:65
+ *        ort_session.run(...)              pepper_variant/modules/python/models/predict_distributed_cpu.py:85-88
+ *      for plan P1 (pepper_variant 2x bi-LSTM + MLP head, models/simple_model.py:48-82) and
+ *        transducer_model(image_chunk, hidden) in the sliding loop
+ *                                          pepper/modules/python/models/predict.py:47-97
+ *      for plan P2 (pepper polisher bi-GRU encoder/decoder, pepper/modules/python/models/simple_model.py:27-42).
+ *
+ * Conventions
+ *   - plain C types only; every function returns 0 on success or a negative PV_ERR_* code;
+ *     pv_last_error() returns a thread-local message for the last failure on this thread.
+ *   - the caller owns every buffer. Entry points ending in _dev take DEVICE pointers and a HIP stream
+ *     (hipStream_t passed as void*, NULL = the context's own stream) and never synchronise with the host;
+ *     the others take HOST pointers, stage through the context's workspace and return when results are
+ *     in the caller's host buffers.
+ *   - one pv_ctx = one HIP device + one stream + one workspace. Calls on distinct contexts are
+ *     independent; calls on one context must not overlap.
+ *   - there is NO CPU fallback: if no HIP device is present pv_create fails with PV_ERR_NO_DEVICE.
+ */
+#ifndef PEPPER_HIP_H
+#define PEPPER_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PV_OK 0
+#define PV_ERR_INVALID (-1)      /* bad argument / malformed input            */
+#define PV_ERR_NO_DEVICE (-2)    /* no HIP device or device id out of range   */
+#define PV_ERR_HIP (-3)          /* a HIP runtime call failed                 */
+#define PV_ERR_CAPACITY (-4)     /* caller output buffers too small (n_out / str_bytes hold the need) */
+#define PV_ERR_LIMIT (-5)        /* an internal fixed limit was exceeded (message says which) */
+#define PV_ERR_STATE (-6)        /* call order problem (e.g. forward before load) */
+
+/* window geometry of the reference (pepper_variant/modules/python/Options.py:5-8,
+ * region_summary.cpp:831 "candidate_window_size + 1") */
+#define PV_WINDOW_ROWS 33
+#define PV_FEATURES 26
+#define PV_WINDOW_BYTES (PV_WINDOW_ROWS * PV_FEATURES)
+#define PV_MAX_COLOR 125         /* region_summary.h:15-16 */
+#define PV_MAX_ALLELE_KEY 61     /* region_summary.cpp:461,511 "candidate_string.length() <= 61" */
+
+/* CIGAR op codes = BAM codes = CIGAR_OPERATIONS (pepper_variant/modules/cpp/cigar.h:15-27) */
+#define PV_CIGAR_MATCH 0
+#define PV_CIGAR_IN 1
+#define PV_CIGAR_DEL 2
+#define PV_CIGAR_REF_SKIP 3
+#define PV_CIGAR_SOFT_CLIP 4
+#define PV_CIGAR_HARD_CLIP 5
+#define PV_CIGAR_PAD 6
+#define PV_CIGAR_EQUAL 7
+#define PV_CIGAR_DIFF 8
+#define PV_CIGAR_BACK 9
+
+typedef struct pv_ctx pv_ctx;
+
+/* ---- image builder ------------------------------------------------------------------------- */
+
+/* The scalar arguments of RegionalSummaryGenerator::generate_summary
+ * (region_summary.h:191-206; call site AlignmentSummarizer.py:223-238), same order, same types. */
+typedef struct pv_params {
+    double min_snp_baseq;
+    double min_indel_baseq;
+    double snp_freq_threshold;
+    double insert_freq_threshold;
+    double delete_freq_threshold;
+    double min_coverage_threshold;
+    double snp_candidate_freq_threshold;
+    double indel_candidate_freq_threshold;
+    double candidate_support_threshold;
+    int32_t skip_indels;
+    int32_t candidate_window_size; /* must be 32 */
+    int32_t feature_size;          /* must be 26 */
+    int32_t reserved;
+} pv_params;
+
+/* A batch of regions in flat SoA form. Region g owns reads [read_off[g], read_off[g+1]) and reference
+ * bytes ref[ref_off[g] .. ref_off[g+1]). This replaces the by-value `vector<type_read>` argument
+ * (read.h:60-108: pos, flags.is_reverse, mapping_quality, sequence, base_qualities, cigar_tuples) and
+ * the constructor arguments (region_summary.cpp:9-17: region_start, region_end, reference_sequence).
+ *   ref_end is INCLUSIVE; R = ref_end - ref_start + 1; ref_off[g+1]-ref_off[g] must be >= R.
+ *   cigar words use BAM packing: (length << 4) | op.
+ *   bases are the upper-case symbols bam_handler.cpp emits (seq_nt16_str "=ACMGRSVTWYHKDBN");
+ *   any other byte is counted like 'N' (and reported through pv_batch_out.n_foreign_bases). */
+typedef struct pv_batch_in {
+    int32_t n_regions;
+    int32_t reserved;
+    const int64_t* ref_start;   /* [n_regions] */
+    const int64_t* ref_end;     /* [n_regions] inclusive */
+    const int64_t* cand_start;  /* [n_regions] candidate_region_start */
+    const int64_t* cand_end;    /* [n_regions] candidate_region_end (inclusive) */
+    const int64_t* ref_off;     /* [n_regions+1] */
+    const uint8_t* ref;         /* reference bytes */
+    const int64_t* read_off;    /* [n_regions+1] */
+    const int64_t* read_pos;    /* [n_reads] type_read::pos */
+    const uint8_t* read_flags;  /* [n_reads] bit0 = flags.is_reverse */
+    const uint8_t* read_mapq;   /* [n_reads] type_read::mapping_quality */
+    const int64_t* base_off;    /* [n_reads+1] into bases/quals */
+    const uint8_t* bases;       /* type_read::sequence */
+    const uint8_t* quals;       /* type_read::base_qualities (raw phred) */
+    const int64_t* cigar_off;   /* [n_reads+1] into cigar */
+    const uint32_t* cigar;      /* type_read::cigar_tuples */
+} pv_batch_in;
+
+/* One output record per surviving candidate allele = one CandidateImageSummary
+ * (region_summary.h:88-111), in the reference's order (regions in batch order, sites ascending,
+ * alleles in std::set<std::string> order). images are already cast to int8 with wrap-around as
+ * DataStore.write_summary does (pepper_variant/modules/python/DataStore.py:68). */
+typedef struct pv_batch_out {
+    int64_t capacity;      /* in: number of windows the arrays below can hold */
+    int64_t str_capacity;  /* in: bytes cand_str can hold */
+    int32_t* region;       /* [capacity] index of the region in the batch */
+    int64_t* position;     /* [capacity] CandidateImageSummary::position */
+    uint8_t* depth;        /* [capacity] min(coverage,125) */
+    uint8_t* cand_freq;    /* [capacity] candidate_frequency[0] = min(allele_depth,125) */
+    int8_t* images;        /* [capacity][33][26] */
+    int32_t* images_i32;   /* optional (may be NULL): the un-cast int values of image_matrix */
+    char* cand_str;        /* allele keys, concatenated: "1T", "2AGG", "3CAA" ... (candidates[0]) */
+    int64_t* cand_off;     /* [capacity+1] */
+    int64_t n_out;         /* out: number of windows produced (or needed on PV_ERR_CAPACITY) */
+    int64_t str_bytes;     /* out: bytes of cand_str produced (or needed) */
+    int64_t n_foreign_bases; /* out: read bases outside the 16 IUPAC symbols (treated as 'N') */
+} pv_batch_out;
+
+pv_ctx* pv_create(int device_id);
+void pv_destroy(pv_ctx* ctx);
+const char* pv_last_error(void);
+/* returns the HIP stream (hipStream_t) the context launches on */
+void* pv_stream(pv_ctx* ctx);
+int pv_synchronize(pv_ctx* ctx);
+
+/* generate_summary for a batch of regions, HOST buffers in and out. */
+int pv_summarize_regions(pv_ctx* ctx, const pv_batch_in* in, const pv_params* params, pv_batch_out* out);
+
+/* Device-resident form used by the fused pipeline and the benchmark: every pointer inside `in` and
+ * `out` (the arrays, not the structs) is a DEVICE pointer; totals that the host form derives by
+ * reading the offset arrays are passed explicitly. Asynchronous on `stream`; the counters
+ * n_out/str_bytes/n_foreign_bases are written to the three-element DEVICE array `d_counts`
+ * (out->n_out etc. are not touched). Windows beyond out->capacity are dropped (d_counts[0] still
+ * holds the number needed). */
+int pv_summarize_regions_dev(pv_ctx* ctx, const pv_batch_in* in, const pv_params* params,
+                             int64_t n_reads, int64_t n_bases, int64_t n_cigar, int64_t n_ref_bytes,
+                             int64_t max_region_len, pv_batch_out* out, int64_t* d_counts, void* stream);
+
+/* ---- recurrent-network inference ------------------------------------------------------------ */
+
+#define PV_PLAN_P1_LSTM 1 /* pepper_variant: 2x bi-LSTM(256) + 5xLinear(512)/SELU + Linear(3) + softmax */
+#define PV_PLAN_P2_GRU 2  /* pepper polisher: bi-GRU(128) encoder+decoder + Linear(256->5), sliding 100/50 over 1000 */
+
+#define PV_DTYPE_F32 0            /* every product in fp32 (f32 MFMA == fmaf chain) */
+#define PV_DTYPE_BF16_INPUT_GEMM 1 /* bf16 operands (fp32 accumulate) for the input-projection GEMMs only */
+
+/* Weights in PyTorch state_dict layout (row-major, fp32), i.e. exactly the tensors
+ * ModelHander.load_simple_model_for_training (pepper_variant/modules/python/models/ModelHander.py:18-44)
+ * obtains from the checkpoint. Index [0] = forward direction, [1] = "_reverse". HOST pointers. */
+typedef struct pv_rnn_dir {
+    const float* w_ih; /* [G*H, K]  (G = 4 for LSTM gates i,f,g,o; 3 for GRU gates r,z,n) */
+    const float* w_hh; /* [G*H, H] */
+    const float* b_ih; /* [G*H] */
+    const float* b_hh; /* [G*H] */
+} pv_rnn_dir;
+
+typedef struct pv_weights_p1 {
+    pv_rnn_dir encoder[2]; /* LSTM(26 -> 256)  simple_model.py:23-27 */
+    pv_rnn_dir decoder[2]; /* LSTM(512 -> 256) simple_model.py:28-32 */
+    const float* linear_w[5]; /* linear_1 [512,16896], linear_2..5 [512,512]  simple_model.py:35-44 */
+    const float* linear_b[5]; /* [512] each */
+    const float* out_w;       /* output_layer_type [3,512] simple_model.py:46 */
+    const float* out_b;       /* [3] */
+} pv_weights_p1;
+
+typedef struct pv_weights_p2 {
+    pv_rnn_dir encoder[2]; /* GRU(10 -> 128)  pepper/modules/python/models/simple_model.py:12-16 */
+    pv_rnn_dir decoder[2]; /* GRU(256 -> 128) :17-21 */
+    const float* dense_w;  /* dense1 [5,256] :24 */
+    const float* dense_b;  /* [5] */
+} pv_weights_p2;
+
+int pv_rnn_load_p1(pv_ctx* ctx, const pv_weights_p1* w, int dtype);
+int pv_rnn_load_p2(pv_ctx* ctx, const pv_weights_p2* w, int dtype);
+
+/* P1: images int8 [B,33,26] -> probs float [B,3] (softmax over {hom-ref, het, hom-alt}).
+ * Equivalent to TransducerGRU.forward(images.float(), train_mode=False) in eval mode. */
+int pv_rnn_forward_p1(pv_ctx* ctx, const int8_t* images, int64_t B, float* probs);
+int pv_rnn_forward_p1_dev(pv_ctx* ctx, const int8_t* d_images, int64_t B, float* d_probs, void* stream);
+/* optional taps for parity tests (device or host per the variant called): encoder/decoder outputs
+ * [B,33,512]; either may be NULL */
+int pv_rnn_forward_p1_debug(pv_ctx* ctx, const int8_t* images, int64_t B, float* probs,
+                            float* enc_out, float* dec_out);
+
+/* P2: images uint8 [B,1000,10] -> labels uint8 [B,1000] (argmax of the accumulated softmax) and,
+ * optionally, the accumulated softmax acc float [B,1000,5] (may be NULL). Reproduces the 19-window
+ * sliding loop with hidden carry of pepper/modules/python/models/predict.py:47-97. */
+int pv_rnn_forward_p2(pv_ctx* ctx, const uint8_t* images, int64_t B, uint8_t* labels, float* acc);
+int pv_rnn_forward_p2_dev(pv_ctx* ctx, const uint8_t* d_images, int64_t B, uint8_t* d_labels, float* d_acc,
+                          void* stream);
+
+/* bytes of device workspace the context currently holds (diagnostics) */
+int64_t pv_workspace_bytes(pv_ctx* ctx);
+/* library/ABI version: major*10000 + minor*100 + patch */
+int pv_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PEPPER_HIP_H */

@@ -1,0 +1,55 @@
+"""TEST INFRASTRUCTURE ONLY — ctypes access to the CPU oracle (oracle/liboracle.so, built from
+region_summary_oracle.c) and, where it has been built in this container, the reference's own image
+builder (oracle/_ref/libref_region_summary.so, built by oracle/Makefile from the sources under
+/root/reference). Neither is ever used by the product path."""
+import ctypes as C
+import os
+import subprocess
+
+from pepper_thesis_amd import _ffi
+from pepper_thesis_amd.batch import Params, RegionBatch, run_flat_summarizer
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+ORACLE_SO = os.path.join(_HERE, "liboracle.so")
+REF_SO = os.path.join(_HERE, "_ref", "libref_region_summary.so")
+
+_SIG = [C.POINTER(_ffi.pv_batch_in), C.POINTER(_ffi.pv_params), C.POINTER(_ffi.pv_batch_out)]
+_libs = {}
+
+
+def build(force=False):
+    """(re)build liboracle.so and, if /root/reference exists, oracle/_ref."""
+    if force or not os.path.exists(ORACLE_SO) or (os.path.exists("/root/reference") and not os.path.exists(REF_SO)):
+        subprocess.check_call(["make", "-s", "-C", _HERE])
+
+
+def _load(path, sym):
+    key = (path, sym)
+    if key not in _libs:
+        lib = C.CDLL(path)
+        fn = getattr(lib, sym)
+        fn.restype = C.c_int
+        fn.argtypes = _SIG
+        _libs[key] = fn
+    return _libs[key]
+
+
+def have_reference():
+    return os.path.exists(REF_SO)
+
+
+def summarize(batch: RegionBatch, params: Params, want_i32=False):
+    """CPU restatement (oracle) of generate_summary over a batch."""
+    build()
+    rc, out = run_flat_summarizer(_load(ORACLE_SO, "oracle_summarize_regions"), batch, params, want_i32)
+    if rc:
+        raise RuntimeError("oracle_summarize_regions failed: %d" % rc)
+    return out
+
+
+def reference_summarize(batch: RegionBatch, params: Params, want_i32=False):
+    """The reference's own region_summary.cpp (only where oracle/_ref was built)."""
+    rc, out = run_flat_summarizer(_load(REF_SO, "ref_summarize_regions"), batch, params, want_i32)
+    if rc:
+        raise RuntimeError("ref_summarize_regions failed: %d" % rc)
+    return out

@@ -1,0 +1,37 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "tests")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def oracle_lib():
+    """the CPU oracle (test infrastructure), built on demand with gcc"""
+    from oracle import oracle
+    oracle.build()
+    return oracle
+
+
+@pytest.fixture(scope="session")
+def summary_golden():
+    import numpy as np
+    path = os.path.join(ROOT, "tests", "golden", "summary_golden.npz")
+    return np.load(path, allow_pickle=False)
+
+
+@pytest.fixture(scope="session")
+def hip_ctx():
+    """one device context for the whole GPU session; fails loudly if the extension is missing"""
+    from pepper_thesis_amd import runtime
+    ctx = runtime.Context(0)
+    yield ctx
+    ctx.close()
