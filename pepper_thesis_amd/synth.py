@@ -179,3 +179,63 @@ def synth_p2_images(seed: int, n: int, seq_len: int = 1000, features: int = 10) 
     """SURVEY 8(d) RNN-P2 workload: uint8 [n, 1000, 10] ~ U[0,254]."""
     rng = np.random.default_rng(seed)
     return rng.integers(0, 255, size=(n, seq_len, features), dtype=np.uint8)
+
+
+# ---- deterministic synthetic weights (no checkpoints exist offline) --------------------------------
+
+def _splitmix_uniform(seed: int, n: int) -> np.ndarray:
+    """n doubles in [0,1), counter-based splitmix64: identical on every NumPy version/platform."""
+    with np.errstate(over="ignore"):
+        z = np.arange(1, n + 1, dtype=np.uint64) * np.uint64(0x9E3779B97F4A7C15) + np.uint64(seed & 0xFFFFFFFFFFFFFFFF)
+        z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        z = z ^ (z >> np.uint64(31))
+    return (z >> np.uint64(11)).astype(np.float64) * (1.0 / 9007199254740992.0)
+
+
+def _uinit(seed, shape, bound):
+    n = int(np.prod(shape))
+    return ((2.0 * _splitmix_uniform(seed, n) - 1.0) * bound).astype(np.float32).reshape(shape)
+
+
+def _rnn_weights(prefix, seed, gates, in_size, hidden):
+    """PyTorch's default LSTM/GRU init law: U(-1/sqrt(H), 1/sqrt(H)) for every tensor."""
+    k = 1.0 / np.sqrt(hidden)
+    w = {}
+    for d, suffix in enumerate(("", "_reverse")):
+        s = seed + 1000 * d
+        w["%s.weight_ih_l0%s" % (prefix, suffix)] = _uinit(s + 1, (gates * hidden, in_size), k)
+        w["%s.weight_hh_l0%s" % (prefix, suffix)] = _uinit(s + 2, (gates * hidden, hidden), k)
+        w["%s.bias_ih_l0%s" % (prefix, suffix)] = _uinit(s + 3, (gates * hidden,), k)
+        w["%s.bias_hh_l0%s" % (prefix, suffix)] = _uinit(s + 4, (gates * hidden,), k)
+    return w
+
+
+def make_weights_p1(seed: int = 1234, head_gain: float = 1.0) -> dict:
+    """state_dict (numpy fp32) of the pepper_variant TransducerGRU(26,1,256,28,3)
+    (pepper_variant/modules/python/models/simple_model.py:23-46; shapes in SURVEY Appendix B).
+    head_gain > 1 scales the Linear weights so that the random-init softmax is not almost uniform."""
+    w = {}
+    w.update(_rnn_weights("encoder", seed + 10, 4, 26, 256))
+    w.update(_rnn_weights("decoder", seed + 5000, 4, 512, 256))
+    sizes = [(512, 33 * 512), (512, 512), (512, 512), (512, 512), (512, 512)]
+    for i, (o, k) in enumerate(sizes):
+        b = 1.0 / np.sqrt(k)
+        w["linear_%d.weight" % (i + 1)] = _uinit(seed + 9000 + 10 * i, (o, k), b * head_gain)
+        w["linear_%d.bias" % (i + 1)] = _uinit(seed + 9001 + 10 * i, (o,), b)
+    b = 1.0 / np.sqrt(512)
+    w["output_layer_type.weight"] = _uinit(seed + 9900, (3, 512), b * head_gain)
+    w["output_layer_type.bias"] = _uinit(seed + 9901, (3,), b)
+    return w
+
+
+def make_weights_p2(seed: int = 4321, dense_gain: float = 1.0) -> dict:
+    """state_dict (numpy fp32) of the polisher TransducerGRU(1,10,1,128,5)
+    (pepper/modules/python/models/simple_model.py:5-25)."""
+    w = {}
+    w.update(_rnn_weights("gru_encoder", seed + 10, 3, 10, 128))
+    w.update(_rnn_weights("gru_decoder", seed + 5000, 3, 256, 128))
+    b = 1.0 / np.sqrt(256)
+    w["dense1.weight"] = _uinit(seed + 9900, (5, 256), b * dense_gain)
+    w["dense1.bias"] = _uinit(seed + 9901, (5,), b)
+    return w
