@@ -92,8 +92,8 @@ typedef struct pv_params {
  * the constructor arguments (region_summary.cpp:9-17: region_start, region_end, reference_sequence).
  *   ref_end is INCLUSIVE; R = ref_end - ref_start + 1; ref_off[g+1]-ref_off[g] must be >= R.
  *   cigar words use BAM packing: (length << 4) | op.
- *   bases are the upper-case symbols bam_handler.cpp emits (seq_nt16_str "=ACMGRSVTWYHKDBN");
- *   any other byte is counted like 'N' (and reported through pv_batch_out.n_foreign_bases). */
+ *   bases are normally the upper-case symbols bam_handler.cpp emits (seq_nt16_str "=ACMGRSVTWYHKDBN"),
+ *   but ANY byte is handled exactly as the reference would (raw-byte SNP keys, toupper for planes). */
 typedef struct pv_batch_in {
     int32_t n_regions;
     int32_t reserved;
@@ -131,7 +131,6 @@ typedef struct pv_batch_out {
     int64_t* cand_off;     /* [capacity+1] */
     int64_t n_out;         /* out: number of windows produced (or needed on PV_ERR_CAPACITY) */
     int64_t str_bytes;     /* out: bytes of cand_str produced (or needed) */
-    int64_t n_foreign_bases; /* out: read bases outside the 16 IUPAC symbols (treated as 'N') */
 } pv_batch_out;
 
 pv_ctx* pv_create(int device_id);
@@ -146,9 +145,10 @@ int pv_summarize_regions(pv_ctx* ctx, const pv_batch_in* in, const pv_params* pa
 
 /* Device-resident form used by the fused pipeline and the benchmark: every pointer inside `in` and
  * `out` (the arrays, not the structs) is a DEVICE pointer; totals that the host form derives by
- * reading the offset arrays are passed explicitly. Asynchronous on `stream`; the counters
- * n_out/str_bytes/n_foreign_bases are written to the three-element DEVICE array `d_counts`
- * (out->n_out etc. are not touched). Windows beyond out->capacity are dropped (d_counts[0] still
+ * reading the offset arrays are passed explicitly. Asynchronous on `stream`; results counters are
+ * written to the four-element DEVICE array `d_counts` = {n_out, str_bytes, status, reserved}
+ * (out->n_out etc. are not touched). status is PV_OK or a PV_ERR_* code detected on the device
+ * (malformed read, workspace limit). Windows beyond out->capacity are dropped (d_counts[0] still
  * holds the number needed). */
 int pv_summarize_regions_dev(pv_ctx* ctx, const pv_batch_in* in, const pv_params* params,
                              int64_t n_reads, int64_t n_bases, int64_t n_cigar, int64_t n_ref_bytes,

@@ -31,7 +31,6 @@ static constexpr int DELETE_ALLELE = 3;
 extern "C" int ref_summarize_regions(const pv_batch_in* in, const pv_params* p, pv_batch_out* out) {
     out->n_out = 0;
     out->str_bytes = 0;
-    out->n_foreign_bases = 0;
     if (out->capacity > 0) out->cand_off[0] = 0;
     for (int g = 0; g < in->n_regions; g++) {
         const int64_t ref_len = in->ref_off[g + 1] - in->ref_off[g];

@@ -233,7 +233,7 @@ static int walk_read(const pv_batch_in* in, int64_t read, int64_t ref_start, int
 }
 
 /* one region; appends to out starting at out->n_out / out->str_bytes. Counts even past capacity. */
-static int summarize_one(const pv_batch_in* in, int g, const pv_params* p, pv_batch_out* out, int64_t* foreign) {
+static int summarize_one(const pv_batch_in* in, int g, const pv_params* p, pv_batch_out* out) {
     const int64_t ref_start = in->ref_start[g], ref_end = in->ref_end[g];
     const int64_t R = ref_end - ref_start + 1;
     const uint8_t* ref = in->ref + in->ref_off[g];
@@ -265,14 +265,6 @@ static int summarize_one(const pv_batch_in* in, int g, const pv_params* p, pv_ba
         rc = walk_read(in, r, ref_start, ref_end, ref, ref_len, p, &c, &ev);
         if (rc) goto done;
     }
-    /* foreign symbol census (diagnostic only; does not change results) */
-    {
-        static const char iupac[] = "=ACMGRSVTWYHKDBN";
-        for (int64_t r = in->read_off[g]; r < in->read_off[g + 1]; r++)
-            for (int64_t b = in->base_off[r]; b < in->base_off[r + 1]; b++)
-                if (!memchr(iupac, in->bases[b], 16)) (*foreign)++;
-    }
-
     /* pass 2 */
     if (ev.n) qsort(ev.v, (size_t)ev.n, sizeof(ora_event), event_cmp);
     {
@@ -406,10 +398,9 @@ int oracle_summarize_regions(const pv_batch_in* in, const pv_params* params, pv_
     if (!in || !params || !out) return PV_ERR_INVALID;
     out->n_out = 0;
     out->str_bytes = 0;
-    out->n_foreign_bases = 0;
     if (out->capacity > 0) out->cand_off[0] = 0;
     for (int g = 0; g < in->n_regions; g++) {
-        int rc = summarize_one(in, g, params, out, &out->n_foreign_bases);
+        int rc = summarize_one(in, g, params, out);
         if (rc) return rc;
     }
     if (out->n_out > out->capacity || out->str_bytes > out->str_capacity) return PV_ERR_CAPACITY;

@@ -92,7 +92,6 @@ class pv_batch_out(C.Structure):
         ("cand_off", C.c_void_p),
         ("n_out", C.c_int64),
         ("str_bytes", C.c_int64),
-        ("n_foreign_bases", C.c_int64),
     ]
 
 

@@ -215,7 +215,6 @@ class SummaryOut:
     images: np.ndarray           # int8 [N,33,26]
     candidates: List[str]
     images_i32: Optional[np.ndarray] = None
-    n_foreign_bases: int = 0
 
     def __len__(self):
         return int(self.position.shape[0])
@@ -249,8 +248,7 @@ class OutBuffers:
         cands = [raw[int(off[i]):int(off[i + 1])].decode("latin-1") for i in range(n)]
         return SummaryOut(self.region[:n].copy(), self.position[:n].copy(), self.depth[:n].copy(),
                           self.cand_freq[:n].copy(), self.images[:n].copy(), cands,
-                          None if self.images_i32 is None else self.images_i32[:n].copy(),
-                          int(self.c.n_foreign_bases))
+                          None if self.images_i32 is None else self.images_i32[:n].copy())
 
 
 def run_flat_summarizer(fn, batch: RegionBatch, params: Params, want_i32: bool = False,

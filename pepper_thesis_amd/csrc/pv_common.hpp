@@ -1,0 +1,98 @@
+// pv_common.hpp — context, workspace arena and error plumbing shared by the C-ABI translation units.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/pepper_hip.h"
+
+#define PV_VERSION_NUM 100  // 0.1.0
+
+void pv_set_error(const char* fmt, ...);
+
+#define PV_HIP(call)                                                                              \
+    do {                                                                                          \
+        hipError_t e__ = (call);                                                                  \
+        if (e__ != hipSuccess) {                                                                  \
+            pv_set_error("%s failed: %s (%s:%d)", #call, hipGetErrorString(e__), __FILE__, __LINE__); \
+            return PV_ERR_HIP;                                                                    \
+        }                                                                                         \
+    } while (0)
+
+#define PV_CHECK(cond, code, ...)    \
+    do {                             \
+        if (!(cond)) {               \
+            pv_set_error(__VA_ARGS__); \
+            return (code);           \
+        }                            \
+    } while (0)
+
+// A named, grow-only device buffer arena: one allocation per role, re-used across calls so that the
+// steady state performs no hipMalloc/hipFree (graph-capture friendly, guide G9).
+struct pv_arena {
+    struct slot {
+        void* p = nullptr;
+        size_t bytes = 0;
+    };
+    std::map<std::string, slot> slots;
+    size_t total = 0;
+
+    int get(const char* name, size_t bytes, void** out) {
+        slot& s = slots[name];
+        if (bytes > s.bytes) {
+            if (s.p) {
+                hipError_t e = hipFree(s.p);  // implicit device sync: only on growth
+                if (e != hipSuccess) { pv_set_error("hipFree(%s): %s", name, hipGetErrorString(e)); return PV_ERR_HIP; }
+                total -= s.bytes;
+                s.p = nullptr;
+                s.bytes = 0;
+            }
+            size_t want = bytes + bytes / 8 + 256;  // slack so that slightly larger batches do not realloc
+            hipError_t e = hipMalloc(&s.p, want);
+            if (e != hipSuccess) { pv_set_error("hipMalloc(%s, %zu): %s", name, want, hipGetErrorString(e)); return PV_ERR_HIP; }
+            s.bytes = want;
+            total += want;
+        }
+        *out = s.p;
+        return PV_OK;
+    }
+    void release() {
+        for (auto& kv : slots)
+            if (kv.second.p) (void)hipFree(kv.second.p);
+        slots.clear();
+        total = 0;
+    }
+};
+
+struct pv_rnn_p1;  // rnn_kernels.hip
+struct pv_rnn_p2;
+
+struct pv_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    pv_arena arena;
+    int num_cu = 256;
+    // pinned host staging for small read-backs
+    int64_t* h_counts = nullptr;
+    pv_rnn_p1* p1 = nullptr;
+    pv_rnn_p2* p2 = nullptr;
+};
+
+template <typename T>
+static inline int pv_get(pv_ctx* c, const char* name, size_t n, T** out) {
+    void* p = nullptr;
+    int rc = c->arena.get(name, n * sizeof(T), &p);
+    *out = (T*)p;
+    return rc;
+}
+
+static inline hipStream_t pv_pick_stream(pv_ctx* c, void* stream) { return stream ? (hipStream_t)stream : c->stream; }
+
+// rnn_kernels.hip
+void pv_rnn_free(pv_ctx* ctx);

@@ -1,0 +1,512 @@
+// rnn_kernels.hip — recurrent-network inference for PEPPER on gfx950 (MI355X), fp32 throughout.
+//
+// P1 (pepper_variant): images int8 [B,33,26] -> bi-LSTM(256) -> bi-LSTM(256) -> flatten 16896 ->
+//     5 x (Linear 512 + SELU) -> Linear 3 -> softmax        (reference: models/simple_model.py:48-82)
+//
+// Kernel family (one 256-thread workgroup = 4 waves, one wave per SIMD, owns a 32-row batch tile):
+//   k_lstm_layer<KP,INT8>  one launch per LSTM layer; a workgroup = (batch tile, direction). Per time
+//        step the gate pre-activations [32 x 1024] = [x_t | h_{t-1}] . [W_ih | W_hh]^T are ONE
+//        concatenated-K product on the f32 MFMA (v_mfma_f32_32x32x2_f32, bitwise an fmaf chain), so
+//        the "input-projection GEMM" and the recurrent product share accumulators and no
+//        pre-activation tensor ever goes to HBM. A operand (x_t, h_{t-1}) lives in LDS; the B operand
+//        (weights) is pre-packed on the host in exact MFMA fragment order and streamed from L2 with
+//        one coalesced 16-B load per lane per 4 MFMAs; wave w owns hidden units [64w,64w+64) for all
+//        four gates so the cell update is purely in-register (C/D layout puts i,f,g,o of one
+//        (row,unit) in the same lane and register index). c stays in registers for all 33 steps, h is
+//        exchanged between the 4 waves through a double-buffered LDS tile. XCD-aware block mapping
+//        keeps one direction's weights (<= 3 MB) per XCD L2.
+//   k_head_splitk          linear_1 (K = 16896) as a split-K MFMA product over time-step chunks,
+//        deterministic partial slabs (no float atomics).
+//   k_head_tail            sum of slabs + bias + SELU, linear_2..5 + SELU (MFMA), output layer, softmax.
+#include "pv_common.hpp"
+
+#include <cmath>
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int T_STEPS = 33;
+constexpr int F_IN = 26;
+constexpr int H = 256;            // LSTM hidden
+constexpr int ROWS = 32;          // batch rows per workgroup (one MFMA M-tile)
+constexpr int HEAD_N = 512;
+constexpr int HEAD_K = T_STEPS * 2 * H;  // 16896
+constexpr int HEAD_SPLITS = 11;          // 3 time steps (1536 k) per split
+constexpr int HEAD_STEPS_PER_SPLIT = 3;
+
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + __expf(-x)); }
+__device__ __forceinline__ float tanhf_(float x) {
+    // 1 - 2/(e^{2x}+1): absolute error ~1e-7, saturates cleanly at +-1
+    const float e = __expf(2.0f * x);
+    return 1.0f - 2.0f / (e + 1.0f);
+}
+__device__ __forceinline__ float seluf_(float x) {
+    return 1.0507009873554805f * (x > 0.0f ? x : 1.6732632423543772f * (__expf(x) - 1.0f));
+}
+
+// acc[nt] += A[32 x 8*nkb] . B  for NT column tiles of 32. A: LDS, row-major, `lda` floats per row
+// (lda % 4 == 0, lda % 64 == 4 keeps ds_read_b128 conflict-free); lane reads 16 B at
+// A[lane&31][8*kb + 4*(lane>>5)]. Bp: this wave's packed stream, NT*256 floats per k-block:
+// Bp[(kb*NT + nt)*256 + lane*4 + j] = W[n(nt,lane&31)][8*kb + 4*(lane>>5) + j].
+// MFMA j of a k-block multiplies k = 8kb + 4*(lane>>5) + j: lanes 0-31 carry k..k+3 of the low half,
+// lanes 32-63 of the high half; the K order inside a block is a permutation of 0..7, which only
+// changes the (fp32) summation order.
+template <int NT>
+__device__ __forceinline__ void mma_panel(f32x16 (&acc)[NT], const float* __restrict__ A, int lda,
+                                          const float* __restrict__ Bp, int nkb, int lane) {
+    const float* ap = A + (lane & 31) * lda + 4 * (lane >> 5);
+    const f32x4* bp = reinterpret_cast<const f32x4*>(Bp) + lane;
+    f32x4 b0[NT], b1[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; nt++) b0[nt] = bp[nt * 64];
+    int kb = 0;
+#pragma nounroll
+    for (; kb + 1 < nkb; kb += 2) {
+#pragma unroll
+        for (int nt = 0; nt < NT; nt++) b1[nt] = bp[((kb + 1) * NT + nt) * 64];
+        f32x4 a = *reinterpret_cast<const f32x4*>(ap + 8 * kb);
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+#pragma unroll
+            for (int nt = 0; nt < NT; nt++) acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j], b0[nt][j], acc[nt], 0, 0, 0);
+        if (kb + 2 < nkb) {
+#pragma unroll
+            for (int nt = 0; nt < NT; nt++) b0[nt] = bp[((kb + 2) * NT + nt) * 64];
+        }
+        a = *reinterpret_cast<const f32x4*>(ap + 8 * (kb + 1));
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+#pragma unroll
+            for (int nt = 0; nt < NT; nt++) acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j], b1[nt][j], acc[nt], 0, 0, 0);
+    }
+    if (kb < nkb) {
+        f32x4 a = *reinterpret_cast<const f32x4*>(ap + 8 * kb);
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+#pragma unroll
+            for (int nt = 0; nt < NT; nt++) acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j], b0[nt][j], acc[nt], 0, 0, 0);
+    }
+}
+
+struct LstmArgs {
+    const int8_t* x_i8;   // [B,33,26]    (encoder)
+    const float* x_f32;   // [B,33,512]   (decoder)
+    const float* wp;      // packed [2 dirs][4 waves][nkb][8][64][4]
+    const float* bias;    // [2][1024] b_ih + b_hh
+    float* out;           // [B,33,512]
+    int64_t B;
+    int n_tiles;
+};
+
+// KP = padded input width (multiple of 8): 32 for the encoder (26 real), 512 for the decoder.
+template <int KP, bool INT8>
+__global__ __launch_bounds__(256, 1) void k_lstm_layer(LstmArgs a) {
+    constexpr int LDX = KP + 4, LDH = H + 4;
+    constexpr int NKB_X = KP / 8, NKB_H = H / 8;
+    extern __shared__ float smem[];
+    float* xbuf = smem;                 // [32][LDX]
+    float* hbuf = smem + ROWS * LDX;    // [2][32][LDH]
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    // XCD-aware mapping: blocks b and b+8 share an XCD (round-robin dispatch); give every XCD one
+    // direction only so that its L2 holds a single direction's packed weights.
+    const int xcd = blockIdx.x & 7;
+    const int dir = xcd & 1;
+    const int tile = (blockIdx.x >> 3) * 4 + (xcd >> 1);
+    if (tile >= a.n_tiles) return;
+    const int64_t b0 = (int64_t)tile * ROWS;
+    const float* wp = a.wp + ((size_t)(dir * 4 + wv) * (NKB_X + NKB_H)) * 8 * 256;
+    const float* bias = a.bias + dir * 4 * H;
+
+    for (int i = tid; i < 2 * ROWS * LDH; i += 256) hbuf[i] = 0.0f;
+    f32x16 cst[2];
+#pragma unroll
+    for (int s2 = 0; s2 < 2; s2++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) cst[s2][r] = 0.0f;
+    float bs[8];
+#pragma unroll
+    for (int nt = 0; nt < 8; nt++) bs[nt] = bias[(nt >> 1) * H + 64 * wv + 32 * (nt & 1) + (lane & 31)];
+
+    for (int s = 0; s < T_STEPS; s++) {
+        const int t = dir ? (T_STEPS - 1 - s) : s;
+        const int cur = s & 1, nxt = cur ^ 1;
+        // ---- stage x_t ---------------------------------------------------------------------------
+        if constexpr (INT8) {
+            for (int i = tid; i < ROWS * KP; i += 256) {
+                const int row = i / KP, k = i - row * KP;
+                int64_t b = b0 + row;
+                if (b >= a.B) b = a.B - 1;
+                xbuf[row * LDX + k] = k < F_IN ? (float)a.x_i8[(b * T_STEPS + t) * F_IN + k] : 0.0f;
+            }
+        } else {
+            constexpr int V4 = KP / 4;  // float4 per row
+#pragma unroll 4
+            for (int i = tid; i < ROWS * V4; i += 256) {
+                const int row = i / V4, c4 = i - row * V4;
+                int64_t b = b0 + row;
+                if (b >= a.B) b = a.B - 1;
+                const f32x4 v = *reinterpret_cast<const f32x4*>(a.x_f32 + (b * T_STEPS + t) * (int64_t)KP + c4 * 4);
+                *reinterpret_cast<f32x4*>(xbuf + row * LDX + c4 * 4) = v;
+            }
+        }
+        __syncthreads();
+        // ---- gates = bias + [x_t | h_{t-1}] . [W_ih | W_hh]^T -------------------------------------
+        f32x16 acc[8];
+#pragma unroll
+        for (int nt = 0; nt < 8; nt++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[nt][r] = bs[nt];
+        mma_panel<8>(acc, xbuf, LDX, wp, NKB_X, lane);
+        mma_panel<8>(acc, hbuf + cur * ROWS * LDH, LDH, wp + (size_t)NKB_X * 8 * 256, NKB_H, lane);
+        // ---- cell update (PyTorch gate order i,f,g,o; nt = gate*2 + sub-tile) ---------------------
+        float* hn = hbuf + nxt * ROWS * LDH;
+#pragma unroll
+        for (int s2 = 0; s2 < 2; s2++) {
+            const int unit = 64 * wv + 32 * s2 + (lane & 31);
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const float ig = sigmoidf_(acc[0 + s2][r]);
+                const float fg = sigmoidf_(acc[2 + s2][r]);
+                const float gg = tanhf_(acc[4 + s2][r]);
+                const float og = sigmoidf_(acc[6 + s2][r]);
+                const float c = fg * cst[s2][r] + ig * gg;
+                cst[s2][r] = c;
+                const float h = og * tanhf_(c);
+                const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                hn[row * LDH + unit] = h;
+                const int64_t b = b0 + row;
+                if (b < a.B) a.out[(b * T_STEPS + t) * (int64_t)(2 * H) + dir * H + unit] = h;
+            }
+        }
+        __syncthreads();
+    }
+}
+
+struct HeadArgs {
+    const float* dec;     // [B,33,512]
+    const float* w1p;     // packed linear_1 [4 waves][2112 kb][4][64][4]
+    float* part;          // [HEAD_SPLITS][B][512]
+    int64_t B;
+    int n_tiles;
+};
+
+__global__ __launch_bounds__(256, 1) void k_head_splitk(HeadArgs a) {
+    constexpr int KC = 2 * H;  // 512 k per time step
+    constexpr int LDA = KC + 4;
+    extern __shared__ float smem[];
+    float* abuf = smem;  // [32][LDA]
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int tile = blockIdx.x / HEAD_SPLITS, split = blockIdx.x - tile * HEAD_SPLITS;
+    const int64_t b0 = (int64_t)tile * ROWS;
+    f32x16 acc[4];
+#pragma unroll
+    for (int nt = 0; nt < 4; nt++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) acc[nt][r] = 0.0f;
+    for (int st = 0; st < HEAD_STEPS_PER_SPLIT; st++) {
+        const int t = split * HEAD_STEPS_PER_SPLIT + st;
+        constexpr int V4 = KC / 4;
+        __syncthreads();
+#pragma unroll 4
+        for (int i = tid; i < ROWS * V4; i += 256) {
+            const int row = i / V4, c4 = i - row * V4;
+            int64_t b = b0 + row;
+            if (b >= a.B) b = a.B - 1;
+            *reinterpret_cast<f32x4*>(abuf + row * LDA + c4 * 4) =
+                *reinterpret_cast<const f32x4*>(a.dec + (b * T_STEPS + t) * (int64_t)KC + c4 * 4);
+        }
+        __syncthreads();
+        const float* wp = a.w1p + ((size_t)wv * (HEAD_K / 8) + (size_t)t * (KC / 8)) * 4 * 256;
+        mma_panel<4>(acc, abuf, LDA, wp, KC / 8, lane);
+    }
+    float* dst = a.part + (size_t)split * a.B * HEAD_N;
+#pragma unroll
+    for (int nt = 0; nt < 4; nt++) {
+        const int n = 128 * wv + 32 * nt + (lane & 31);
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const int64_t b = b0 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            if (b < a.B) dst[b * HEAD_N + n] = acc[nt][r];
+        }
+    }
+}
+
+struct TailArgs {
+    const float* part;   // [HEAD_SPLITS][B][512]
+    const float* b1;     // [512]
+    const float* wp[4];  // packed linear_2..5 [4 waves][64 kb][4][64][4]
+    const float* b[4];   // [512]
+    const float* wo;     // [3][512]
+    const float* bo;     // [3]
+    float* probs;        // [B,3]
+    int64_t B;
+};
+
+__global__ __launch_bounds__(256, 1) void k_head_tail(TailArgs a) {
+    constexpr int LDY = HEAD_N + 4;
+    extern __shared__ float smem[];
+    float* y0 = smem;               // [32][LDY]
+    float* y1 = smem + ROWS * LDY;  // [32][LDY]
+    __shared__ float logits[ROWS][4];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int64_t b0 = (int64_t)blockIdx.x * ROWS;
+    // y0 = selu(sum of slabs + b1)   (simple_model.py:57-59)
+    for (int i = tid; i < ROWS * HEAD_N; i += 256) {
+        const int row = i / HEAD_N, n = i - row * HEAD_N;
+        int64_t b = b0 + row;
+        if (b >= a.B) b = a.B - 1;
+        float v = a.b1[n];
+#pragma unroll
+        for (int s = 0; s < HEAD_SPLITS; s++) v += a.part[((size_t)s * a.B + b) * HEAD_N + n];
+        y0[row * LDY + n] = seluf_(v);
+    }
+    __syncthreads();
+    float* src = y0;
+    float* dst = y1;
+    for (int layer = 0; layer < 4; layer++) {  // linear_2..5 + SELU (:61-76)
+        f32x16 acc[4];
+#pragma unroll
+        for (int nt = 0; nt < 4; nt++) {
+            const float bv = a.b[layer][128 * wv + 32 * nt + (lane & 31)];
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[nt][r] = bv;
+        }
+        mma_panel<4>(acc, src, LDY, a.wp[layer] + (size_t)wv * (HEAD_N / 8) * 4 * 256, HEAD_N / 8, lane);
+#pragma unroll
+        for (int nt = 0; nt < 4; nt++) {
+            const int n = 128 * wv + 32 * nt + (lane & 31);
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                dst[row * LDY + n] = seluf_(acc[nt][r]);
+            }
+        }
+        __syncthreads();
+        float* tmp = src; src = dst; dst = tmp;
+    }
+    // output_layer_type (512 -> 3) + softmax(dim=1) (:77-82): 8 lanes per (row, class) pair
+    {
+        const int pair = tid >> 3, sub = tid & 7;  // 32 pairs per pass
+        for (int p = pair; p < ROWS * 3; p += 32) {
+            const int row = p / 3, cls = p - row * 3;
+            float s = 0.0f;
+            for (int k = sub; k < HEAD_N; k += 8) s += src[row * LDY + k] * a.wo[cls * HEAD_N + k];
+            s += __shfl_xor(s, 4, 64);
+            s += __shfl_xor(s, 2, 64);
+            s += __shfl_xor(s, 1, 64);
+            if (sub == 0) logits[row][cls] = s + a.bo[cls];
+        }
+    }
+    __syncthreads();
+    if (tid < ROWS) {
+        const int64_t b = b0 + tid;
+        if (b < a.B) {
+            const float l0 = logits[tid][0], l1 = logits[tid][1], l2 = logits[tid][2];
+            const float m = fmaxf(l0, fmaxf(l1, l2));
+            const float e0 = expf(l0 - m), e1 = expf(l1 - m), e2 = expf(l2 - m);
+            const float inv = 1.0f / (e0 + e1 + e2);
+            a.probs[b * 3 + 0] = e0 * inv;
+            a.probs[b * 3 + 1] = e1 * inv;
+            a.probs[b * 3 + 2] = e2 * inv;
+        }
+    }
+}
+
+// ---- host-side weight packing -----------------------------------------------------------------------
+// LSTM layer: gate column of (wave w, tile nt, lane) = (nt>>1)*H + 64w + 32(nt&1) + (lane&31)
+static void pack_lstm(const pv_rnn_dir* dirs, int K, int KP, std::vector<float>& wp, std::vector<float>& bias) {
+    const int nkb = (KP + H) / 8;
+    wp.assign((size_t)2 * 4 * nkb * 8 * 256, 0.0f);
+    bias.assign((size_t)2 * 4 * H, 0.0f);
+    for (int d = 0; d < 2; d++) {
+        for (int n = 0; n < 4 * H; n++) bias[(size_t)d * 4 * H + n] = dirs[d].b_ih[n] + dirs[d].b_hh[n];
+        for (int w = 0; w < 4; w++)
+            for (int kb = 0; kb < nkb; kb++)
+                for (int nt = 0; nt < 8; nt++)
+                    for (int lane = 0; lane < 64; lane++) {
+                        const int n = (nt >> 1) * H + 64 * w + 32 * (nt & 1) + (lane & 31);
+                        float* dst = &wp[((((size_t)(d * 4 + w) * nkb + kb) * 8 + nt) * 64 + lane) * 4];
+                        for (int j = 0; j < 4; j++) {
+                            const int k = kb * 8 + 4 * (lane >> 5) + j;
+                            float v = 0.0f;
+                            if (k < KP) { if (k < K) v = dirs[d].w_ih[(size_t)n * K + k]; }
+                            else v = dirs[d].w_hh[(size_t)n * H + (k - KP)];
+                            dst[j] = v;
+                        }
+                    }
+    }
+}
+// Linear [512, K]: column of (wave w, tile nt, lane) = 128w + 32nt + (lane&31)
+static void pack_linear(const float* W, int K, std::vector<float>& wp) {
+    const int nkb = K / 8;
+    wp.assign((size_t)4 * nkb * 4 * 256, 0.0f);
+    for (int w = 0; w < 4; w++)
+        for (int kb = 0; kb < nkb; kb++)
+            for (int nt = 0; nt < 4; nt++)
+                for (int lane = 0; lane < 64; lane++) {
+                    const int n = 128 * w + 32 * nt + (lane & 31);
+                    float* dst = &wp[((((size_t)w * nkb + kb) * 4 + nt) * 64 + lane) * 4];
+                    for (int j = 0; j < 4; j++) dst[j] = W[(size_t)n * K + kb * 8 + 4 * (lane >> 5) + j];
+                }
+}
+
+}  // namespace
+
+struct pv_rnn_p1 {
+    float* enc_wp = nullptr; float* enc_bias = nullptr;
+    float* dec_wp = nullptr; float* dec_bias = nullptr;
+    float* w1p = nullptr; float* b1 = nullptr;
+    float* wlp[4] = {nullptr, nullptr, nullptr, nullptr};
+    float* bl[4] = {nullptr, nullptr, nullptr, nullptr};
+    float* wo = nullptr; float* bo = nullptr;
+    int dtype = PV_DTYPE_F32;
+    std::vector<void*> owned;
+};
+struct pv_rnn_p2 {
+    std::vector<void*> owned;
+};
+
+static int dev_upload(const std::vector<float>& h, float** d, std::vector<void*>& owned) {
+    PV_HIP(hipMalloc((void**)d, h.size() * sizeof(float)));
+    owned.push_back(*d);
+    PV_HIP(hipMemcpy(*d, h.data(), h.size() * sizeof(float), hipMemcpyHostToDevice));
+    return PV_OK;
+}
+static int dev_upload(const float* h, size_t n, float** d, std::vector<void*>& owned) {
+    PV_HIP(hipMalloc((void**)d, n * sizeof(float)));
+    owned.push_back(*d);
+    PV_HIP(hipMemcpy(*d, h, n * sizeof(float), hipMemcpyHostToDevice));
+    return PV_OK;
+}
+
+void pv_rnn_free(pv_ctx* ctx) {
+    if (ctx->p1) {
+        for (void* p : ctx->p1->owned) (void)hipFree(p);
+        delete ctx->p1;
+        ctx->p1 = nullptr;
+    }
+    if (ctx->p2) {
+        for (void* p : ctx->p2->owned) (void)hipFree(p);
+        delete ctx->p2;
+        ctx->p2 = nullptr;
+    }
+}
+
+extern "C" int pv_rnn_load_p1(pv_ctx* ctx, const pv_weights_p1* w, int dtype) {
+    PV_CHECK(ctx && w, PV_ERR_INVALID, "null argument");
+    PV_CHECK(dtype == PV_DTYPE_F32, PV_ERR_INVALID, "dtype %d not implemented (only PV_DTYPE_F32)", dtype);
+    for (int d = 0; d < 2; d++) {
+        PV_CHECK(w->encoder[d].w_ih && w->encoder[d].w_hh && w->encoder[d].b_ih && w->encoder[d].b_hh &&
+                     w->decoder[d].w_ih && w->decoder[d].w_hh && w->decoder[d].b_ih && w->decoder[d].b_hh,
+                 PV_ERR_INVALID, "missing LSTM tensor");
+    }
+    for (int i = 0; i < 5; i++) PV_CHECK(w->linear_w[i] && w->linear_b[i], PV_ERR_INVALID, "missing linear_%d", i + 1);
+    PV_CHECK(w->out_w && w->out_b, PV_ERR_INVALID, "missing output layer");
+    PV_HIP(hipSetDevice(ctx->device));
+    if (ctx->p1) {
+        PV_HIP(hipStreamSynchronize(ctx->stream));
+        for (void* p : ctx->p1->owned) (void)hipFree(p);
+        delete ctx->p1;
+        ctx->p1 = nullptr;
+    }
+    pv_rnn_p1* m = new pv_rnn_p1();
+    ctx->p1 = m;
+    m->dtype = dtype;
+    std::vector<float> wp, bias;
+    int rc;
+    pack_lstm(w->encoder, F_IN, 32, wp, bias);
+    if ((rc = dev_upload(wp, &m->enc_wp, m->owned)) || (rc = dev_upload(bias, &m->enc_bias, m->owned))) return rc;
+    pack_lstm(w->decoder, 2 * H, 2 * H, wp, bias);
+    if ((rc = dev_upload(wp, &m->dec_wp, m->owned)) || (rc = dev_upload(bias, &m->dec_bias, m->owned))) return rc;
+    pack_linear(w->linear_w[0], HEAD_K, wp);
+    if ((rc = dev_upload(wp, &m->w1p, m->owned)) || (rc = dev_upload(w->linear_b[0], HEAD_N, &m->b1, m->owned))) return rc;
+    for (int i = 0; i < 4; i++) {
+        pack_linear(w->linear_w[i + 1], HEAD_N, wp);
+        if ((rc = dev_upload(wp, &m->wlp[i], m->owned)) || (rc = dev_upload(w->linear_b[i + 1], HEAD_N, &m->bl[i], m->owned)))
+            return rc;
+    }
+    if ((rc = dev_upload(w->out_w, 3 * HEAD_N, &m->wo, m->owned)) || (rc = dev_upload(w->out_b, 3, &m->bo, m->owned))) return rc;
+    // opt in to large dynamic LDS once
+    PV_HIP(hipFuncSetAttribute((const void*)k_lstm_layer<32, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    PV_HIP(hipFuncSetAttribute((const void*)k_lstm_layer<512, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    PV_HIP(hipFuncSetAttribute((const void*)k_head_splitk, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    PV_HIP(hipFuncSetAttribute((const void*)k_head_tail, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    return PV_OK;
+}
+
+static int p1_forward_launch(pv_ctx* ctx, const int8_t* d_images, int64_t B, float* d_probs, float* enc_out,
+                             float* dec_out, float* part, hipStream_t st) {
+    pv_rnn_p1* m = ctx->p1;
+    const int n_tiles = (int)((B + ROWS - 1) / ROWS);
+    const unsigned lstm_grid = (unsigned)(((n_tiles + 3) / 4) * 8);
+    LstmArgs e;
+    e.x_i8 = d_images; e.x_f32 = nullptr; e.wp = m->enc_wp; e.bias = m->enc_bias; e.out = enc_out; e.B = B; e.n_tiles = n_tiles;
+    const size_t lds_enc = (size_t)(ROWS * (32 + 4) + 2 * ROWS * (H + 4)) * sizeof(float);
+    k_lstm_layer<32, true><<<lstm_grid, 256, lds_enc, st>>>(e);
+    LstmArgs d = e;
+    d.x_i8 = nullptr; d.x_f32 = enc_out; d.wp = m->dec_wp; d.bias = m->dec_bias; d.out = dec_out;
+    const size_t lds_dec = (size_t)(ROWS * (2 * H + 4) + 2 * ROWS * (H + 4)) * sizeof(float);
+    k_lstm_layer<512, false><<<lstm_grid, 256, lds_dec, st>>>(d);
+    HeadArgs h;
+    h.dec = dec_out; h.w1p = m->w1p; h.part = part; h.B = B; h.n_tiles = n_tiles;
+    k_head_splitk<<<(unsigned)(n_tiles * HEAD_SPLITS), 256, (size_t)ROWS * (2 * H + 4) * sizeof(float), st>>>(h);
+    TailArgs t;
+    t.part = part; t.b1 = m->b1;
+    for (int i = 0; i < 4; i++) { t.wp[i] = m->wlp[i]; t.b[i] = m->bl[i]; }
+    t.wo = m->wo; t.bo = m->bo; t.probs = d_probs; t.B = B;
+    k_head_tail<<<(unsigned)n_tiles, 256, (size_t)2 * ROWS * (HEAD_N + 4) * sizeof(float), st>>>(t);
+    PV_HIP(hipGetLastError());
+    return PV_OK;
+}
+
+static int p1_workspace(pv_ctx* ctx, int64_t B, float** enc, float** dec, float** part) {
+    int rc;
+    if ((rc = pv_get(ctx, "p1.enc_out", (size_t)B * T_STEPS * 2 * H, enc))) return rc;
+    if ((rc = pv_get(ctx, "p1.dec_out", (size_t)B * T_STEPS * 2 * H, dec))) return rc;
+    if ((rc = pv_get(ctx, "p1.part", (size_t)HEAD_SPLITS * B * HEAD_N, part))) return rc;
+    return PV_OK;
+}
+
+extern "C" int pv_rnn_forward_p1_dev(pv_ctx* ctx, const int8_t* d_images, int64_t B, float* d_probs, void* stream) {
+    PV_CHECK(ctx && d_images && d_probs, PV_ERR_INVALID, "null argument");
+    PV_CHECK(ctx->p1, PV_ERR_STATE, "pv_rnn_load_p1 has not been called on this context");
+    PV_CHECK(B >= 0 && B < (1ll << 24), PV_ERR_INVALID, "batch %lld out of range", (long long)B);
+    if (B == 0) return PV_OK;
+    PV_HIP(hipSetDevice(ctx->device));
+    float *enc, *dec, *part;
+    int rc = p1_workspace(ctx, B, &enc, &dec, &part);
+    if (rc) return rc;
+    return p1_forward_launch(ctx, d_images, B, d_probs, enc, dec, part, pv_pick_stream(ctx, stream));
+}
+
+extern "C" int pv_rnn_forward_p1_debug(pv_ctx* ctx, const int8_t* images, int64_t B, float* probs, float* enc_out,
+                                       float* dec_out) {
+    PV_CHECK(ctx && images && probs, PV_ERR_INVALID, "null argument");
+    PV_CHECK(ctx->p1, PV_ERR_STATE, "pv_rnn_load_p1 has not been called on this context");
+    PV_CHECK(B >= 0 && B < (1ll << 24), PV_ERR_INVALID, "batch %lld out of range", (long long)B);
+    if (B == 0) return PV_OK;
+    PV_HIP(hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    float *enc, *dec, *part, *d_probs;
+    int8_t* d_img;
+    int rc = p1_workspace(ctx, B, &enc, &dec, &part);
+    if (rc) return rc;
+    if ((rc = pv_get(ctx, "p1.images", (size_t)B * PV_WINDOW_BYTES, &d_img))) return rc;
+    if ((rc = pv_get(ctx, "p1.probs", (size_t)B * 3, &d_probs))) return rc;
+    PV_HIP(hipMemcpyAsync(d_img, images, (size_t)B * PV_WINDOW_BYTES, hipMemcpyHostToDevice, st));
+    if ((rc = p1_forward_launch(ctx, d_img, B, d_probs, enc, dec, part, st))) return rc;
+    PV_HIP(hipMemcpyAsync(probs, d_probs, (size_t)B * 3 * sizeof(float), hipMemcpyDeviceToHost, st));
+    const size_t nb = (size_t)B * T_STEPS * 2 * H * sizeof(float);
+    if (enc_out) PV_HIP(hipMemcpyAsync(enc_out, enc, nb, hipMemcpyDeviceToHost, st));
+    if (dec_out) PV_HIP(hipMemcpyAsync(dec_out, dec, nb, hipMemcpyDeviceToHost, st));
+    PV_HIP(hipStreamSynchronize(st));
+    return PV_OK;
+}
+
+extern "C" int pv_rnn_forward_p1(pv_ctx* ctx, const int8_t* images, int64_t B, float* probs) {
+    return pv_rnn_forward_p1_debug(ctx, images, B, probs, nullptr, nullptr);
+}
+
+// ---- P2 (bi-GRU polisher model): see rnn_gru.hip ----------------------------------------------------

@@ -1,0 +1,946 @@
+// summary_kernels.hip — the pileup summary-image builder on gfx950 (MI355X).
+//
+// Replaces RegionalSummaryGenerator::generate_summary + populate_summary_matrix
+// (reference: pepper_variant/modules/cpp/region_summary.cpp:337-566, 568-916) for a whole BATCH of
+// regions per call. It is an HBM-bound integer pipeline; nothing here is GEMM-shaped.
+//
+// Data layout in HBM (column = one reference position; global column id = ref_off[g] + i):
+//   cnt[NCNT][n_cols] int32, PLANE-MAJOR, so that the 64 lanes of a wave that walk 64 consecutive
+//   read bases touch 64 consecutive ints of one plane (coalesced atomics / loads):
+//     0 coverage  1 snp_count  2 insert_count  3 delete_count  4 rare-event count
+//     5 + 8*strand + {0 REF, 1 A, 2 C, 3 G, 4 T, 5 I, 6 D, 7 *}   (the 16 accumulated planes of the
+//     reference's 26; planes 0-3,5-7,16-18 are constants or overlays and are never stored)
+//   the clamp of planes 11..24 (region_summary.cpp:648-653) is applied when windows are gathered, so
+//   the raw counters stay available as exact SNP allele counts.
+//
+// Pipeline (all on one stream, no host round trip in the middle):
+//   k_cigar_scan     wave per read: prefix sums over CIGAR ops -> per-op (column, read index)
+//   k_pileup         wave per 64 ops: load-balanced expansion of aligned bases over lanes; counters
+//   k_site_scan      thread per column: frequency thresholds -> site flags, per-block site counts
+//   k_scan_*         single-block exclusive scans (tiny arrays)
+//   k_site_rank      column -> site rank, site list, per-site event bucket sizes
+//   k_collect        lane per op: second walk over the CIGAR stream only; allele events of SITES
+//   k_site_alleles   wave per site: dedupe + order alleles like std::set<std::string>, filters
+//   k_write_windows  wave per site: gather 33x26, clamp, overlays, int8 cast, metadata, keys
+//
+// Allele keys never leave their source: an allele is (type, length, pointer into bases/ref), compared
+// bytewise exactly as std::string operator< would compare "<type digit><bytes>".
+#include "pv_common.hpp"
+
+namespace {
+
+constexpr int NCNT = 21;
+constexpr int C_COV = 0, C_SNP = 1, C_INS = 2, C_DEL = 3, C_RARE = 4, C_PLANE = 5;
+constexpr int32_t OP_INACTIVE = 0x7fffffff;
+constexpr int UMAX = 1024;  // distinct alleles per site held in LDS
+
+enum { D_NSITES = 0, D_NEVENTS = 1, D_NOUT = 2, D_STRBYTES = 3, D_STATUS = 4, D_NDIAG = 8 };
+
+struct Event {  // 16 B
+    int64_t src;  // index into bases (kind 1) or ref (kind 2)
+    int32_t len;
+    uint8_t type;   // 1 SNP 2 INS 3 DEL
+    uint8_t rev;
+    uint8_t kind;   // 1 bases, 2 ref
+    uint8_t flags;  // bit0: is an allele observation; bit1: plane correction (lower-case acgt counted in an ACGT plane)
+};
+
+struct AlleleRec {  // 32 B
+    int64_t src;
+    int32_t len;
+    int32_t total;
+    int32_t fwd;
+    int32_t rev;
+    uint8_t type;
+    uint8_t kind;  // 0 immediate byte, 1 bases, 2 ref
+    uint8_t imm;
+    uint8_t pad;
+    int32_t pad2;
+};
+
+struct SumArgs {
+    pv_batch_in in;
+    pv_params p;
+    int64_t n_reads, n_bases, n_cigar, n_cols;
+    int32_t* op_ref;
+    int32_t* op_rd;
+    int32_t* op_read;
+    uint8_t* op_flag;
+    int32_t* read_region;
+    int32_t* cnt;
+    uint8_t* flags;
+    int32_t* site_rank;
+    int32_t* blk_cnt;
+    int32_t* blk_off;
+    int32_t* site_col;
+    int32_t* site_region;
+    int32_t* site_nev;
+    int32_t* site_evoff;
+    int32_t* site_fill;
+    int32_t* site_nemit;
+    int64_t* site_strbytes;
+    int32_t* site_outoff;
+    int64_t* site_stroff;
+    Event* ev;
+    AlleleRec* rec;
+    int64_t* diag;
+    int64_t max_sites;
+    int64_t max_events;
+    pv_batch_out out;
+    int64_t* d_counts;
+};
+
+__device__ __forceinline__ int up(int c) { return (c >= 'a' && c <= 'z') ? c - 32 : c; }
+__device__ __forceinline__ bool is_acgt(int c) { return c == 'A' || c == 'C' || c == 'G' || c == 'T'; }
+// offset of get_feature_index's result from its strand start (region_summary.cpp:208-215): A1 C2 G3 T4 I5 D6 other 7
+__device__ __forceinline__ int sym_of(int c) {
+    c = up(c);
+    return c == 'A' ? 1 : c == 'C' ? 2 : c == 'G' ? 3 : c == 'T' ? 4 : c == 'I' ? 5 : c == 'D' ? 6 : 7;
+}
+__device__ __forceinline__ int refcode(int c) {  // get_reference_feature_value, :165-172
+    c = up(c);
+    return c == 'A' ? 1 : c == 'C' ? 2 : c == 'G' ? 3 : c == 'T' ? 4 : 5;
+}
+__device__ __forceinline__ void set_status(int64_t* diag, int code) {
+    atomicCAS((unsigned long long*)&diag[D_STATUS], 0ull, (unsigned long long)(long long)code);
+}
+__device__ __forceinline__ int upper_bound_i64(const int64_t* a, int n, int64_t v) {  // first idx with a[idx] > v
+    int lo = 0, hi = n;
+    while (lo < hi) {
+        int mid = (lo + hi) >> 1;
+        if (a[mid] <= v) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+}
+
+__device__ __forceinline__ int64_t wave_incl_scan(int64_t v, int lane) {
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        int64_t t = __shfl_up(v, d, 64);
+        if (lane >= d) v += t;
+    }
+    return v;
+}
+__device__ __forceinline__ int wave_incl_scan32(int v, int lane) {
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        int t = __shfl_up(v, d, 64);
+        if (lane >= d) v += t;
+    }
+    return v;
+}
+
+// ---- K1 -------------------------------------------------------------------------------------------
+// One wave per read. CIGAR semantics of populate_summary_matrix (:353-565): M/=/X consume both,
+// I and S consume the read, D consumes the reference, N and P consume BOTH (the REF_SKIP/PAD cases
+// fall through into SOFT_CLIP, :556-561), H/B/unknown consume nothing. The walk stops at the first
+// op that starts beyond ref_end (:355); those ops are marked inactive.
+__global__ __launch_bounds__(256) void k_cigar_scan(SumArgs a) {
+    const int lane = threadIdx.x & 63;
+    const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= a.n_reads) return;
+    const int g = upper_bound_i64(a.in.read_off, a.in.n_regions + 1, r) - 1;
+    if (lane == 0) a.read_region[r] = g;
+    const int64_t c0 = a.in.cigar_off[r], c1 = a.in.cigar_off[r + 1];
+    const bool skip = a.in.read_mapq[r] == 0;  // :619
+    const int64_t R = a.in.ref_end[g] - a.in.ref_start[g] + 1;
+    if (!skip && a.in.base_off[r + 1] - a.in.base_off[r] <= 0 && lane == 0) set_status(a.diag, PV_ERR_INVALID);
+    int64_t ref_rel = a.in.read_pos[r] - a.in.ref_start[g];
+    int64_t rd = 0;
+    for (int64_t cb = c0; cb < c1; cb += 64) {
+        const int64_t c = cb + lane;
+        uint32_t w = c < c1 ? a.in.cigar[c] : 0u;
+        const int op = w & 0xF;
+        const int64_t len = c < c1 ? (int64_t)(w >> 4) : 0;
+        const bool cr = (op == 0 || op == 7 || op == 8 || op == 2 || op == 3 || op == 6);
+        const bool cq = (op == 0 || op == 7 || op == 8 || op == 1 || op == 4 || op == 3 || op == 6);
+        const int64_t dr = cr ? len : 0, dq = cq ? len : 0;
+        const int64_t ir = wave_incl_scan(dr, lane), iq = wave_incl_scan(dq, lane);
+        const int64_t my_ref = ref_rel + ir - dr, my_rd = rd + iq - dq;
+        if (c < c1) {
+            const bool active = !skip && my_ref < R;
+            if (active && (my_ref < -(1ll << 30) || my_rd > (1ll << 30))) set_status(a.diag, PV_ERR_LIMIT);
+            a.op_ref[c] = active ? (int32_t)my_ref : OP_INACTIVE;
+            a.op_rd[c] = (int32_t)my_rd;
+            a.op_read[c] = (int32_t)r;
+            a.op_flag[c] = 0;
+        }
+        ref_rel += __shfl(ir, 63, 64);
+        rd += __shfl(iq, 63, 64);
+    }
+}
+
+// ---- K2 -------------------------------------------------------------------------------------------
+struct OpCtx {  // what a lane knows about "its" op
+    int32_t ref_rel, rd, len, op;
+    int32_t col_base, R;
+    int64_t base0, seq_end;  // global index of this read's first base / one past its last
+    int64_t ref_len;
+    bool rev, active, anchor_next;
+};
+
+__device__ __forceinline__ OpCtx load_op(const SumArgs& a, int64_t c) {
+    OpCtx o;
+    o.active = false;
+    o.len = 0; o.op = 15; o.ref_rel = 0; o.rd = 0; o.col_base = 0; o.R = 0; o.base0 = 0; o.seq_end = 0;
+    o.ref_len = 0; o.rev = false; o.anchor_next = false;
+    if (c >= a.n_cigar) return o;
+    const int32_t rr = a.op_ref[c];
+    if (rr == OP_INACTIVE) return o;
+    const uint32_t w = a.in.cigar[c];
+    const int32_t r = a.op_read[c];
+    const int g = a.read_region[r];
+    o.active = true;
+    o.op = w & 0xF;
+    o.len = (int32_t)(w >> 4);
+    o.ref_rel = rr;
+    o.rd = a.op_rd[c];
+    o.col_base = (int32_t)a.in.ref_off[g];
+    o.ref_len = a.in.ref_off[g + 1] - a.in.ref_off[g];
+    o.R = (int32_t)(a.in.ref_end[g] - a.in.ref_start[g] + 1);
+    o.base0 = a.in.base_off[r];
+    o.seq_end = a.in.base_off[r + 1];
+    o.rev = (a.in.read_flags[r] & 1) != 0;
+    const bool last = (c + 1 == a.in.cigar_off[r + 1]);
+    if (!last) {
+        const int nop = a.in.cigar[c + 1] & 0xF;
+        o.anchor_next = (nop == PV_CIGAR_IN || nop == PV_CIGAR_DEL);  // :381-391
+    }
+    return o;
+}
+
+__global__ __launch_bounds__(256) void k_pileup(SumArgs a) {
+    __shared__ int32_t s_pref[4][64];
+    __shared__ int32_t s_col0[4][64];   // column of op offset 0
+    __shared__ int64_t s_base[4][64];   // global base index of op offset 0
+    __shared__ int64_t s_end[4][64];
+    __shared__ int32_t s_i0[4][64];
+    __shared__ int32_t s_meta[4][64];   // len-1 (31 bits would overflow: see below) packed separately
+    __shared__ uint8_t s_fl[4][64];     // bit0 rev, bit1 anchor_next
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int64_t c = ((int64_t)blockIdx.x * 4 + wv) * 64 + lane;
+    const OpCtx o = load_op(a, c);  // no early exit on status here: every wave must reach the barrier below
+    int32_t* cnt = a.cnt;
+    const int64_t NC = a.n_cols;
+    const int sbase = C_PLANE + (o.rev ? 8 : 0);
+
+    // (1) indel ops: one lane each
+    if (o.active && o.op == PV_CIGAR_IN) {  // :431-490
+        const int64_t anchor = (int64_t)o.ref_rel - 1;
+        if (anchor >= 0 && anchor < o.R && o.rd >= 1) {
+            const int64_t col = o.col_base + anchor;
+            const int64_t start = o.base0 + o.rd - 1;
+            const int64_t L = (int64_t)o.len + 1;
+            if (start + L > o.seq_end) {
+                set_status(a.diag, PV_ERR_INVALID);
+            } else {
+                int64_t qs = 0;
+                for (int64_t i = 0; i < L; i++) qs += a.in.quals[start + i];
+                const bool qok = (double)qs >= a.p.min_indel_baseq * (double)L;
+                if (qok && (double)a.in.quals[start] < a.p.min_snp_baseq) atomicAdd(&cnt[C_COV * NC + col], 1);  // :453
+                if (1 + L <= PV_MAX_ALLELE_KEY && qok) {
+                    if (is_acgt(up(a.in.ref[col]))) atomicAdd(&cnt[(sbase + 5) * NC + col], -1);
+                    atomicAdd(&cnt[C_INS * NC + col], 1);
+                    a.op_flag[c] = 1;
+                }
+            }
+        }
+    } else if (o.active && o.op == PV_CIGAR_DEL) {  // :491-555
+        const int64_t anchor = (int64_t)o.ref_rel - 1;
+        if (anchor >= 0 && anchor < o.R) {
+            const int64_t col = o.col_base + anchor;
+            if (is_acgt(up(a.in.ref[col]))) atomicAdd(&cnt[(sbase + 6) * NC + col], -1);  // unconditional, :496
+            int64_t L = (int64_t)o.len + 1;
+            if (anchor + L > o.ref_len) L = o.ref_len - anchor;  // substr truncation, :500
+            if (1 + L <= PV_MAX_ALLELE_KEY) {
+                atomicAdd(&cnt[C_DEL * NC + col], 1);
+                a.op_flag[c] = 1;
+            }
+        }
+        int64_t i0 = o.ref_rel < 0 ? -(int64_t)o.ref_rel : 0;
+        int64_t i1 = (int64_t)o.R - o.ref_rel;
+        if (i1 > o.len) i1 = o.len;
+        for (int64_t i = i0; i < i1; i++) {  // :542-552
+            const int64_t col = o.col_base + o.ref_rel + i;
+            if (is_acgt(up(a.in.ref[col]))) atomicAdd(&cnt[(sbase + 7) * NC + col], -1);
+        }
+    }
+
+    // (2) aligned bases: expand the in-region part of every M/=/X op of this chunk over the lanes
+    const bool is_m = o.active && (o.op == PV_CIGAR_MATCH || o.op == PV_CIGAR_EQUAL || o.op == PV_CIGAR_DIFF);
+    int32_t i0 = 0, eff = 0;
+    if (is_m) {
+        int64_t lo = o.ref_rel < 0 ? -(int64_t)o.ref_rel : 0;
+        int64_t hi = (int64_t)o.R - o.ref_rel;
+        if (hi > o.len) hi = o.len;
+        if (hi > lo) { i0 = (int32_t)lo; eff = (int32_t)(hi - lo); }
+    }
+    const int32_t incl = wave_incl_scan32(eff, lane);
+    s_pref[wv][lane] = incl;
+    s_col0[wv][lane] = o.col_base + o.ref_rel;
+    s_base[wv][lane] = o.base0 + o.rd;
+    s_end[wv][lane] = o.seq_end;
+    s_i0[wv][lane] = i0 - (incl - eff);  // so that i = j + s_i0
+    s_meta[wv][lane] = o.len - 1;
+    s_fl[wv][lane] = (uint8_t)((o.rev ? 1 : 0) | (o.anchor_next ? 2 : 0));
+    __syncthreads();
+    const int32_t total = s_pref[wv][63];
+    for (int32_t j = lane; j < total; j += 64) {
+        int lo = 0, hi = 63;  // first lane whose inclusive prefix exceeds j
+#pragma unroll
+        for (int it = 0; it < 6; it++) {
+            const int mid = (lo + hi) >> 1;
+            if (s_pref[wv][mid] > j) hi = mid; else lo = mid + 1;
+        }
+        const int ow = lo;
+        const int32_t i = j + s_i0[wv][ow];
+        const int64_t col = (int64_t)s_col0[wv][ow] + i;
+        const int64_t bi = s_base[wv][ow] + i;
+        if (bi >= s_end[wv][ow]) { set_status(a.diag, PV_ERR_INVALID); continue; }
+        const int fl = s_fl[wv][ow];
+        const int base = a.in.bases[bi];
+        const int q = a.in.quals[bi];
+        const int refb = a.in.ref[col];
+        const bool qok = (double)q >= a.p.min_snp_baseq;
+        if (!qok) continue;
+        const int pb = C_PLANE + ((fl & 1) ? 8 : 0);
+        atomicAdd(&cnt[C_COV * NC + col], 1);                                        // :379
+        if (!((fl & 2) && i == s_meta[wv][ow])) atomicAdd(&cnt[pb * NC + col], -1);  // :381-391 REFF/REFR
+        const bool refvalid = is_acgt(up(refb));
+        if (refvalid) atomicAdd(&cnt[(pb + sym_of(base)) * NC + col], -1);          // :396,423
+        const bool mism = refb != base;                                              // raw bytes, :394
+        if (mism) atomicAdd(&cnt[C_SNP * NC + col], 1);
+        const bool rare = mism && !(refvalid && is_acgt(base));
+        const bool corr = refvalid && base != up(base) && is_acgt(up(base));
+        if (rare || corr) atomicAdd(&cnt[C_RARE * NC + col], 1);
+    }
+}
+
+// ---- K3 -------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void k_site_scan(SumArgs a) {
+    const int64_t col = (int64_t)blockIdx.x * 1024 + threadIdx.x;
+    int site = 0;
+    if (col < a.n_cols) {
+        const int g = upper_bound_i64(a.in.ref_off, a.in.n_regions + 1, col) - 1;
+        const int64_t i = col - a.in.ref_off[g];
+        const int64_t R = a.in.ref_end[g] - a.in.ref_start[g] + 1;
+        uint8_t f = 0;
+        if (g >= 0 && g < a.in.n_regions && i < R) {  // :634-646
+            const int64_t NC = a.n_cols;
+            const int cov = a.cnt[C_COV * NC + col];
+            const double cv = (double)cov > 1.0 ? (double)cov : 1.0;
+            const double fs = (double)a.cnt[C_SNP * NC + col] / cv;
+            const double fi = (double)a.cnt[C_INS * NC + col] / cv;
+            const double fd = (double)a.cnt[C_DEL * NC + col] / cv;
+            const bool ps = fs >= a.p.snp_freq_threshold, pi = fi >= a.p.insert_freq_threshold,
+                       pd = fd >= a.p.delete_freq_threshold;
+            const int64_t pos = a.in.ref_start[g] + i;
+            if ((ps || pi || pd) && pos >= a.in.cand_start[g] && pos <= a.in.cand_end[g] &&
+                (double)cov >= a.p.min_coverage_threshold)
+                f = (uint8_t)(1 | (ps ? 2 : 0) | (pi ? 4 : 0) | (pd ? 8 : 0));
+        }
+        a.flags[col] = f;
+        site = f & 1;
+    }
+    const int n = __syncthreads_count(site);
+    if (threadIdx.x == 0) a.blk_cnt[blockIdx.x] = n;
+}
+
+// single-block exclusive scan of n (read from device if n_ptr) int32 values; total -> *total_out (int64)
+__global__ __launch_bounds__(1024) void k_scan_i32(const int32_t* in, int32_t* out, int64_t n_fixed,
+                                                   const int64_t* n_ptr, int64_t n_cap, int64_t* total_out) {
+    __shared__ int32_t s_w[16];
+    __shared__ int64_t s_carry;
+    int64_t n = n_ptr ? *n_ptr : n_fixed;
+    if (n > n_cap) n = n_cap;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    if (threadIdx.x == 0) s_carry = 0;
+    __syncthreads();
+    for (int64_t b = 0; b < n; b += 1024) {
+        const int64_t i = b + threadIdx.x;
+        const int32_t v = i < n ? in[i] : 0;
+        const int32_t inc = wave_incl_scan32(v, lane);
+        if (lane == 63) s_w[wv] = inc;
+        __syncthreads();
+        int32_t woff = 0;
+        for (int k = 0; k < wv; k++) woff += s_w[k];
+        const int64_t carry = s_carry;
+        if (i < n) out[i] = (int32_t)(carry + woff + inc - v);
+        __syncthreads();
+        if (threadIdx.x == 1023) s_carry = carry + woff + inc;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0 && total_out) *total_out = s_carry;
+}
+
+__global__ __launch_bounds__(1024) void k_scan_i64(const int64_t* in, int64_t* out, const int64_t* n_ptr, int64_t n_cap,
+                                                   int64_t* total_out) {
+    __shared__ int64_t s_w[16];
+    __shared__ int64_t s_carry;
+    int64_t n = *n_ptr;
+    if (n > n_cap) n = n_cap;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    if (threadIdx.x == 0) s_carry = 0;
+    __syncthreads();
+    for (int64_t b = 0; b < n; b += 1024) {
+        const int64_t i = b + threadIdx.x;
+        const int64_t v = i < n ? in[i] : 0;
+        const int64_t inc = wave_incl_scan(v, lane);
+        if (lane == 63) s_w[wv] = inc;
+        __syncthreads();
+        int64_t woff = 0;
+        for (int k = 0; k < wv; k++) woff += s_w[k];
+        const int64_t carry = s_carry;
+        if (i < n) out[i] = carry + woff + inc - v;
+        __syncthreads();
+        if (threadIdx.x == 1023) s_carry = carry + woff + inc;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0 && total_out) *total_out = s_carry;
+}
+
+__global__ __launch_bounds__(1024) void k_site_rank(SumArgs a) {
+    __shared__ int32_t s_w[16];
+    const int64_t col = (int64_t)blockIdx.x * 1024 + threadIdx.x;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int f = col < a.n_cols ? a.flags[col] : 0;
+    const int site = f & 1;
+    const unsigned long long m = __ballot(site);
+    const int before = __popcll(m & ((1ull << lane) - 1ull));
+    if (lane == 0) s_w[wv] = __popcll(m);
+    __syncthreads();
+    int woff = 0;
+    for (int k = 0; k < wv; k++) woff += s_w[k];
+    const int32_t rank = a.blk_off[blockIdx.x] + woff + before;
+    if (col < a.n_cols) a.site_rank[col] = rank;
+    if (site && rank < a.max_sites) {
+        const int64_t NC = a.n_cols;
+        a.site_col[rank] = (int32_t)col;
+        a.site_region[rank] = upper_bound_i64(a.in.ref_off, a.in.n_regions + 1, col) - 1;
+        a.site_nev[rank] = a.cnt[C_INS * NC + col] + a.cnt[C_DEL * NC + col] + a.cnt[C_RARE * NC + col];
+        a.site_fill[rank] = 0;
+    }
+}
+
+__global__ void k_check_limits(SumArgs a) {
+    if (a.diag[D_NSITES] > a.max_sites || a.diag[D_NEVENTS] > a.max_events) set_status(a.diag, PV_ERR_LIMIT);
+}
+
+// ---- K5 -------------------------------------------------------------------------------------------
+__device__ __forceinline__ void push_event(const SumArgs& a, int32_t s, int64_t src, int32_t len, int type, bool rev,
+                                           int kind, int flags) {
+    const int32_t slot = atomicAdd(&a.site_fill[s], 1);
+    if (slot >= a.site_nev[s]) { set_status(a.diag, PV_ERR_INVALID); return; }  // cannot happen: exact bucket sizes
+    Event e;
+    e.src = src; e.len = len; e.type = (uint8_t)type; e.rev = rev ? 1 : 0; e.kind = (uint8_t)kind; e.flags = (uint8_t)flags;
+    a.ev[(int64_t)a.site_evoff[s] + slot] = e;
+}
+
+__global__ __launch_bounds__(256) void k_collect(SumArgs a) {
+    const int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (a.diag[D_STATUS] != 0) return;
+    const OpCtx o = load_op(a, c);
+    if (!o.active) return;
+    if (o.op == PV_CIGAR_IN) {
+        if (!a.op_flag[c]) return;
+        const int64_t col = (int64_t)o.col_base + o.ref_rel - 1;
+        if (a.flags[col] & 1) push_event(a, a.site_rank[col], o.base0 + o.rd - 1, o.len + 1, 2, o.rev, 1, 1);
+    } else if (o.op == PV_CIGAR_DEL) {
+        if (!a.op_flag[c]) return;
+        const int64_t anchor = (int64_t)o.ref_rel - 1;
+        const int64_t col = o.col_base + anchor;
+        int64_t L = (int64_t)o.len + 1;
+        if (anchor + L > o.ref_len) L = o.ref_len - anchor;
+        if (a.flags[col] & 1) push_event(a, a.site_rank[col], col, (int32_t)L, 3, o.rev, 2, 1);
+    } else if (o.op == PV_CIGAR_MATCH || o.op == PV_CIGAR_EQUAL || o.op == PV_CIGAR_DIFF) {
+        int64_t lo = o.ref_rel < 0 ? -(int64_t)o.ref_rel : 0;
+        int64_t hi = (int64_t)o.R - o.ref_rel;
+        if (hi > o.len) hi = o.len;
+        if (hi <= lo) return;
+        const int64_t ca = (int64_t)o.col_base + o.ref_rel + lo;      // first column
+        const int64_t cb = (int64_t)o.col_base + o.ref_rel + hi - 1;  // last column
+        const int32_t s0 = a.site_rank[ca];
+        const int32_t s1 = a.site_rank[cb] + (a.flags[cb] & 1);
+        for (int32_t s = s0; s < s1; s++) {
+            const int64_t col = a.site_col[s];
+            if (a.cnt[C_RARE * a.n_cols + col] == 0) continue;
+            const int64_t i = col - ((int64_t)o.col_base + o.ref_rel);
+            const int64_t bi = o.base0 + o.rd + i;
+            if (bi >= o.seq_end) continue;  // already reported by k_pileup
+            const int base = a.in.bases[bi];
+            if (!((double)a.in.quals[bi] >= a.p.min_snp_baseq)) continue;
+            const int refb = a.in.ref[col];
+            const bool refvalid = is_acgt(up(refb));
+            const bool rare = (refb != base) && !(refvalid && is_acgt(base));
+            const bool corr = refvalid && base != up(base) && is_acgt(up(base));
+            if (rare || corr) push_event(a, s, bi, 1, 1, o.rev, 1, (rare ? 1 : 0) | (corr ? 2 : 0));
+        }
+    }
+}
+
+// ---- K6 -------------------------------------------------------------------------------------------
+struct Key {
+    int64_t src;
+    int32_t len;
+    uint8_t type, kind, imm;
+};
+__device__ __forceinline__ int key_byte(const SumArgs& a, const Key& k, int i) {
+    return k.kind == 0 ? k.imm : (k.kind == 1 ? a.in.bases[k.src + i] : a.in.ref[k.src + i]);
+}
+// std::string compare of "<type digit><bytes>"
+__device__ __forceinline__ int key_cmp(const SumArgs& a, const Key& x, const Key& y) {
+    if (x.type != y.type) return x.type < y.type ? -1 : 1;
+    const int m = x.len < y.len ? x.len : y.len;
+    for (int i = 0; i < m; i++) {
+        const int bx = key_byte(a, x, i), by = key_byte(a, y, i);
+        if (bx != by) return bx < by ? -1 : 1;
+    }
+    if (x.len != y.len) return x.len < y.len ? -1 : 1;
+    return 0;
+}
+
+__global__ __launch_bounds__(64) void k_site_alleles(SumArgs a) {
+    __shared__ int64_t u_src[UMAX];
+    __shared__ int32_t u_len[UMAX];
+    __shared__ int32_t u_fwd[UMAX];
+    __shared__ int32_t u_rev[UMAX];
+    __shared__ uint8_t u_type[UMAX];
+    __shared__ uint8_t u_kind[UMAX];
+    __shared__ uint8_t u_imm[UMAX];
+    __shared__ uint8_t u_ok[UMAX];
+    __shared__ int16_t u_order[UMAX];
+    __shared__ int32_t s_nU;
+    const int lane = threadIdx.x;
+    if (a.diag[D_STATUS] != 0) return;
+    int64_t n_sites = a.diag[D_NSITES];
+    if (n_sites > a.max_sites) n_sites = a.max_sites;
+    for (int64_t s = blockIdx.x; s < n_sites; s += gridDim.x) {
+        const int64_t col = a.site_col[s];
+        const int64_t NC = a.n_cols;
+        const int f = a.flags[col];
+        const int cov = a.cnt[C_COV * NC + col];
+        const int depth = cov < PV_MAX_COLOR ? cov : PV_MAX_COLOR;  // :682
+        const int refraw = a.in.ref[col];
+        const bool refvalid = is_acgt(up(refraw));
+        __syncthreads();
+        // slots 0..3: SNP alleles whose counts are the (negated, un-clamped) A/C/G/T planes
+        if (lane < 4) {
+            const int b = "ACGT"[lane];
+            u_src[lane] = 0; u_len[lane] = 1; u_type[lane] = 1; u_kind[lane] = 0; u_imm[lane] = (uint8_t)b;
+            const bool ok = refvalid && b != refraw;
+            u_ok[lane] = ok;
+            u_fwd[lane] = ok ? -a.cnt[(C_PLANE + 1 + lane) * NC + col] : 0;
+            u_rev[lane] = ok ? -a.cnt[(C_PLANE + 8 + 1 + lane) * NC + col] : 0;
+        }
+        if (lane == 0) s_nU = 4;
+        __syncthreads();
+        const int nev = a.site_nev[s];
+        const int64_t eoff = a.site_evoff[s];
+        for (int eb = 0; eb < nev; eb += 64) {
+            const bool have = eb + lane < nev;
+            Event e;
+            e.src = 0; e.len = 0; e.type = 0; e.rev = 0; e.kind = 1; e.flags = 0;
+            if (have) e = a.ev[eoff + eb + lane];
+            if (have && (e.flags & 2)) {  // lower-case acgt was counted in plane toupper(): take it back out
+                const int ub = up(a.in.bases[e.src]);
+                const int sl = ub == 'A' ? 0 : ub == 'C' ? 1 : ub == 'G' ? 2 : 3;
+                if (u_ok[sl]) atomicAdd(e.rev ? &u_rev[sl] : &u_fwd[sl], -1);
+            }
+            bool pending = have && (e.flags & 1);
+            Key ke; ke.src = e.src; ke.len = e.len; ke.type = e.type; ke.kind = e.kind; ke.imm = 0;
+            int checked = 4;  // slots 0..3 can never equal an event key (see k_pileup: those are not events)
+            while (true) {
+                const int nU = s_nU;
+                if (pending) {
+                    for (int k = checked; k < nU; k++) {
+                        Key ku; ku.src = u_src[k]; ku.len = u_len[k]; ku.type = u_type[k]; ku.kind = u_kind[k]; ku.imm = u_imm[k];
+                        if (ku.type == ke.type && ku.len == ke.len && key_cmp(a, ku, ke) == 0) {
+                            atomicAdd(e.rev ? &u_rev[k] : &u_fwd[k], 1);
+                            pending = false;
+                            break;
+                        }
+                    }
+                }
+                checked = nU;
+                const unsigned long long m = __ballot(pending);
+                if (m == 0) break;
+                const int leader = __ffsll((long long)m) - 1;
+                if (lane == leader) {
+                    if (nU < UMAX) {
+                        u_src[nU] = ke.src; u_len[nU] = ke.len; u_type[nU] = ke.type; u_kind[nU] = ke.kind; u_imm[nU] = 0;
+                        u_ok[nU] = 1; u_fwd[nU] = e.rev ? 0 : 1; u_rev[nU] = e.rev ? 1 : 0;
+                        s_nU = nU + 1;
+                    } else {
+                        set_status(a.diag, PV_ERR_LIMIT);
+                    }
+                    pending = false;
+                }
+                __syncthreads();
+            }
+            __syncthreads();
+        }
+        __syncthreads();
+        const int nU = s_nU;
+        // order like std::set<std::string> (:670): rank among the observed alleles
+        int nV = 0;
+        for (int kb = 0; kb < nU; kb += 64) {
+            const int k = kb + lane;
+            const bool live = k < nU && u_ok[k] && (u_fwd[k] + u_rev[k]) > 0;
+            if (live) {
+                Key kk; kk.src = u_src[k]; kk.len = u_len[k]; kk.type = u_type[k]; kk.kind = u_kind[k]; kk.imm = u_imm[k];
+                int rank = 0;
+                for (int j = 0; j < nU; j++) {
+                    if (j == k || !u_ok[j] || (u_fwd[j] + u_rev[j]) <= 0) continue;
+                    Key kj; kj.src = u_src[j]; kj.len = u_len[j]; kj.type = u_type[j]; kj.kind = u_kind[j]; kj.imm = u_imm[j];
+                    if (key_cmp(a, kj, kk) < 0) rank++;
+                }
+                u_order[rank] = (int16_t)k;
+            }
+            nV += __popcll(__ballot(live));
+        }
+        __syncthreads();
+        // filters (:682-712) in set order; survivors become allele records
+        const int64_t recbase = eoff + 4 * s;
+        int nemit = 0;
+        int64_t sbytes = 0;
+        for (int rb = 0; rb < nV; rb += 64) {
+            const int r = rb + lane;
+            bool keep = false;
+            int k = 0;
+            if (r < nV) {
+                k = u_order[r];
+                const int total = u_fwd[k] + u_rev[k];
+                const int t = u_type[k];
+                const double dd = (double)depth > 1.0 ? (double)depth : 1.0;
+                const double freq = (double)total / dd;
+                keep = true;
+                if ((double)total < a.p.candidate_support_threshold) keep = false;
+                if (t != 1 && freq < a.p.indel_candidate_freq_threshold) keep = false;
+                if (t == 1 && freq < a.p.snp_candidate_freq_threshold) keep = false;
+                if (t != 1 && a.p.skip_indels) keep = false;
+                if ((t == 1 && !(f & 2)) || (t == 2 && !(f & 4)) || (t == 3 && !(f & 8))) keep = false;
+            }
+            const unsigned long long m = __ballot(keep);
+            if (keep) {
+                const int e = nemit + __popcll(m & ((1ull << lane) - 1ull));
+                AlleleRec rc;
+                rc.src = u_src[k]; rc.len = u_len[k]; rc.total = u_fwd[k] + u_rev[k]; rc.fwd = u_fwd[k]; rc.rev = u_rev[k];
+                rc.type = u_type[k]; rc.kind = u_kind[k]; rc.imm = u_imm[k]; rc.pad = 0; rc.pad2 = 0;
+                a.rec[recbase + e] = rc;
+            }
+            nemit += __popcll(m);
+            int64_t b = keep ? 1 + u_len[k] : 0;
+            for (int d = 32; d >= 1; d >>= 1) b += __shfl_xor(b, d, 64);
+            sbytes += b;
+        }
+        if (lane == 0) {
+            a.site_nemit[s] = nemit;
+            a.site_strbytes[s] = sbytes;
+        }
+    }
+}
+
+__global__ void k_publish_counts(SumArgs a) {
+    a.d_counts[0] = a.diag[D_NOUT];
+    a.d_counts[1] = a.diag[D_STRBYTES];
+    a.d_counts[2] = a.diag[D_STATUS];
+    a.d_counts[3] = a.diag[D_NSITES];
+}
+
+// ---- K8 -------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_write_windows(SumArgs a) {
+    const int lane = threadIdx.x;
+    if (a.diag[D_STATUS] != 0) return;
+    int64_t n_sites = a.diag[D_NSITES];
+    if (n_sites > a.max_sites) n_sites = a.max_sites;
+    const int64_t NC = a.n_cols;
+    for (int64_t s = blockIdx.x; s < n_sites; s += gridDim.x) {
+        const int nemit = a.site_nemit[s];
+        if (nemit == 0) continue;
+        const int64_t col = a.site_col[s];
+        const int g = a.site_region[s];
+        const int64_t col_base = a.in.ref_off[g];
+        const int64_t R = a.in.ref_end[g] - a.in.ref_start[g] + 1;
+        const int64_t ci = col - col_base;
+        const int cov = a.cnt[C_COV * NC + col];
+        const int depth = cov < PV_MAX_COLOR ? cov : PV_MAX_COLOR;
+        const int refraw = a.in.ref[col];
+        const bool refvalid = is_acgt(up(refraw));
+        const int64_t recbase = (int64_t)a.site_evoff[s] + 4 * s;
+        int64_t so = a.site_stroff[s];
+        for (int e = 0; e < nemit; e++) {
+            const AlleleRec rc = a.rec[recbase + e];
+            const int64_t k = (int64_t)a.site_outoff[s] + e;
+            const int64_t send = so + 1 + rc.len;
+            if (k < a.out.capacity && send <= a.out.str_capacity) {
+                const int cfwd = rc.fwd < PV_MAX_COLOR ? rc.fwd : PV_MAX_COLOR;
+                const int crev = rc.rev < PV_MAX_COLOR ? rc.rev : PV_MAX_COLOR;
+                const int clen = rc.len < PV_MAX_COLOR ? rc.len : PV_MAX_COLOR;
+                int alt = 0, ff = -1, fr = -1;
+                if (rc.type == 1) {
+                    alt = rc.kind == 0 ? rc.imm : a.in.bases[rc.src];
+                    if (refvalid) { ff = 7 + sym_of(alt); fr = 18 + sym_of(alt); }
+                } else if (rc.type == 2) {
+                    if (refvalid) { ff = 12; fr = 23; }
+                } else {
+                    if (refvalid) { ff = 13; fr = 24; }
+                }
+                int end_index = 16 + rc.len - 1;  // :885
+                if (end_index > 31) end_index = 31;
+                for (int el = lane; el < PV_WINDOW_BYTES; el += 64) {
+                    const int row = el / PV_FEATURES, pl = el - row * PV_FEATURES;
+                    const int64_t i = ci - 16 + row;
+                    int v = 0;
+                    if (i >= 0 && i < R) {  // row R of the reference's matrix exists and is all zero (:835)
+                        const int64_t c2 = col_base + i;
+                        if (pl == 0) v = refcode(a.in.ref[c2]);
+                        else if (pl == 4) v = a.cnt[(C_PLANE + 0) * NC + c2];
+                        else if (pl >= 8 && pl <= 14) v = a.cnt[(C_PLANE + 1 + (pl - 8)) * NC + c2];
+                        else if (pl == 15) v = a.cnt[(C_PLANE + 8) * NC + c2];
+                        else if (pl >= 19) v = a.cnt[(C_PLANE + 8 + 1 + (pl - 19)) * NC + c2];
+                        if (pl >= 11 && pl <= 24) v = v > PV_MAX_COLOR ? PV_MAX_COLOR : (v < -PV_MAX_COLOR ? -PV_MAX_COLOR : v);  // :648-653
+                    }
+                    if (row == 16) {  // :848-894
+                        if (rc.type == 1) {
+                            if (pl == 1) v = refcode(alt);
+                            if (pl == 5) v = cfwd;
+                            if (pl == 16) v = crev;
+                        } else if (rc.type == 2) {
+                            if (pl == 2) v = clen;
+                            if (pl == 6) v = cfwd;
+                            if (pl == 17) v = crev;
+                        } else {
+                            if (pl == 3) v = clen;
+                            if (pl == 7) v = cfwd;
+                            if (pl == 18) v = crev;
+                        }
+                        if (pl == ff || pl == fr) v = -v;
+                    } else if (rc.type == 3 && row > 16 && row <= end_index) {  // :895-904
+                        if (pl == 3) v = clen;
+                        if (pl == 7) v = cfwd;
+                        if (pl == 18) v = crev;
+                        if (refvalid && (pl == 14 || pl == 25)) v = -v;
+                    }
+                    a.out.images[k * PV_WINDOW_BYTES + el] = (int8_t)(uint8_t)(v & 0xFF);  // DataStore.py:68 wrap
+                    if (a.out.images_i32) a.out.images_i32[k * PV_WINDOW_BYTES + el] = v;
+                }
+                if (lane == 0) {
+                    a.out.region[k] = g;
+                    a.out.position[k] = a.in.ref_start[g] + ci;
+                    a.out.depth[k] = (uint8_t)depth;
+                    a.out.cand_freq[k] = (uint8_t)(rc.total < PV_MAX_COLOR ? rc.total : PV_MAX_COLOR);
+                    a.out.cand_off[k] = so;
+                    a.out.cand_off[k + 1] = send;
+                    a.out.cand_str[so] = (char)('0' + rc.type);
+                }
+                for (int i = lane; i < rc.len; i += 64) {
+                    const int b = rc.kind == 0 ? rc.imm : (rc.kind == 1 ? a.in.bases[rc.src + i] : a.in.ref[rc.src + i]);
+                    a.out.cand_str[so + 1 + i] = (char)b;
+                }
+            }
+            so = send;
+        }
+    }
+}
+
+__global__ void k_zero_diag(int64_t* diag) {
+    if (threadIdx.x < D_NDIAG) diag[threadIdx.x] = 0;
+}
+
+}  // namespace
+
+static inline unsigned int grid_for(int64_t n, int per) { return (unsigned int)((n + per - 1) / per); }
+
+// Workspace + launch sequence. Everything asynchronous on `st`.
+static int summarize_launch(pv_ctx* ctx, const pv_batch_in* in, const pv_params* params, int64_t n_reads,
+                            int64_t n_bases, int64_t n_cigar, int64_t n_cols, int64_t max_sites, int64_t max_events,
+                            const pv_batch_out* out, int64_t* d_counts, hipStream_t st) {
+    PV_CHECK(params->candidate_window_size == 32 && params->feature_size == PV_FEATURES, PV_ERR_INVALID,
+             "candidate_window_size must be 32 and feature_size 26 (got %d, %d)", params->candidate_window_size,
+             params->feature_size);
+    PV_CHECK(n_cols < (1ll << 31) - 2048 && n_cigar < (1ll << 31) && n_reads < (1ll << 31), PV_ERR_LIMIT,
+             "batch too large for 32-bit column/op indices (cols %lld, ops %lld)", (long long)n_cols, (long long)n_cigar);
+    SumArgs a;
+    memset(&a, 0, sizeof(a));
+    a.in = *in;
+    a.p = *params;
+    a.n_reads = n_reads; a.n_bases = n_bases; a.n_cigar = n_cigar; a.n_cols = n_cols;
+    a.max_sites = max_sites; a.max_events = max_events;
+    a.out = *out;
+    a.d_counts = d_counts;
+    const int64_t n_blk = (n_cols + 1023) / 1024;
+    int rc;
+    const int64_t nc1 = n_cigar > 0 ? n_cigar : 1, nr1 = n_reads > 0 ? n_reads : 1;
+    if ((rc = pv_get(ctx, "sum.op_ref", nc1, &a.op_ref))) return rc;
+    if ((rc = pv_get(ctx, "sum.op_rd", nc1, &a.op_rd))) return rc;
+    if ((rc = pv_get(ctx, "sum.op_read", nc1, &a.op_read))) return rc;
+    if ((rc = pv_get(ctx, "sum.op_flag", nc1, &a.op_flag))) return rc;
+    if ((rc = pv_get(ctx, "sum.read_region", nr1, &a.read_region))) return rc;
+    if ((rc = pv_get(ctx, "sum.cnt", (size_t)NCNT * n_cols, &a.cnt))) return rc;
+    if ((rc = pv_get(ctx, "sum.flags", n_cols, &a.flags))) return rc;
+    if ((rc = pv_get(ctx, "sum.site_rank", n_cols, &a.site_rank))) return rc;
+    if ((rc = pv_get(ctx, "sum.blk_cnt", n_blk, &a.blk_cnt))) return rc;
+    if ((rc = pv_get(ctx, "sum.blk_off", n_blk, &a.blk_off))) return rc;
+    if ((rc = pv_get(ctx, "sum.site_col", max_sites, &a.site_col))) return rc;
+    if ((rc = pv_get(ctx, "sum.site_region", max_sites, &a.site_region))) return rc;
+    if ((rc = pv_get(ctx, "sum.site_nev", max_sites, &a.site_nev))) return rc;
+    if ((rc = pv_get(ctx, "sum.site_evoff", max_sites, &a.site_evoff))) return rc;
+    if ((rc = pv_get(ctx, "sum.site_fill", max_sites, &a.site_fill))) return rc;
+    if ((rc = pv_get(ctx, "sum.site_nemit", max_sites, &a.site_nemit))) return rc;
+    if ((rc = pv_get(ctx, "sum.site_strbytes", max_sites, &a.site_strbytes))) return rc;
+    if ((rc = pv_get(ctx, "sum.site_outoff", max_sites, &a.site_outoff))) return rc;
+    if ((rc = pv_get(ctx, "sum.site_stroff", max_sites, &a.site_stroff))) return rc;
+    if ((rc = pv_get(ctx, "sum.ev", max_events, &a.ev))) return rc;
+    if ((rc = pv_get(ctx, "sum.rec", max_events + 4 * max_sites, &a.rec))) return rc;
+    if ((rc = pv_get(ctx, "sum.diag", (size_t)D_NDIAG, &a.diag))) return rc;
+
+    k_zero_diag<<<1, 64, 0, st>>>(a.diag);
+    PV_HIP(hipMemsetAsync(a.cnt, 0, (size_t)NCNT * n_cols * sizeof(int32_t), st));
+    if (n_reads > 0) k_cigar_scan<<<grid_for(n_reads, 4), 256, 0, st>>>(a);
+    if (n_cigar > 0) k_pileup<<<grid_for(n_cigar, 256), 256, 0, st>>>(a);
+    k_site_scan<<<(unsigned)n_blk, 1024, 0, st>>>(a);
+    k_scan_i32<<<1, 1024, 0, st>>>(a.blk_cnt, a.blk_off, n_blk, nullptr, n_blk, &a.diag[D_NSITES]);
+    k_site_rank<<<(unsigned)n_blk, 1024, 0, st>>>(a);
+    k_scan_i32<<<1, 1024, 0, st>>>(a.site_nev, a.site_evoff, 0, &a.diag[D_NSITES], max_sites, &a.diag[D_NEVENTS]);
+    k_check_limits<<<1, 1, 0, st>>>(a);
+    if (n_cigar > 0) k_collect<<<grid_for(n_cigar, 256), 256, 0, st>>>(a);
+    const unsigned site_grid = (unsigned)(max_sites < 4096 ? (max_sites > 0 ? max_sites : 1) : 4096);
+    k_site_alleles<<<site_grid, 64, 0, st>>>(a);
+    k_scan_i32<<<1, 1024, 0, st>>>(a.site_nemit, a.site_outoff, 0, &a.diag[D_NSITES], max_sites, &a.diag[D_NOUT]);
+    k_scan_i64<<<1, 1024, 0, st>>>(a.site_strbytes, a.site_stroff, &a.diag[D_NSITES], max_sites, &a.diag[D_STRBYTES]);
+    k_write_windows<<<site_grid, 64, 0, st>>>(a);
+    k_publish_counts<<<1, 1, 0, st>>>(a);
+    PV_HIP(hipGetLastError());
+    return PV_OK;
+}
+
+static void default_limits(int64_t n_cols, int64_t n_cigar, int64_t n_bases, int64_t capacity, int64_t* max_sites,
+                           int64_t* max_events) {
+    int64_t s = n_cols / 8 + 1024;
+    if (s < 2 * capacity) s = 2 * capacity;
+    if (s > n_cols) s = n_cols;
+    if (s < 1) s = 1;
+    *max_sites = s;
+    *max_events = n_cigar + n_bases / 64 + 4096;
+}
+
+extern "C" int pv_summarize_regions_dev(pv_ctx* ctx, const pv_batch_in* in, const pv_params* params, int64_t n_reads,
+                                        int64_t n_bases, int64_t n_cigar, int64_t n_ref_bytes, int64_t max_region_len,
+                                        pv_batch_out* out, int64_t* d_counts, void* stream) {
+    PV_CHECK(ctx && in && params && out && d_counts, PV_ERR_INVALID, "null argument");
+    PV_CHECK(in->n_regions >= 0 && n_ref_bytes >= 0, PV_ERR_INVALID, "negative sizes");
+    (void)max_region_len;
+    PV_HIP(hipSetDevice(ctx->device));
+    int64_t ms, me;
+    default_limits(n_ref_bytes, n_cigar, n_bases, out->capacity, &ms, &me);
+    return summarize_launch(ctx, in, params, n_reads, n_bases, n_cigar, n_ref_bytes > 0 ? n_ref_bytes : 1, ms, me, out,
+                            d_counts, pv_pick_stream(ctx, stream));
+}
+
+template <typename T>
+static int upload(pv_ctx* ctx, const char* name, const T* h, size_t n, const T** d, hipStream_t st) {
+    T* p = nullptr;
+    int rc = pv_get(ctx, name, n ? n : 1, &p);
+    if (rc) return rc;
+    if (n) PV_HIP(hipMemcpyAsync(p, h, n * sizeof(T), hipMemcpyHostToDevice, st));
+    *d = p;
+    return PV_OK;
+}
+
+extern "C" int pv_summarize_regions(pv_ctx* ctx, const pv_batch_in* in, const pv_params* params, pv_batch_out* out) {
+    PV_CHECK(ctx && in && params && out, PV_ERR_INVALID, "null argument");
+    PV_HIP(hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    const int G = in->n_regions;
+    out->n_out = 0;
+    out->str_bytes = 0;
+    if (out->capacity > 0 && out->cand_off) out->cand_off[0] = 0;
+    if (G <= 0) return PV_OK;
+    // host-side validation of the offset arrays (cheap: O(regions + reads))
+    const int64_t n_reads = in->read_off[G], n_cols = in->ref_off[G];
+    PV_CHECK(in->read_off[0] == 0 && in->ref_off[0] == 0 && n_reads >= 0, PV_ERR_INVALID, "offset arrays must start at 0");
+    for (int g = 0; g < G; g++) {
+        const int64_t R = in->ref_end[g] - in->ref_start[g] + 1;
+        PV_CHECK(R >= 1 && in->ref_off[g + 1] - in->ref_off[g] >= R, PV_ERR_INVALID,
+                 "region %d: reference shorter than ref_end-ref_start+1", g);
+        PV_CHECK(in->read_off[g + 1] >= in->read_off[g], PV_ERR_INVALID, "read_off not monotone");
+    }
+    const int64_t n_bases = n_reads ? in->base_off[n_reads] : 0, n_cigar = n_reads ? in->cigar_off[n_reads] : 0;
+    for (int64_t r = 0; r < n_reads; r++)
+        PV_CHECK(in->base_off[r + 1] >= in->base_off[r] && in->cigar_off[r + 1] >= in->cigar_off[r], PV_ERR_INVALID,
+                 "read %lld: offsets not monotone", (long long)r);
+
+    pv_batch_in d = *in;
+    int rc;
+    if ((rc = upload(ctx, "in.ref_start", in->ref_start, G, &d.ref_start, st))) return rc;
+    if ((rc = upload(ctx, "in.ref_end", in->ref_end, G, &d.ref_end, st))) return rc;
+    if ((rc = upload(ctx, "in.cand_start", in->cand_start, G, &d.cand_start, st))) return rc;
+    if ((rc = upload(ctx, "in.cand_end", in->cand_end, G, &d.cand_end, st))) return rc;
+    if ((rc = upload(ctx, "in.ref_off", in->ref_off, G + 1, &d.ref_off, st))) return rc;
+    if ((rc = upload(ctx, "in.ref", in->ref, n_cols, &d.ref, st))) return rc;
+    if ((rc = upload(ctx, "in.read_off", in->read_off, G + 1, &d.read_off, st))) return rc;
+    if ((rc = upload(ctx, "in.read_pos", in->read_pos, n_reads, &d.read_pos, st))) return rc;
+    if ((rc = upload(ctx, "in.read_flags", in->read_flags, n_reads, &d.read_flags, st))) return rc;
+    if ((rc = upload(ctx, "in.read_mapq", in->read_mapq, n_reads, &d.read_mapq, st))) return rc;
+    if ((rc = upload(ctx, "in.base_off", in->base_off, n_reads + 1, &d.base_off, st))) return rc;
+    if ((rc = upload(ctx, "in.bases", in->bases, n_bases, &d.bases, st))) return rc;
+    if ((rc = upload(ctx, "in.quals", in->quals, n_bases, &d.quals, st))) return rc;
+    if ((rc = upload(ctx, "in.cigar_off", in->cigar_off, n_reads + 1, &d.cigar_off, st))) return rc;
+    if ((rc = upload(ctx, "in.cigar", in->cigar, n_cigar, &d.cigar, st))) return rc;
+
+    const int64_t cap = out->capacity > 0 ? out->capacity : 0, scap = out->str_capacity > 0 ? out->str_capacity : 0;
+    pv_batch_out dout = *out;
+    if ((rc = pv_get(ctx, "out.region", cap + 1, &dout.region))) return rc;
+    if ((rc = pv_get(ctx, "out.position", cap + 1, &dout.position))) return rc;
+    if ((rc = pv_get(ctx, "out.depth", cap + 1, &dout.depth))) return rc;
+    if ((rc = pv_get(ctx, "out.cand_freq", cap + 1, &dout.cand_freq))) return rc;
+    if ((rc = pv_get(ctx, "out.images", (size_t)(cap + 1) * PV_WINDOW_BYTES, &dout.images))) return rc;
+    dout.images_i32 = nullptr;
+    if (out->images_i32)
+        if ((rc = pv_get(ctx, "out.images_i32", (size_t)(cap + 1) * PV_WINDOW_BYTES, &dout.images_i32))) return rc;
+    if ((rc = pv_get(ctx, "out.cand_str", scap + 1, &dout.cand_str))) return rc;
+    if ((rc = pv_get(ctx, "out.cand_off", cap + 2, &dout.cand_off))) return rc;
+    int64_t* d_counts = nullptr;
+    if ((rc = pv_get(ctx, "out.counts", (size_t)4, &d_counts))) return rc;
+
+    int64_t ms, me;
+    default_limits(n_cols, n_cigar, n_bases, cap, &ms, &me);
+    for (int attempt = 0; attempt < 3; attempt++) {
+        rc = summarize_launch(ctx, &d, params, n_reads, n_bases, n_cigar, n_cols, ms, me, &dout, d_counts, st);
+        if (rc) return rc;
+        PV_HIP(hipMemcpyAsync(ctx->h_counts, d_counts, 4 * sizeof(int64_t), hipMemcpyDeviceToHost, st));
+        PV_HIP(hipStreamSynchronize(st));
+        if (ctx->h_counts[2] == PV_ERR_LIMIT && attempt < 2) {  // workspace heuristics too small: take exact bounds
+            ms = n_cols;
+            me = n_cigar + n_bases;
+            continue;
+        }
+        break;
+    }
+    const int64_t status = ctx->h_counts[2];
+    PV_CHECK(status != PV_ERR_INVALID, PV_ERR_INVALID, "malformed read: CIGAR walks past the end of its bases");
+    PV_CHECK(status != PV_ERR_LIMIT, PV_ERR_LIMIT, "more than %d distinct alleles at one site, or index range exceeded", UMAX);
+    PV_CHECK(status == 0, (int)status, "device status %lld", (long long)status);
+    out->n_out = ctx->h_counts[0];
+    out->str_bytes = ctx->h_counts[1];
+    if (out->n_out > cap || out->str_bytes > scap) {
+        pv_set_error("output capacity too small: need %lld windows, %lld key bytes", (long long)out->n_out,
+                     (long long)out->str_bytes);
+        return PV_ERR_CAPACITY;
+    }
+    const int64_t n = out->n_out;
+    if (n > 0) {
+        PV_HIP(hipMemcpyAsync(out->region, dout.region, n * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+        PV_HIP(hipMemcpyAsync(out->position, dout.position, n * sizeof(int64_t), hipMemcpyDeviceToHost, st));
+        PV_HIP(hipMemcpyAsync(out->depth, dout.depth, n, hipMemcpyDeviceToHost, st));
+        PV_HIP(hipMemcpyAsync(out->cand_freq, dout.cand_freq, n, hipMemcpyDeviceToHost, st));
+        PV_HIP(hipMemcpyAsync(out->images, dout.images, n * PV_WINDOW_BYTES, hipMemcpyDeviceToHost, st));
+        if (out->images_i32)
+            PV_HIP(hipMemcpyAsync(out->images_i32, dout.images_i32, n * PV_WINDOW_BYTES * sizeof(int32_t),
+                                  hipMemcpyDeviceToHost, st));
+        PV_HIP(hipMemcpyAsync(out->cand_str, dout.cand_str, out->str_bytes, hipMemcpyDeviceToHost, st));
+        PV_HIP(hipMemcpyAsync(out->cand_off, dout.cand_off, (n + 1) * sizeof(int64_t), hipMemcpyDeviceToHost, st));
+        PV_HIP(hipStreamSynchronize(st));
+    }
+    return PV_OK;
+}

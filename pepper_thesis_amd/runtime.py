@@ -1,0 +1,132 @@
+"""Thin Python handle on a pv_ctx (one HIP device + stream + workspace) of the C-ABI.
+
+All compute happens in csrc/libpepper_hip.so; this module only marshals numpy arrays / device
+pointers. There is no CPU fallback: constructing a Context without a HIP device raises.
+"""
+import ctypes as C
+from typing import Optional
+
+import numpy as np
+
+from . import _ffi
+from .batch import OutBuffers, Params, RegionBatch, SummaryOut
+
+
+def _dir_struct(w, prefix, suffix, keep):
+    d = _ffi.pv_rnn_dir()
+    for field, key in (("w_ih", "weight_ih_l0"), ("w_hh", "weight_hh_l0"), ("b_ih", "bias_ih_l0"), ("b_hh", "bias_hh_l0")):
+        a = np.ascontiguousarray(w["%s.%s%s" % (prefix, key, suffix)], dtype=np.float32)
+        keep.append(a)
+        setattr(d, field, a.ctypes.data)
+    return d
+
+
+class Context:
+    """pv_create / pv_destroy with the reference operators as methods."""
+
+    def __init__(self, device_id: int = 0):
+        self.lib = _ffi.load()
+        self.handle = self.lib.pv_create(int(device_id))
+        if not self.handle:
+            msg = self.lib.pv_last_error()
+            raise _ffi.PepperHipError(_ffi.PV_ERR_NO_DEVICE, msg.decode() if msg else "pv_create failed")
+        self.device_id = int(device_id)
+
+    def close(self):
+        if getattr(self, "handle", None):
+            self.lib.pv_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def stream(self) -> int:
+        return int(self.lib.pv_stream(self.handle) or 0)
+
+    def synchronize(self):
+        _ffi.check(self.lib.pv_synchronize(self.handle))
+
+    def workspace_bytes(self) -> int:
+        return int(self.lib.pv_workspace_bytes(self.handle))
+
+    # ---- image builder ---------------------------------------------------------------------------
+    def summarize(self, batch: RegionBatch, params: Params, want_i32: bool = False,
+                  capacity: Optional[int] = None, str_capacity: Optional[int] = None) -> SummaryOut:
+        """RegionalSummaryGenerator.generate_summary for every region of the batch (host buffers)."""
+        cin, cp = batch.as_c(), params.as_c()
+        cap = capacity or max(1024, batch.n_regions * 1024)
+        scap = str_capacity or cap * 8
+        for _ in range(3):
+            ob = OutBuffers(cap, scap, want_i32)
+            rc = self.lib.pv_summarize_regions(self.handle, C.byref(cin), C.byref(cp), C.byref(ob.c))
+            if rc == _ffi.PV_ERR_CAPACITY:
+                cap, scap = max(cap, int(ob.c.n_out)), max(scap, int(ob.c.str_bytes))
+                continue
+            _ffi.check(rc)
+            return ob.result()
+        _ffi.check(rc)
+
+    # ---- RNN ------------------------------------------------------------------------------------------
+    def load_p1(self, weights: dict, dtype: int = _ffi.PV_DTYPE_F32):
+        """weights: state_dict of the pepper_variant TransducerGRU as numpy arrays (ModelHander.py:18-44)."""
+        keep = []
+        w = _ffi.pv_weights_p1()
+        for d, suffix in enumerate(("", "_reverse")):
+            w.encoder[d] = _dir_struct(weights, "encoder", suffix, keep)
+            w.decoder[d] = _dir_struct(weights, "decoder", suffix, keep)
+        for i in range(5):
+            a = np.ascontiguousarray(weights["linear_%d.weight" % (i + 1)], dtype=np.float32)
+            b = np.ascontiguousarray(weights["linear_%d.bias" % (i + 1)], dtype=np.float32)
+            keep += [a, b]
+            w.linear_w[i], w.linear_b[i] = a.ctypes.data, b.ctypes.data
+        a = np.ascontiguousarray(weights["output_layer_type.weight"], dtype=np.float32)
+        b = np.ascontiguousarray(weights["output_layer_type.bias"], dtype=np.float32)
+        keep += [a, b]
+        w.out_w, w.out_b = a.ctypes.data, b.ctypes.data
+        _ffi.check(self.lib.pv_rnn_load_p1(self.handle, C.byref(w), int(dtype)))
+
+    def forward_p1(self, images: np.ndarray, taps: bool = False):
+        """images int8 [B,33,26] -> probs float32 [B,3] (+ encoder/decoder outputs when taps=True)."""
+        x = np.ascontiguousarray(images, dtype=np.int8)
+        assert x.ndim == 3 and x.shape[1:] == (33, 26), x.shape
+        B = x.shape[0]
+        probs = np.zeros((B, 3), np.float32)
+        if not taps:
+            _ffi.check(self.lib.pv_rnn_forward_p1(self.handle, x.ctypes.data, B, probs.ctypes.data))
+            return probs
+        enc = np.zeros((B, 33, 512), np.float32)
+        dec = np.zeros((B, 33, 512), np.float32)
+        _ffi.check(self.lib.pv_rnn_forward_p1_debug(self.handle, x.ctypes.data, B, probs.ctypes.data,
+                                                    enc.ctypes.data, dec.ctypes.data))
+        return probs, enc, dec
+
+    def forward_p1_dev(self, d_images_ptr: int, B: int, d_probs_ptr: int, stream: int = 0):
+        """device pointers in, asynchronous on `stream` (0 = the context's stream)."""
+        _ffi.check(self.lib.pv_rnn_forward_p1_dev(self.handle, d_images_ptr, int(B), d_probs_ptr, stream or None))
+
+    def load_p2(self, weights: dict, dtype: int = _ffi.PV_DTYPE_F32):
+        keep = []
+        w = _ffi.pv_weights_p2()
+        for d, suffix in enumerate(("", "_reverse")):
+            w.encoder[d] = _dir_struct(weights, "gru_encoder", suffix, keep)
+            w.decoder[d] = _dir_struct(weights, "gru_decoder", suffix, keep)
+        a = np.ascontiguousarray(weights["dense1.weight"], dtype=np.float32)
+        b = np.ascontiguousarray(weights["dense1.bias"], dtype=np.float32)
+        keep += [a, b]
+        w.dense_w, w.dense_b = a.ctypes.data, b.ctypes.data
+        _ffi.check(self.lib.pv_rnn_load_p2(self.handle, C.byref(w), int(dtype)))
+
+    def forward_p2(self, images: np.ndarray, want_acc: bool = False):
+        """images uint8 [B,1000,10] -> labels uint8 [B,1000] (+ accumulated softmax [B,1000,5])."""
+        x = np.ascontiguousarray(images, dtype=np.uint8)
+        assert x.ndim == 3 and x.shape[1:] == (1000, 10), x.shape
+        B = x.shape[0]
+        labels = np.zeros((B, 1000), np.uint8)
+        acc = np.zeros((B, 1000, 5), np.float32) if want_acc else None
+        _ffi.check(self.lib.pv_rnn_forward_p2(self.handle, x.ctypes.data, B, labels.ctypes.data,
+                                              None if acc is None else acc.ctypes.data))
+        return (labels, acc) if want_acc else labels
