@@ -354,6 +354,11 @@ static void pack_linear(const float* W, int K, std::vector<float>& wp) {
 
 }  // namespace
 
+static constexpr size_t LDS_ENC = (size_t)(ROWS * (32 + 4) + 2 * ROWS * (H + 4)) * sizeof(float);
+static constexpr size_t LDS_DEC = (size_t)(ROWS * (2 * H + 4) + 2 * ROWS * (H + 4)) * sizeof(float);
+static constexpr size_t LDS_SPLITK = (size_t)ROWS * (2 * H + 4) * sizeof(float);
+static constexpr size_t LDS_TAIL = (size_t)2 * ROWS * (HEAD_N + 4) * sizeof(float);
+
 struct pv_rnn_p1 {
     float* enc_wp = nullptr; float* enc_bias = nullptr;
     float* dec_wp = nullptr; float* dec_bias = nullptr;
@@ -428,11 +433,11 @@ extern "C" int pv_rnn_load_p1(pv_ctx* ctx, const pv_weights_p1* w, int dtype) {
             return rc;
     }
     if ((rc = dev_upload(w->out_w, 3 * HEAD_N, &m->wo, m->owned)) || (rc = dev_upload(w->out_b, 3, &m->bo, m->owned))) return rc;
-    // opt in to large dynamic LDS once
-    PV_HIP(hipFuncSetAttribute((const void*)k_lstm_layer<32, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    PV_HIP(hipFuncSetAttribute((const void*)k_lstm_layer<512, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    PV_HIP(hipFuncSetAttribute((const void*)k_head_splitk, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    PV_HIP(hipFuncSetAttribute((const void*)k_head_tail, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    // opt in to > 64 KB of dynamic LDS (exact sizes; static LDS counts against the 160 KB too)
+    PV_HIP(hipFuncSetAttribute((const void*)k_lstm_layer<32, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_ENC));
+    PV_HIP(hipFuncSetAttribute((const void*)k_lstm_layer<512, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_DEC));
+    PV_HIP(hipFuncSetAttribute((const void*)k_head_splitk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_SPLITK));
+    PV_HIP(hipFuncSetAttribute((const void*)k_head_tail, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_TAIL));
     return PV_OK;
 }
 
@@ -443,20 +448,18 @@ static int p1_forward_launch(pv_ctx* ctx, const int8_t* d_images, int64_t B, flo
     const unsigned lstm_grid = (unsigned)(((n_tiles + 3) / 4) * 8);
     LstmArgs e;
     e.x_i8 = d_images; e.x_f32 = nullptr; e.wp = m->enc_wp; e.bias = m->enc_bias; e.out = enc_out; e.B = B; e.n_tiles = n_tiles;
-    const size_t lds_enc = (size_t)(ROWS * (32 + 4) + 2 * ROWS * (H + 4)) * sizeof(float);
-    k_lstm_layer<32, true><<<lstm_grid, 256, lds_enc, st>>>(e);
+    k_lstm_layer<32, true><<<lstm_grid, 256, LDS_ENC, st>>>(e);
     LstmArgs d = e;
     d.x_i8 = nullptr; d.x_f32 = enc_out; d.wp = m->dec_wp; d.bias = m->dec_bias; d.out = dec_out;
-    const size_t lds_dec = (size_t)(ROWS * (2 * H + 4) + 2 * ROWS * (H + 4)) * sizeof(float);
-    k_lstm_layer<512, false><<<lstm_grid, 256, lds_dec, st>>>(d);
+    k_lstm_layer<512, false><<<lstm_grid, 256, LDS_DEC, st>>>(d);
     HeadArgs h;
     h.dec = dec_out; h.w1p = m->w1p; h.part = part; h.B = B; h.n_tiles = n_tiles;
-    k_head_splitk<<<(unsigned)(n_tiles * HEAD_SPLITS), 256, (size_t)ROWS * (2 * H + 4) * sizeof(float), st>>>(h);
+    k_head_splitk<<<(unsigned)(n_tiles * HEAD_SPLITS), 256, LDS_SPLITK, st>>>(h);
     TailArgs t;
     t.part = part; t.b1 = m->b1;
     for (int i = 0; i < 4; i++) { t.wp[i] = m->wlp[i]; t.b[i] = m->bl[i]; }
     t.wo = m->wo; t.bo = m->bo; t.probs = d_probs; t.B = B;
-    k_head_tail<<<(unsigned)n_tiles, 256, (size_t)2 * ROWS * (HEAD_N + 4) * sizeof(float), st>>>(t);
+    k_head_tail<<<(unsigned)n_tiles, 256, LDS_TAIL, st>>>(t);
     PV_HIP(hipGetLastError());
     return PV_OK;
 }
