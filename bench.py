@@ -1,0 +1,220 @@
+#!/usr/bin/env python3
+"""bench.py — headline benchmark of the MI355X-native PEPPER hot path.
+
+Metric (BASELINE.json): pileup windows/s (+ Mbp/s inferred) on the HG003-chr20-shaped ONT R9 workload,
+configs[1]: batch = 512 windows per step, fp32, one MI355X per rank. No real BAM / checkpoint exists
+offline, so inputs are the synthetic shapes SURVEY.md 8(d) fixes (R = 100 200 columns at 60x with
+10 kb reads; random-init weights of the pepper_variant architecture).
+
+One STEP = one 100.2 kb region through the image builder + one 512-window batch through the RNN
+(every window the region yields is inferred; the batch is topped up to exactly 512 with resident
+synthetic windows). Like the reference's `callers_per_gpu` (RunInferenceArguments.py:67-74) the host
+loop keeps CALLERS = 8 steps in flight, here by fusing them into ONE launch chain per group
+(8 regions per builder call, 4096 windows per RNN call) so that a single stream fills all 256 CUs.
+
+  python bench.py [--gpus N] [--steps K] [--warmup W]
+N > 1: launched by torch.distributed.run, one rank per GPU; regions shard across ranks (no data-path
+collective); one RCCL gather of the per-window predictions to rank 0 ends the timed region.
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+BATCH = 512
+CALLERS = 8                      # steps fused per launch chain
+REGION_LEN = 100_200             # 100 kb interval + 2 x 100 safe bases (AlignmentSummarizer.py:181-182)
+DEPTH = 60
+READ_LEN = 10_000
+SITE_EVERY = 260                 # planted sites: ~430-480 windows per region (< 512 by construction)
+FLOP_PER_WINDOW = 161_328_128
+FLOP_DEC_PER_WINDOW = 103_809_024
+FLOP_ENC_PER_WINDOW = 38_117_376
+PEAK_F32_TFLOPS = 157.3          # MI355X_MICROARCH.md: f32 MFMA == f32 vector peak
+PEAK_HBM_GBS = 8000.0
+
+
+def log(msg):
+    sys.stderr.write("[bench] %s\n" % msg)
+    sys.stderr.flush()
+
+
+def cpu_baseline(weights, region, threads):
+    """CPU baseline on a bounded sample of the same workload: one region through the image builder
+    (the REFERENCE's region_summary.cpp if oracle/_ref was built, else the C oracle) + 512-window
+    batches through the stock-torch twin of the reference's eager predict loop."""
+    import torch
+    from oracle import oracle, rnn_torch_twin
+    from pepper_thesis_amd import synth
+    from pepper_thesis_amd.batch import PRESETS, pack_regions
+    P = PRESETS["ont_r9_guppy5_sup"]
+    b = pack_regions([region])
+    kind_builder = "reference" if oracle.have_reference() else "port"
+    fn = oracle.reference_summarize if oracle.have_reference() else oracle.summarize
+    if not oracle.have_reference():
+        oracle.build()
+    t0 = time.perf_counter()
+    out = fn(b, P)
+    t_builder = time.perf_counter() - t0
+    torch.set_num_threads(threads)
+    model = rnn_torch_twin.build_p1(weights)
+    x = synth.synth_windows(5, 2 * BATCH)
+    rnn_torch_twin.predict_p1(model, x[:64])  # warm
+    t0 = time.perf_counter()
+    rnn_torch_twin.predict_p1(model, x, BATCH)
+    t_rnn = (time.perf_counter() - t0) / 2.0
+    per_step = t_builder + t_rnn
+    return {
+        "value": BATCH / per_step, "unit": "windows/s", "cores": threads,
+        "kind": "port",
+        "sample": "1 region (%d windows) through the %s image builder on 1 core: %.3f s; 2 x 512 windows through the "
+                  "stock torch.nn twin of the reference's eager predict loop on %d threads: %.3f s per 512"
+                  % (len(out), "reference C++ (oracle/_ref)" if kind_builder == "reference" else "C oracle",
+                     t_builder, threads, t_rnn),
+        "mbp_per_s": REGION_LEN / 1e6 / per_step,
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=64)
+    ap.add_argument("--warmup", type=int, default=8)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    else:
+        dist = None
+        torch.cuda.set_device(local_rank)
+    dev = "cuda:%d" % local_rank
+
+    from pepper_thesis_amd import runtime, synth
+    from pepper_thesis_amd.batch import PRESETS, pack_regions
+    from pepper_thesis_amd.device import DeviceBatch, DeviceOut
+    from pepper_thesis_amd.dist import gather_predictions
+
+    K, W = int(args.steps), int(args.warmup)
+    groups = (K + CALLERS - 1) // CALLERS
+    wgroups = (W + CALLERS - 1) // CALLERS
+    if K % CALLERS:
+        log("--steps %d is not a multiple of %d: timing %d steps" % (K, CALLERS, groups * CALLERS))
+    K = groups * CALLERS
+
+    # ---- synthetic workload (seeded; rank r gets its own regions: regions shard across GPUs) ---------
+    t0 = time.time()
+    regions = [synth.synth_region(1234 + 97 * (rank * CALLERS + i), region_len=REGION_LEN, depth=DEPTH,
+                                  read_len=READ_LEN, site_every=SITE_EVERY,
+                                  ref_start=1_000_000 + (rank * CALLERS + i) * (REGION_LEN - 200))
+               for i in range(CALLERS)]
+    batch = pack_regions(regions)
+    weights = synth.make_weights_p1(1234)
+    pad = synth.synth_windows(4242 + rank, CALLERS * BATCH)
+    log("rank %d: generated %d regions (%d reads, %.1f M bases) in %.1f s" %
+        (rank, len(regions), batch.n_reads, batch.n_bases / 1e6, time.time() - t0))
+    P = PRESETS["ont_r9_guppy5_sup"]
+
+    ctx = runtime.Context(local_rank)
+    ctx.load_p1(weights)
+    dbatch = DeviceBatch(batch, dev)
+    win = torch.from_numpy(pad).to(dev)                               # [4096,33,26] int8, builder writes the front
+    dout = DeviceOut(CALLERS * BATCH, CALLERS * BATCH * 16, dev, images=win)
+    probs = torch.zeros((groups, CALLERS * BATCH, 3), dtype=torch.float32, device=dev)
+    torch.cuda.synchronize()
+
+    def group(g):
+        ctx.summarize_dev(dbatch, P, dout)
+        ctx.forward_p1_dev(win.data_ptr(), CALLERS * BATCH, probs[g % groups].data_ptr())
+
+    for g in range(wgroups):
+        group(g)
+    ctx.synchronize()
+    n_windows_region = dout.n_out()
+    assert dout.status() == 0, "device status %d" % dout.status()
+    assert n_windows_region <= CALLERS * BATCH, "regions yield %d windows > %d" % (n_windows_region, CALLERS * BATCH)
+
+    # ---- timed region ----------------------------------------------------------------------------------
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    ctx.profile_begin()
+    t0 = time.perf_counter()
+    for g in range(groups):
+        group(g)
+    gathered = None
+    if dist is not None:
+        ctx.synchronize()
+        gathered = gather_predictions(probs.view(-1, 3), dst=0)
+    ctx.synchronize()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    prof = ctx.profile_end()
+    if dist is not None:
+        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+
+    if rank == 0:
+        total_windows = K * BATCH * world
+        value = total_windows / dt
+        dec_ms, dec_n = prof.get("k_lstm_layer_dec", (0.0, 0))
+        dec_avg_s = dec_ms / max(dec_n, 1) / 1e3
+        achieved_tf = FLOP_DEC_PER_WINDOW * CALLERS * BATCH / dec_avg_s / 1e12 if dec_avg_s > 0 else 0.0
+        sum_ms, sum_n = prof.get("summary_pipeline", (0.0, 0))
+        pile_ms, pile_n = prof.get("k_pileup", (0.0, 0))
+        alg_bytes = batch.algorithmic_bytes(n_windows_region)
+        out = {
+            "metric": "pileup windows/sec (whole node) + Mbp/sec inferred, HG003 chr20 ONT R9",
+            "value": value, "unit": "windows/s", "n_gpus": world, "steps": K, "warmup": wgroups * CALLERS,
+            "ms_per_step": dt / K * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "configs[1]: HG003-chr20-shaped ONT R9 synthetic, batch=512 windows/step, fp32 bi-LSTM P1, "
+                                   "1 region (R=100200, 60x, 10 kb reads) per step, %d steps fused per launch chain" % CALLERS,
+                       "batch": BATCH, "callers": CALLERS, "region_len": REGION_LEN, "depth": DEPTH,
+                       "windows_per_region": n_windows_region / CALLERS, "parallelism": "region-sharded x%d" % world},
+            "mbp_per_s": K * world * REGION_LEN / 1e6 / dt,
+            "roofline": {"bound": "mfma", "kernel": "k_lstm_layer<512> (decoder bi-LSTM, fused input projection + recurrence)",
+                         "achieved": achieved_tf, "peak": PEAK_F32_TFLOPS, "unit": "TFLOP/s",
+                         "frac": achieved_tf / PEAK_F32_TFLOPS, "traffic": None,
+                         "launch_ms": dec_avg_s * 1e3, "flop_per_launch": FLOP_DEC_PER_WINDOW * CALLERS * BATCH},
+            "roofline_builder": {"bound": "hbm", "kernel": "summary pipeline (k_cigar_scan .. k_write_windows), %d regions/launch" % CALLERS,
+                                 "achieved": alg_bytes / (sum_ms / max(sum_n, 1) / 1e3) / 1e9 if sum_ms > 0 else 0.0,
+                                 "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                                 "frac": (alg_bytes / (sum_ms / max(sum_n, 1) / 1e3) / 1e9 / PEAK_HBM_GBS) if sum_ms > 0 else 0.0,
+                                 "traffic": None, "launch_ms": sum_ms / max(sum_n, 1), "k_pileup_ms": pile_ms / max(pile_n, 1),
+                                 "algorithmic_bytes_per_launch": alg_bytes},
+            "kernel_ms": {k: v[0] / max(v[1], 1) for k, v in prof.items()},
+            "rnn_model_tflops": FLOP_PER_WINDOW * value / 1e12,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            try:
+                out["cpu_baseline"] = cpu_baseline(weights, regions[0], len(os.sched_getaffinity(0)))
+            except Exception as e:  # the baseline is reporting only; never fail the bench for it
+                out["cpu_baseline"] = {"value": None, "unit": "windows/s", "cores": 0, "kind": "port", "sample": "failed: %r" % (e,)}
+        print(json.dumps(out))
+        sys.stdout.flush()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    ctx.close()
+
+
+if __name__ == "__main__":
+    main()

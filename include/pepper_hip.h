@@ -207,6 +207,13 @@ int pv_rnn_forward_p2(pv_ctx* ctx, const uint8_t* images, int64_t B, uint8_t* la
 int pv_rnn_forward_p2_dev(pv_ctx* ctx, const uint8_t* d_images, int64_t B, uint8_t* d_labels, float* d_acc,
                           void* stream);
 
+/* Per-kernel timing for the benchmark's roofline leg: between pv_profile_begin and pv_profile_end every
+ * kernel the context launches is bracketed by HIP events on its launch stream. pv_profile_end
+ * synchronises the device and returns the number of distinct kernels; names_buf receives their names
+ * ('\n'-separated), ms_sum[i] / counts[i] the summed duration and launch count of kernel i. */
+int pv_profile_begin(pv_ctx* ctx);
+int pv_profile_end(pv_ctx* ctx, char* names_buf, int buf_len, float* ms_sum, int* counts, int max_kernels);
+
 /* bytes of device workspace the context currently holds (diagnostics) */
 int64_t pv_workspace_bytes(pv_ctx* ctx);
 /* library/ABI version: major*10000 + minor*100 + patch */

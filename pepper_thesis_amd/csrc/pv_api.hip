@@ -47,6 +47,8 @@ extern "C" void pv_destroy(pv_ctx* c) {
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
     pv_rnn_free(c);
+    for (auto& r : c->prof.recs) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
+    for (auto e : c->prof.pool) (void)hipEventDestroy(e);
     c->arena.release();
     if (c->h_counts) (void)hipHostFree(c->h_counts);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -60,6 +62,44 @@ extern "C" int pv_synchronize(pv_ctx* c) {
     PV_HIP(hipSetDevice(c->device));
     PV_HIP(hipStreamSynchronize(c->stream));
     return PV_OK;
+}
+
+extern "C" int pv_profile_begin(pv_ctx* c) {
+    PV_CHECK(c, PV_ERR_INVALID, "null context");
+    for (auto& r : c->prof.recs) { c->prof.pool.push_back(r.a); c->prof.pool.push_back(r.b); }
+    c->prof.recs.clear();
+    c->prof.on = true;
+    return PV_OK;
+}
+
+// Synchronises the context's stream, then aggregates the event-bracketed launches by kernel name.
+// names: '\n'-separated list written into names_buf; ms_sum[i]/counts[i] follow the same order.
+extern "C" int pv_profile_end(pv_ctx* c, char* names_buf, int buf_len, float* ms_sum, int* counts, int max_kernels) {
+    PV_CHECK(c && names_buf && ms_sum && counts && buf_len > 0, PV_ERR_INVALID, "null argument");
+    PV_HIP(hipSetDevice(c->device));
+    PV_HIP(hipDeviceSynchronize());
+    c->prof.on = false;
+    std::vector<std::string> names;
+    for (auto& r : c->prof.recs) {
+        float ms = 0.f;
+        PV_HIP(hipEventElapsedTime(&ms, r.a, r.b));
+        size_t k = 0;
+        for (; k < names.size(); k++) if (names[k] == r.name) break;
+        if (k == names.size()) {
+            if ((int)k >= max_kernels) continue;
+            names.push_back(r.name);
+            ms_sum[k] = 0.f;
+            counts[k] = 0;
+        }
+        ms_sum[k] += ms;
+        counts[k] += 1;
+    }
+    std::string joined;
+    for (size_t k = 0; k < names.size(); k++) { if (k) joined += "\n"; joined += names[k]; }
+    snprintf(names_buf, (size_t)buf_len, "%s", joined.c_str());
+    for (auto& r : c->prof.recs) { c->prof.pool.push_back(r.a); c->prof.pool.push_back(r.b); }
+    c->prof.recs.clear();
+    return (int)names.size();
 }
 
 extern "C" int64_t pv_workspace_bytes(pv_ctx* c) { return c ? (int64_t)c->arena.total : 0; }

@@ -70,6 +70,20 @@ struct pv_arena {
     }
 };
 
+// Optional per-kernel timing with HIP events recorded on the launch stream (bench.py's roofline leg).
+struct pv_prof {
+    bool on = false;
+    struct rec { const char* name; hipEvent_t a, b; };
+    std::vector<rec> recs;
+    std::vector<hipEvent_t> pool;
+    hipEvent_t take() {
+        if (!pool.empty()) { hipEvent_t e = pool.back(); pool.pop_back(); return e; }
+        hipEvent_t e = nullptr;
+        (void)hipEventCreate(&e);
+        return e;
+    }
+};
+
 struct pv_rnn_p1;  // rnn_kernels.hip
 struct pv_rnn_p2;
 
@@ -82,6 +96,20 @@ struct pv_ctx {
     int64_t* h_counts = nullptr;
     pv_rnn_p1* p1 = nullptr;
     pv_rnn_p2* p2 = nullptr;
+    pv_prof prof;
+};
+
+// RAII bracket: { pv_prof_scope ps(ctx, "k_name", stream); kernel<<<...>>>(...); }
+struct pv_prof_scope {
+    pv_ctx* c; hipStream_t st; size_t idx; bool on;
+    pv_prof_scope(pv_ctx* c_, const char* name, hipStream_t st_) : c(c_), st(st_), idx(0), on(c_->prof.on) {
+        if (!on) return;
+        pv_prof::rec r; r.name = name; r.a = c->prof.take(); r.b = c->prof.take();
+        (void)hipEventRecord(r.a, st);
+        idx = c->prof.recs.size();
+        c->prof.recs.push_back(r);
+    }
+    ~pv_prof_scope() { if (on) (void)hipEventRecord(c->prof.recs[idx].b, st); }
 };
 
 template <typename T>

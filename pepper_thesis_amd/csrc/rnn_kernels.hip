@@ -448,18 +448,18 @@ static int p1_forward_launch(pv_ctx* ctx, const int8_t* d_images, int64_t B, flo
     const unsigned lstm_grid = (unsigned)(((n_tiles + 3) / 4) * 8);
     LstmArgs e;
     e.x_i8 = d_images; e.x_f32 = nullptr; e.wp = m->enc_wp; e.bias = m->enc_bias; e.out = enc_out; e.B = B; e.n_tiles = n_tiles;
-    k_lstm_layer<32, true><<<lstm_grid, 256, LDS_ENC, st>>>(e);
+    { pv_prof_scope ps(ctx, "k_lstm_layer_enc", st); k_lstm_layer<32, true><<<lstm_grid, 256, LDS_ENC, st>>>(e); }
     LstmArgs d = e;
     d.x_i8 = nullptr; d.x_f32 = enc_out; d.wp = m->dec_wp; d.bias = m->dec_bias; d.out = dec_out;
-    k_lstm_layer<512, false><<<lstm_grid, 256, LDS_DEC, st>>>(d);
+    { pv_prof_scope ps(ctx, "k_lstm_layer_dec", st); k_lstm_layer<512, false><<<lstm_grid, 256, LDS_DEC, st>>>(d); }
     HeadArgs h;
     h.dec = dec_out; h.w1p = m->w1p; h.part = part; h.B = B; h.n_tiles = n_tiles;
-    k_head_splitk<<<(unsigned)(n_tiles * HEAD_SPLITS), 256, LDS_SPLITK, st>>>(h);
+    { pv_prof_scope ps(ctx, "k_head_splitk", st); k_head_splitk<<<(unsigned)(n_tiles * HEAD_SPLITS), 256, LDS_SPLITK, st>>>(h); }
     TailArgs t;
     t.part = part; t.b1 = m->b1;
     for (int i = 0; i < 4; i++) { t.wp[i] = m->wlp[i]; t.b[i] = m->bl[i]; }
     t.wo = m->wo; t.bo = m->bo; t.probs = d_probs; t.B = B;
-    k_head_tail<<<(unsigned)n_tiles, 256, LDS_TAIL, st>>>(t);
+    { pv_prof_scope ps(ctx, "k_head_tail", st); k_head_tail<<<(unsigned)n_tiles, 256, LDS_TAIL, st>>>(t); }
     PV_HIP(hipGetLastError());
     return PV_OK;
 }

@@ -794,21 +794,22 @@ static int summarize_launch(pv_ctx* ctx, const pv_batch_in* in, const pv_params*
     if ((rc = pv_get(ctx, "sum.rec", max_events + 4 * max_sites, &a.rec))) return rc;
     if ((rc = pv_get(ctx, "sum.diag", (size_t)D_NDIAG, &a.diag))) return rc;
 
+    pv_prof_scope ps_all(ctx, "summary_pipeline", st);
     k_zero_diag<<<1, 64, 0, st>>>(a.diag);
     PV_HIP(hipMemsetAsync(a.cnt, 0, (size_t)NCNT * n_cols * sizeof(int32_t), st));
-    if (n_reads > 0) k_cigar_scan<<<grid_for(n_reads, 4), 256, 0, st>>>(a);
-    if (n_cigar > 0) k_pileup<<<grid_for(n_cigar, 256), 256, 0, st>>>(a);
+    if (n_reads > 0) { pv_prof_scope ps(ctx, "k_cigar_scan", st); k_cigar_scan<<<grid_for(n_reads, 4), 256, 0, st>>>(a); }
+    if (n_cigar > 0) { pv_prof_scope ps(ctx, "k_pileup", st); k_pileup<<<grid_for(n_cigar, 256), 256, 0, st>>>(a); }
     k_site_scan<<<(unsigned)n_blk, 1024, 0, st>>>(a);
     k_scan_i32<<<1, 1024, 0, st>>>(a.blk_cnt, a.blk_off, n_blk, nullptr, n_blk, &a.diag[D_NSITES]);
     k_site_rank<<<(unsigned)n_blk, 1024, 0, st>>>(a);
     k_scan_i32<<<1, 1024, 0, st>>>(a.site_nev, a.site_evoff, 0, &a.diag[D_NSITES], max_sites, &a.diag[D_NEVENTS]);
     k_check_limits<<<1, 1, 0, st>>>(a);
-    if (n_cigar > 0) k_collect<<<grid_for(n_cigar, 256), 256, 0, st>>>(a);
+    if (n_cigar > 0) { pv_prof_scope ps(ctx, "k_collect", st); k_collect<<<grid_for(n_cigar, 256), 256, 0, st>>>(a); }
     const unsigned site_grid = (unsigned)(max_sites < 4096 ? (max_sites > 0 ? max_sites : 1) : 4096);
-    k_site_alleles<<<site_grid, 64, 0, st>>>(a);
+    { pv_prof_scope ps(ctx, "k_site_alleles", st); k_site_alleles<<<site_grid, 64, 0, st>>>(a); }
     k_scan_i32<<<1, 1024, 0, st>>>(a.site_nemit, a.site_outoff, 0, &a.diag[D_NSITES], max_sites, &a.diag[D_NOUT]);
     k_scan_i64<<<1, 1024, 0, st>>>(a.site_strbytes, a.site_stroff, &a.diag[D_NSITES], max_sites, &a.diag[D_STRBYTES]);
-    k_write_windows<<<site_grid, 64, 0, st>>>(a);
+    { pv_prof_scope ps(ctx, "k_write_windows", st); k_write_windows<<<site_grid, 64, 0, st>>>(a); }
     k_publish_counts<<<1, 1, 0, st>>>(a);
     PV_HIP(hipGetLastError());
     return PV_OK;

@@ -1,0 +1,63 @@
+"""Device-resident batches: torch is used only as the HBM allocator / stream provider here.
+
+The C-ABI's *_dev entry points take raw device pointers; these helpers keep the owning torch tensors
+alive next to the C structs that point into them.
+"""
+import numpy as np
+import torch
+
+from . import _ffi
+from .batch import RegionBatch
+
+
+class DeviceBatch:
+    """A RegionBatch uploaded to HBM once (the benchmark's 'inputs already resident' state)."""
+
+    def __init__(self, batch: RegionBatch, device="cuda:0"):
+        self.host = batch
+        self.t = {}
+        c = _ffi.pv_batch_in()
+        c.n_regions = batch.n_regions
+        for f in RegionBatch.FIELDS:
+            a = getattr(batch, f)
+            if a.dtype == np.uint32:  # torch has no uint32 arithmetic; reinterpret the bits
+                t = torch.from_numpy(a.view(np.int32).copy()).to(device)
+            else:
+                t = torch.from_numpy(np.ascontiguousarray(a)).to(device)
+            if t.numel() == 0:
+                t = torch.zeros(1, dtype=t.dtype, device=device)
+            self.t[f] = t
+            setattr(c, f, t.data_ptr())
+        self.c = c
+        self.n_reads, self.n_bases, self.n_cigar = batch.n_reads, batch.n_bases, batch.n_cigar
+        self.n_ref_bytes = int(batch.ref.shape[0])
+        self.max_region_len = batch.max_region_len
+
+
+class DeviceOut:
+    """Caller-owned output arrays of pv_batch_out in HBM. `images` may alias a larger window buffer."""
+
+    def __init__(self, capacity: int, str_capacity: int, device="cuda:0", images: torch.Tensor = None):
+        self.capacity, self.str_capacity = int(capacity), int(str_capacity)
+        self.region = torch.zeros(capacity, dtype=torch.int32, device=device)
+        self.position = torch.zeros(capacity, dtype=torch.int64, device=device)
+        self.depth = torch.zeros(capacity, dtype=torch.uint8, device=device)
+        self.cand_freq = torch.zeros(capacity, dtype=torch.uint8, device=device)
+        self.images = images if images is not None else torch.zeros((capacity, 33, 26), dtype=torch.int8, device=device)
+        assert self.images.is_contiguous() and self.images.shape[0] >= capacity
+        self.cand_str = torch.zeros(str_capacity, dtype=torch.uint8, device=device)
+        self.cand_off = torch.zeros(capacity + 1, dtype=torch.int64, device=device)
+        self.counts = torch.zeros(4, dtype=torch.int64, device=device)
+        c = _ffi.pv_batch_out()
+        c.capacity, c.str_capacity = self.capacity, self.str_capacity
+        c.region, c.position = self.region.data_ptr(), self.position.data_ptr()
+        c.depth, c.cand_freq = self.depth.data_ptr(), self.cand_freq.data_ptr()
+        c.images, c.images_i32 = self.images.data_ptr(), None
+        c.cand_str, c.cand_off = self.cand_str.data_ptr(), self.cand_off.data_ptr()
+        self.c = c
+
+    def n_out(self) -> int:
+        return int(self.counts[0].item())
+
+    def status(self) -> int:
+        return int(self.counts[2].item())

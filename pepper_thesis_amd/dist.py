@@ -1,0 +1,59 @@
+"""Multi-GPU plumbing: region sharding and the single exchange step (gather of predictions).
+
+The reference distributes by process fan-out only: interval i goes to worker i % threads
+(pepper_variant/modules/python/ImageGenerationUI.py:211) and files to callers i % callers
+(RunInference.py:101-106); every caller writes its own prediction file and no gather exists. Here one
+process drives one GPU, regions are dealt the same round-robin way, and the per-window predictions
+are gathered to rank 0 with ONE collective (RCCL when the backend is nccl; gloo in CPU tests).
+"""
+from typing import List, Optional, Sequence
+
+import torch
+import torch.distributed as dist
+
+
+def shard_regions(n_items: int, rank: int, world: int) -> List[int]:
+    """indices of the intervals this rank owns: i % world == rank (ImageGenerationUI.py:211)"""
+    return [i for i in range(n_items) if i % world == rank]
+
+
+def gather_predictions(local: torch.Tensor, dst: int = 0, keys: Optional[torch.Tensor] = None):
+    """Gather [n_r, C] float rows (and optional int64 keys [n_r]) from every rank to `dst`.
+
+    Ranks may hold different row counts: counts are all-gathered first, payloads are padded to the
+    maximum and moved with one all_gather_into_tensor (a few MB at most: ~16 B per window).
+    Returns (rows [sum n_r, C], keys or None, counts) on dst, None elsewhere."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return local, keys, [int(local.shape[0])]
+    world, rank = dist.get_world_size(), dist.get_rank()
+    dev = local.device
+    n = torch.tensor([local.shape[0]], dtype=torch.int64, device=dev)
+    counts = torch.zeros(world, dtype=torch.int64, device=dev)
+    dist.all_gather_into_tensor(counts, n)
+    counts_l = [int(c) for c in counts.tolist()]
+    m = max(max(counts_l), 1)
+    C = int(local.shape[1])
+    pad = torch.zeros((m, C), dtype=local.dtype, device=dev)
+    pad[: local.shape[0]] = local
+    allrows = torch.empty((world * m, C), dtype=local.dtype, device=dev)
+    dist.all_gather_into_tensor(allrows, pad)
+    allkeys = None
+    if keys is not None:
+        kp = torch.zeros(m, dtype=torch.int64, device=dev)
+        kp[: keys.shape[0]] = keys
+        allkeys = torch.empty(world * m, dtype=torch.int64, device=dev)
+        dist.all_gather_into_tensor(allkeys, kp)
+    if rank != dst:
+        return None
+    rows = torch.cat([allrows[r * m: r * m + counts_l[r]] for r in range(world)])
+    ks = None if allkeys is None else torch.cat([allkeys[r * m: r * m + counts_l[r]] for r in range(world)])
+    return rows, ks, counts_l
+
+
+def merge_sharded(rows_per_rank: Sequence[torch.Tensor], idx_per_rank: Sequence[Sequence[int]], n_items: int):
+    """undo shard_regions for one-row-per-item payloads (used by tests)"""
+    out = [None] * n_items
+    for rows, idx in zip(rows_per_rank, idx_per_rank):
+        for k, i in enumerate(idx):
+            out[i] = rows[k]
+    return out

@@ -130,3 +130,25 @@ class Context:
         _ffi.check(self.lib.pv_rnn_forward_p2(self.handle, x.ctypes.data, B, labels.ctypes.data,
                                               None if acc is None else acc.ctypes.data))
         return (labels, acc) if want_acc else labels
+
+    # ---- device-resident forms (the fused pipeline / benchmark) -----------------------------------------
+    def summarize_dev(self, dbatch: "DeviceBatch", params: Params, dout: "DeviceOut", stream: int = 0):
+        """asynchronous; every array lives in HBM (see device.py). Counters land in dout.counts."""
+        cp = params.as_c()
+        _ffi.check(self.lib.pv_summarize_regions_dev(
+            self.handle, C.byref(dbatch.c), C.byref(cp), dbatch.n_reads, dbatch.n_bases, dbatch.n_cigar,
+            dbatch.n_ref_bytes, dbatch.max_region_len, C.byref(dout.c), dout.counts.data_ptr(), stream or None))
+
+    def profile_begin(self):
+        _ffi.check(self.lib.pv_profile_begin(self.handle))
+
+    def profile_end(self) -> dict:
+        """-> {kernel name: (total ms, launches)} measured with HIP events on the launch stream"""
+        buf = C.create_string_buffer(4096)
+        ms = (C.c_float * 64)()
+        cnt = (C.c_int * 64)()
+        n = self.lib.pv_profile_end(self.handle, buf, 4096, ms, cnt, 64)
+        if n < 0:
+            _ffi.check(n)
+        names = buf.value.decode().split("\n") if n else []
+        return {names[i]: (float(ms[i]), int(cnt[i])) for i in range(n)}
