@@ -205,7 +205,7 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             try:
-                out["cpu_baseline"] = cpu_baseline(weights, regions[0], len(os.sched_getaffinity(0)))
+                out["cpu_baseline"] = cpu_baseline(weights, regions[0], min(len(os.sched_getaffinity(0)), 16))
             except Exception as e:  # the baseline is reporting only; never fail the bench for it
                 out["cpu_baseline"] = {"value": None, "unit": "windows/s", "cores": 0, "kind": "port", "sample": "failed: %r" % (e,)}
         print(json.dumps(out))
