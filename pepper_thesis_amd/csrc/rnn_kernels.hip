@@ -21,6 +21,7 @@
 #include "pv_common.hpp"
 
 #include <cmath>
+#include <cstdlib>
 
 namespace {
 
@@ -36,11 +37,14 @@ constexpr int HEAD_K = T_STEPS * 2 * H;  // 16896
 constexpr int HEAD_SPLITS = 11;          // 3 time steps (1536 k) per split
 constexpr int HEAD_STEPS_PER_SPLIT = 3;
 
-__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + __expf(-x)); }
+// v_exp_f32 / v_rcp_f32 (1 ulp) instead of the IEEE division sequence: ~3x fewer VALU instructions in the
+// cell update; absolute error of sigmoid/tanh stays ~1e-7 (tests pin 2e-5 on layer outputs).
+__device__ __forceinline__ float rcpf_(float x) { return __builtin_amdgcn_rcpf(x); }
+__device__ __forceinline__ float sigmoidf_(float x) { return rcpf_(1.0f + __expf(-x)); }
 __device__ __forceinline__ float tanhf_(float x) {
-    // 1 - 2/(e^{2x}+1): absolute error ~1e-7, saturates cleanly at +-1
+    // 1 - 2/(e^{2x}+1): saturates cleanly at +-1 (e = inf -> 1, e = 0 -> -1)
     const float e = __expf(2.0f * x);
-    return 1.0f - 2.0f / (e + 1.0f);
+    return 1.0f - 2.0f * rcpf_(e + 1.0f);
 }
 __device__ __forceinline__ float seluf_(float x) {
     return 1.0507009873554805f * (x > 0.0f ? x : 1.6732632423543772f * (__expf(x) - 1.0f));
@@ -93,18 +97,69 @@ __device__ __forceinline__ void mma_panel(f32x16 (&acc)[NT], const float* __rest
 struct LstmArgs {
     const int8_t* x_i8;   // [B,33,26]    (encoder)
     const float* x_f32;   // [B,33,512]   (decoder)
-    const float* wp;      // packed [2 dirs][4 waves][nkb][8][64][4]
+    const float* wp;      // packed [2 dirs][NW waves][nkb][32/NW tiles][64][4]
     const float* bias;    // [2][1024] b_ih + b_hh
     float* out;           // [B,33,512]
     int64_t B;
     int n_tiles;
+    int ablate;  // diagnostics only (PV_ABLATE): 1 = trivial cell update, 2 = stage x_t only at step 0, 4 = no global h store
 };
 
+// One software-pipelined K loop over TWO LDS operands ([x_t | h_{t-1}]): k-blocks [0,nkb1) read A1,
+// [nkb1,nkb1+nkb2) read A2; the packed weight stream is contiguous over both. B fragments of block 0
+// are resident in registers (`bres`, identical every time step), blocks kb+1 (B from L2, A from LDS)
+// are fetched while block kb multiplies.
+template <int NT>
+__device__ __forceinline__ void mma_dual(f32x16 (&acc)[NT], const float* __restrict__ A1, int lda1, int nkb1,
+                                         const float* __restrict__ A2, int lda2, int nkb2,
+                                         const float* __restrict__ Bp, const f32x4 (&bres)[NT], int lane) {
+    const float* ap1 = A1 + (lane & 31) * lda1 + 4 * (lane >> 5);
+    const float* ap2 = A2 + (lane & 31) * lda2 + 4 * (lane >> 5) - 8 * nkb1;
+    const f32x4* bp = reinterpret_cast<const f32x4*>(Bp) + lane;
+    const int nkb = nkb1 + nkb2;
+    f32x4 b0[NT], b1[NT], a0, a1;
+#pragma unroll
+    for (int nt = 0; nt < NT; nt++) b0[nt] = bres[nt];
+    a0 = *reinterpret_cast<const f32x4*>((0 < nkb1 ? ap1 : ap2));
+    int kb = 0;
+#pragma nounroll
+    for (; kb + 1 < nkb; kb += 2) {
+#pragma unroll
+        for (int nt = 0; nt < NT; nt++) b1[nt] = bp[((kb + 1) * NT + nt) * 64];
+        a1 = *reinterpret_cast<const f32x4*>((kb + 1 < nkb1 ? ap1 : ap2) + 8 * (kb + 1));
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+#pragma unroll
+            for (int nt = 0; nt < NT; nt++) acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[j], b0[nt][j], acc[nt], 0, 0, 0);
+        if (kb + 2 < nkb) {
+#pragma unroll
+            for (int nt = 0; nt < NT; nt++) b0[nt] = bp[((kb + 2) * NT + nt) * 64];
+            a0 = *reinterpret_cast<const f32x4*>((kb + 2 < nkb1 ? ap1 : ap2) + 8 * (kb + 2));
+        }
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+#pragma unroll
+            for (int nt = 0; nt < NT; nt++) acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[j], b1[nt][j], acc[nt], 0, 0, 0);
+    }
+    if (kb < nkb) {
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+#pragma unroll
+            for (int nt = 0; nt < NT; nt++) acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[j], b0[nt][j], acc[nt], 0, 0, 0);
+    }
+}
+
 // KP = padded input width (multiple of 8): 32 for the encoder (26 real), 512 for the decoder.
-template <int KP, bool INT8>
-__global__ __launch_bounds__(256, 1) void k_lstm_layer(LstmArgs a) {
+// NW = waves per workgroup: 8 (two per SIMD: one wave's LDS/L2 waits and cell update hide behind the
+// other's MFMAs) or 4 (one per SIMD).
+template <int KP, bool INT8, int NW>
+__global__ __launch_bounds__(NW * 64, NW / 4) void k_lstm_layer(LstmArgs a) {
     constexpr int LDX = KP + 4, LDH = H + 4;
     constexpr int NKB_X = KP / 8, NKB_H = H / 8;
+    constexpr int NT = 32 / NW;   // 32-column gate tiles per wave
+    constexpr int S2 = NT / 4;    // 32-unit sub-tiles per wave
+    constexpr int UW = H / NW;    // hidden units per wave
+    constexpr int NTHR = NW * 64;
     extern __shared__ float smem[];
     float* xbuf = smem;                 // [32][LDX]
     float* hbuf = smem + ROWS * LDX;    // [2][32][LDH]
@@ -116,71 +171,116 @@ __global__ __launch_bounds__(256, 1) void k_lstm_layer(LstmArgs a) {
     const int tile = (blockIdx.x >> 3) * 4 + (xcd >> 1);
     if (tile >= a.n_tiles) return;
     const int64_t b0 = (int64_t)tile * ROWS;
-    const float* wp = a.wp + ((size_t)(dir * 4 + wv) * (NKB_X + NKB_H)) * 8 * 256;
+    const float* wp = a.wp + ((size_t)(dir * NW + wv) * (NKB_X + NKB_H)) * NT * 256;
     const float* bias = a.bias + dir * 4 * H;
 
-    for (int i = tid; i < 2 * ROWS * LDH; i += 256) hbuf[i] = 0.0f;
-    f32x16 cst[2];
+    for (int i = tid; i < 2 * ROWS * LDH; i += NTHR) hbuf[i] = 0.0f;
+    f32x16 cst[S2];
 #pragma unroll
-    for (int s2 = 0; s2 < 2; s2++)
+    for (int s2 = 0; s2 < S2; s2++)
 #pragma unroll
         for (int r = 0; r < 16; r++) cst[s2][r] = 0.0f;
-    float bs[8];
+    float bs[NT];
+    f32x4 bres[NT];
 #pragma unroll
-    for (int nt = 0; nt < 8; nt++) bs[nt] = bias[(nt >> 1) * H + 64 * wv + 32 * (nt & 1) + (lane & 31)];
+    for (int nt = 0; nt < NT; nt++) {
+        bs[nt] = bias[(nt / S2) * H + UW * wv + 32 * (nt % S2) + (lane & 31)];
+        bres[nt] = reinterpret_cast<const f32x4*>(wp)[nt * 64 + lane];
+    }
+
+    // x_t staging through registers: the global loads for step s+1 are issued before step s's MFMAs
+    // and written to LDS after them, so their latency hides behind the matrix work.
+    constexpr int V4 = KP / 4;                                  // float4 per row (fp32 input)
+    constexpr int XR = INT8 ? 1 : (ROWS * V4 + NTHR - 1) / NTHR;  // float4 registers per thread
+    constexpr int XI = (ROWS * KP + NTHR - 1) / NTHR;           // int8 elements per thread (encoder)
+    f32x4 xr[XR];
+    float xi[INT8 ? XI : 1];
+    auto x_load = [&](int t) {
+        if constexpr (INT8) {
+#pragma unroll
+            for (int u = 0; u < XI; u++) {
+                const int i = tid + u * NTHR;
+                const int row = i / KP, k = i - row * KP;
+                int64_t b = b0 + row;
+                if (b >= a.B) b = a.B - 1;
+                xi[u] = (i < ROWS * KP && k < F_IN) ? (float)a.x_i8[(b * T_STEPS + t) * F_IN + k] : 0.0f;
+            }
+        } else {
+#pragma unroll
+            for (int u = 0; u < XR; u++) {
+                const int i = tid + u * NTHR;
+                const int row = i / V4, c4 = i - row * V4;
+                int64_t b = b0 + (row < ROWS ? row : ROWS - 1);
+                if (b >= a.B) b = a.B - 1;
+                xr[u] = *reinterpret_cast<const f32x4*>(a.x_f32 + (b * T_STEPS + t) * (int64_t)KP + c4 * 4);
+            }
+        }
+    };
+    auto x_store = [&]() {
+        if constexpr (INT8) {
+#pragma unroll
+            for (int u = 0; u < XI; u++) {
+                const int i = tid + u * NTHR;
+                const int row = i / KP, k = i - row * KP;
+                if (i < ROWS * KP) xbuf[row * LDX + k] = xi[u];
+            }
+        } else {
+#pragma unroll
+            for (int u = 0; u < XR; u++) {
+                const int i = tid + u * NTHR;
+                const int row = i / V4, c4 = i - row * V4;
+                if (i < ROWS * V4) *reinterpret_cast<f32x4*>(xbuf + row * LDX + c4 * 4) = xr[u];
+            }
+        }
+    };
+    x_load(dir ? T_STEPS - 1 : 0);
+    x_store();
+    __syncthreads();
 
     for (int s = 0; s < T_STEPS; s++) {
         const int t = dir ? (T_STEPS - 1 - s) : s;
         const int cur = s & 1, nxt = cur ^ 1;
-        // ---- stage x_t ---------------------------------------------------------------------------
-        if constexpr (INT8) {
-            for (int i = tid; i < ROWS * KP; i += 256) {
-                const int row = i / KP, k = i - row * KP;
-                int64_t b = b0 + row;
-                if (b >= a.B) b = a.B - 1;
-                xbuf[row * LDX + k] = k < F_IN ? (float)a.x_i8[(b * T_STEPS + t) * F_IN + k] : 0.0f;
-            }
-        } else {
-            constexpr int V4 = KP / 4;  // float4 per row
-#pragma unroll 4
-            for (int i = tid; i < ROWS * V4; i += 256) {
-                const int row = i / V4, c4 = i - row * V4;
-                int64_t b = b0 + row;
-                if (b >= a.B) b = a.B - 1;
-                const f32x4 v = *reinterpret_cast<const f32x4*>(a.x_f32 + (b * T_STEPS + t) * (int64_t)KP + c4 * 4);
-                *reinterpret_cast<f32x4*>(xbuf + row * LDX + c4 * 4) = v;
-            }
-        }
-        __syncthreads();
+        if (s + 1 < T_STEPS && !(a.ablate & 2)) x_load(dir ? (T_STEPS - 2 - s) : (s + 1));
         // ---- gates = bias + [x_t | h_{t-1}] . [W_ih | W_hh]^T -------------------------------------
-        f32x16 acc[8];
+        f32x16 acc[NT];
 #pragma unroll
-        for (int nt = 0; nt < 8; nt++)
+        for (int nt = 0; nt < NT; nt++)
 #pragma unroll
             for (int r = 0; r < 16; r++) acc[nt][r] = bs[nt];
-        mma_panel<8>(acc, xbuf, LDX, wp, NKB_X, lane);
-        mma_panel<8>(acc, hbuf + cur * ROWS * LDH, LDH, wp + (size_t)NKB_X * 8 * 256, NKB_H, lane);
-        // ---- cell update (PyTorch gate order i,f,g,o; nt = gate*2 + sub-tile) ---------------------
+        mma_dual<NT>(acc, xbuf, LDX, NKB_X, hbuf + cur * ROWS * LDH, LDH, NKB_H, wp, bres, lane);
+        // ---- cell update (PyTorch gate order i,f,g,o; nt = gate*S2 + sub-tile) ---------------------
         float* hn = hbuf + nxt * ROWS * LDH;
 #pragma unroll
-        for (int s2 = 0; s2 < 2; s2++) {
-            const int unit = 64 * wv + 32 * s2 + (lane & 31);
+        for (int s2 = 0; s2 < S2; s2++) {
+            const int unit = UW * wv + 32 * s2 + (lane & 31);
 #pragma unroll
             for (int r = 0; r < 16; r++) {
-                const float ig = sigmoidf_(acc[0 + s2][r]);
-                const float fg = sigmoidf_(acc[2 + s2][r]);
-                const float gg = tanhf_(acc[4 + s2][r]);
-                const float og = sigmoidf_(acc[6 + s2][r]);
+                if (a.ablate & 1) {
+                    const float h = acc[0 * S2 + s2][r] * 1e-3f + acc[1 * S2 + s2][r] * 1e-3f + acc[2 * S2 + s2][r] * 1e-3f + acc[3 * S2 + s2][r] * 1e-3f;
+                    const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                    hn[row * LDH + unit] = h;
+                    const int64_t b = b0 + row;
+                    if (b < a.B && !(a.ablate & 4)) a.out[(b * T_STEPS + t) * (int64_t)(2 * H) + dir * H + unit] = h;
+                    continue;
+                }
+                const float ig = sigmoidf_(acc[0 * S2 + s2][r]);
+                const float fg = sigmoidf_(acc[1 * S2 + s2][r]);
+                const float gg = tanhf_(acc[2 * S2 + s2][r]);
+                const float og = sigmoidf_(acc[3 * S2 + s2][r]);
                 const float c = fg * cst[s2][r] + ig * gg;
                 cst[s2][r] = c;
                 const float h = og * tanhf_(c);
                 const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
                 hn[row * LDH + unit] = h;
                 const int64_t b = b0 + row;
-                if (b < a.B) a.out[(b * T_STEPS + t) * (int64_t)(2 * H) + dir * H + unit] = h;
+                if (b < a.B && !(a.ablate & 4)) a.out[(b * T_STEPS + t) * (int64_t)(2 * H) + dir * H + unit] = h;
             }
         }
-        __syncthreads();
+        __syncthreads();  // everyone is done reading xbuf / hbuf[cur]; hbuf[nxt] is complete
+        if (s + 1 < T_STEPS && !(a.ablate & 2)) {
+            x_store();
+            __syncthreads();
+        }
     }
 }
 
@@ -315,19 +415,20 @@ __global__ __launch_bounds__(256, 1) void k_head_tail(TailArgs a) {
 }
 
 // ---- host-side weight packing -----------------------------------------------------------------------
-// LSTM layer: gate column of (wave w, tile nt, lane) = (nt>>1)*H + 64w + 32(nt&1) + (lane&31)
-static void pack_lstm(const pv_rnn_dir* dirs, int K, int KP, std::vector<float>& wp, std::vector<float>& bias) {
-    const int nkb = (KP + H) / 8;
-    wp.assign((size_t)2 * 4 * nkb * 8 * 256, 0.0f);
+// LSTM layer, NW waves per workgroup: NT = 32/NW tiles per wave, S2 = NT/4 sub-tiles;
+// gate column of (wave w, tile nt, lane) = (nt/S2)*H + (H/NW)*w + 32*(nt%S2) + (lane&31)
+static void pack_lstm(const pv_rnn_dir* dirs, int K, int KP, int NW, std::vector<float>& wp, std::vector<float>& bias) {
+    const int nkb = (KP + H) / 8, NT = 32 / NW, S2 = NT / 4, UW = H / NW;
+    wp.assign((size_t)2 * NW * nkb * NT * 256, 0.0f);
     bias.assign((size_t)2 * 4 * H, 0.0f);
     for (int d = 0; d < 2; d++) {
         for (int n = 0; n < 4 * H; n++) bias[(size_t)d * 4 * H + n] = dirs[d].b_ih[n] + dirs[d].b_hh[n];
-        for (int w = 0; w < 4; w++)
+        for (int w = 0; w < NW; w++)
             for (int kb = 0; kb < nkb; kb++)
-                for (int nt = 0; nt < 8; nt++)
+                for (int nt = 0; nt < NT; nt++)
                     for (int lane = 0; lane < 64; lane++) {
-                        const int n = (nt >> 1) * H + 64 * w + 32 * (nt & 1) + (lane & 31);
-                        float* dst = &wp[((((size_t)(d * 4 + w) * nkb + kb) * 8 + nt) * 64 + lane) * 4];
+                        const int n = (nt / S2) * H + UW * w + 32 * (nt % S2) + (lane & 31);
+                        float* dst = &wp[((((size_t)(d * NW + w) * nkb + kb) * NT + nt) * 64 + lane) * 4];
                         for (int j = 0; j < 4; j++) {
                             const int k = kb * 8 + 4 * (lane >> 5) + j;
                             float v = 0.0f;
@@ -367,6 +468,7 @@ struct pv_rnn_p1 {
     float* bl[4] = {nullptr, nullptr, nullptr, nullptr};
     float* wo = nullptr; float* bo = nullptr;
     int dtype = PV_DTYPE_F32;
+    int nw = 8;  // waves per LSTM workgroup (PV_LSTM_WAVES=4|8)
     std::vector<void*> owned;
 };
 struct pv_rnn_p2 {
@@ -421,9 +523,10 @@ extern "C" int pv_rnn_load_p1(pv_ctx* ctx, const pv_weights_p1* w, int dtype) {
     m->dtype = dtype;
     std::vector<float> wp, bias;
     int rc;
-    pack_lstm(w->encoder, F_IN, 32, wp, bias);
+    if (const char* e = getenv("PV_LSTM_WAVES")) m->nw = (atoi(e) == 4) ? 4 : 8;
+    pack_lstm(w->encoder, F_IN, 32, m->nw, wp, bias);
     if ((rc = dev_upload(wp, &m->enc_wp, m->owned)) || (rc = dev_upload(bias, &m->enc_bias, m->owned))) return rc;
-    pack_lstm(w->decoder, 2 * H, 2 * H, wp, bias);
+    pack_lstm(w->decoder, 2 * H, 2 * H, m->nw, wp, bias);
     if ((rc = dev_upload(wp, &m->dec_wp, m->owned)) || (rc = dev_upload(bias, &m->dec_bias, m->owned))) return rc;
     pack_linear(w->linear_w[0], HEAD_K, wp);
     if ((rc = dev_upload(wp, &m->w1p, m->owned)) || (rc = dev_upload(w->linear_b[0], HEAD_N, &m->b1, m->owned))) return rc;
@@ -434,8 +537,10 @@ extern "C" int pv_rnn_load_p1(pv_ctx* ctx, const pv_weights_p1* w, int dtype) {
     }
     if ((rc = dev_upload(w->out_w, 3 * HEAD_N, &m->wo, m->owned)) || (rc = dev_upload(w->out_b, 3, &m->bo, m->owned))) return rc;
     // opt in to > 64 KB of dynamic LDS (exact sizes; static LDS counts against the 160 KB too)
-    PV_HIP(hipFuncSetAttribute((const void*)k_lstm_layer<32, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_ENC));
-    PV_HIP(hipFuncSetAttribute((const void*)k_lstm_layer<512, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_DEC));
+    PV_HIP(hipFuncSetAttribute((const void*)k_lstm_layer<32, true, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_ENC));
+    PV_HIP(hipFuncSetAttribute((const void*)k_lstm_layer<512, false, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_DEC));
+    PV_HIP(hipFuncSetAttribute((const void*)k_lstm_layer<32, true, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_ENC));
+    PV_HIP(hipFuncSetAttribute((const void*)k_lstm_layer<512, false, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_DEC));
     PV_HIP(hipFuncSetAttribute((const void*)k_head_splitk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_SPLITK));
     PV_HIP(hipFuncSetAttribute((const void*)k_head_tail, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_TAIL));
     return PV_OK;
@@ -447,11 +552,20 @@ static int p1_forward_launch(pv_ctx* ctx, const int8_t* d_images, int64_t B, flo
     const int n_tiles = (int)((B + ROWS - 1) / ROWS);
     const unsigned lstm_grid = (unsigned)(((n_tiles + 3) / 4) * 8);
     LstmArgs e;
+    e.ablate = getenv("PV_ABLATE") ? atoi(getenv("PV_ABLATE")) : 0;
     e.x_i8 = d_images; e.x_f32 = nullptr; e.wp = m->enc_wp; e.bias = m->enc_bias; e.out = enc_out; e.B = B; e.n_tiles = n_tiles;
-    { pv_prof_scope ps(ctx, "k_lstm_layer_enc", st); k_lstm_layer<32, true><<<lstm_grid, 256, LDS_ENC, st>>>(e); }
+    {
+        pv_prof_scope ps(ctx, "k_lstm_layer_enc", st);
+        if (m->nw == 8) k_lstm_layer<32, true, 8><<<lstm_grid, 512, LDS_ENC, st>>>(e);
+        else k_lstm_layer<32, true, 4><<<lstm_grid, 256, LDS_ENC, st>>>(e);
+    }
     LstmArgs d = e;
     d.x_i8 = nullptr; d.x_f32 = enc_out; d.wp = m->dec_wp; d.bias = m->dec_bias; d.out = dec_out;
-    { pv_prof_scope ps(ctx, "k_lstm_layer_dec", st); k_lstm_layer<512, false><<<lstm_grid, 256, LDS_DEC, st>>>(d); }
+    {
+        pv_prof_scope ps(ctx, "k_lstm_layer_dec", st);
+        if (m->nw == 8) k_lstm_layer<512, false, 8><<<lstm_grid, 512, LDS_DEC, st>>>(d);
+        else k_lstm_layer<512, false, 4><<<lstm_grid, 256, LDS_DEC, st>>>(d);
+    }
     HeadArgs h;
     h.dec = dec_out; h.w1p = m->w1p; h.part = part; h.B = B; h.n_tiles = n_tiles;
     { pv_prof_scope ps(ctx, "k_head_splitk", st); k_head_splitk<<<(unsigned)(n_tiles * HEAD_SPLITS), 256, LDS_SPLITK, st>>>(h); }
