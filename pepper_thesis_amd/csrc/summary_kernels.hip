@@ -33,8 +33,9 @@ constexpr int NCNT = 21;
 constexpr int C_COV = 0, C_SNP = 1, C_INS = 2, C_DEL = 3, C_RARE = 4, C_PLANE = 5;
 constexpr int32_t OP_INACTIVE = 0x7fffffff;
 constexpr int UMAX = 1024;  // distinct alleles per site held in LDS
+constexpr int TILE_COLS = 512;  // columns per pileup tile (one workgroup accumulates a tile in LDS)
 
-enum { D_NSITES = 0, D_NEVENTS = 1, D_NOUT = 2, D_STRBYTES = 3, D_STATUS = 4, D_NDIAG = 8 };
+enum { D_NSITES = 0, D_NEVENTS = 1, D_NOUT = 2, D_STRBYTES = 3, D_STATUS = 4, D_NPAIRS = 5, D_NDIAG = 8 };
 
 struct Event {  // 16 B
     int64_t src;  // index into bases (kind 1) or ref (kind 2)
@@ -58,6 +59,12 @@ struct AlleleRec {  // 32 B
     int32_t pad2;
 };
 
+struct PairRec {  // 48 B: everything a tile workgroup needs to walk one (read, tile) pair
+    int32_t read, op_lo, op_hi, col_base;
+    int32_t R, c_last, ref_len, rev;
+    int64_t base0, seq_end;
+};
+
 struct SumArgs {
     pv_batch_in in;
     pv_params p;
@@ -67,6 +74,14 @@ struct SumArgs {
     int32_t* op_read;
     uint8_t* op_flag;
     int32_t* read_region;
+    int32_t* read_t0;
+    int32_t* read_t1;
+    int32_t* tile_cnt;   // [n_tiles] (read, tile) pairs per tile
+    int32_t* tile_off;   // [n_tiles] exclusive scan
+    int32_t* tile_fill;
+    PairRec* pairs;      // [n_pairs]
+    int64_t n_tiles;
+    int64_t max_pairs;
     int32_t* cnt;
     uint8_t* flags;
     int32_t* site_rank;
@@ -168,6 +183,50 @@ __global__ __launch_bounds__(256) void k_cigar_scan(SumArgs a) {
         ref_rel += __shfl(ir, 63, 64);
         rd += __shfl(iq, 63, 64);
     }
+    // Column span that this read can touch: every effect of populate_summary_matrix lies between the
+    // column before its first position (an insert anchored at pos-1 after a leading soft clip) and its
+    // last reference-consumed column, clipped to the region. One (read, tile) pair per overlapped tile.
+    int64_t lo = a.in.read_pos[r] - a.in.ref_start[g] - 1, hi = ref_rel - 1;
+    if (lo < 0) lo = 0;
+    if (hi > R - 1) hi = R - 1;
+    const int64_t cb0 = a.in.ref_off[g];
+    int32_t t0 = 0, t1 = -1;
+    if (!skip && hi >= lo) { t0 = (int32_t)((cb0 + lo) / TILE_COLS); t1 = (int32_t)((cb0 + hi) / TILE_COLS); }
+    if (lane == 0) { a.read_t0[r] = t0; a.read_t1[r] = t1; }
+    for (int32_t t = t0 + lane; t <= t1; t += 64) atomicAdd(&a.tile_cnt[t], 1);
+}
+
+// One wave per read, one lane per overlapped tile: claim a slot in the tile's pair list and record the
+// op range [op_lo, op_hi) of the read that can touch the tile (binary searches over the per-op start
+// columns; an op starting one column past the tile may still anchor an indel on the tile's last column).
+__global__ __launch_bounds__(256) void k_tile_fill(SumArgs a) {
+    const int lane = threadIdx.x & 63;
+    const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= a.n_reads || a.diag[D_STATUS] != 0) return;
+    const int32_t t0 = a.read_t0[r], t1 = a.read_t1[r];
+    if (t1 < t0) return;
+    const int g = a.read_region[r];
+    const int64_t cb0 = a.in.ref_off[g];
+    const int32_t c0 = (int32_t)a.in.cigar_off[r], c1 = (int32_t)a.in.cigar_off[r + 1];
+    for (int32_t t = t0 + lane; t <= t1; t += 64) {
+        const int64_t tlo = (int64_t)t * TILE_COLS - cb0, thi = tlo + TILE_COLS - 1;  // region-relative columns
+        int32_t lo = c0, hi = c1;  // first op with op_ref >= tlo
+        while (lo < hi) { const int32_t mid = (lo + hi) >> 1; if ((int64_t)a.op_ref[mid] < tlo) lo = mid + 1; else hi = mid; }
+        int32_t op_lo = lo > c0 ? lo - 1 : c0;
+        lo = op_lo; hi = c1;  // first op with op_ref > thi + 1
+        while (lo < hi) { const int32_t mid = (lo + hi) >> 1; if ((int64_t)a.op_ref[mid] <= thi + 1) lo = mid + 1; else hi = mid; }
+        const int32_t op_hi = lo;
+        const int32_t slot = a.tile_off[t] + atomicAdd(&a.tile_fill[t], 1);
+        PairRec pr;
+        pr.read = (int32_t)r; pr.op_lo = op_lo; pr.op_hi = op_hi; pr.col_base = (int32_t)cb0;
+        pr.R = (int32_t)(a.in.ref_end[g] - a.in.ref_start[g] + 1);
+        pr.c_last = c1 - 1;
+        pr.ref_len = (int32_t)(a.in.ref_off[g + 1] - cb0);
+        pr.rev = a.in.read_flags[r] & 1;
+        pr.base0 = a.in.base_off[r];
+        pr.seq_end = a.in.base_off[r + 1];
+        a.pairs[slot] = pr;
+    }
 }
 
 // ---- K2 -------------------------------------------------------------------------------------------
@@ -209,110 +268,175 @@ __device__ __forceinline__ OpCtx load_op(const SumArgs& a, int64_t c) {
     return o;
 }
 
-__global__ __launch_bounds__(256) void k_pileup(SumArgs a) {
-    __shared__ int32_t s_pref[4][64];
-    __shared__ int32_t s_col0[4][64];   // column of op offset 0
-    __shared__ int64_t s_base[4][64];   // global base index of op offset 0
-    __shared__ int64_t s_end[4][64];
-    __shared__ int32_t s_i0[4][64];
-    __shared__ int32_t s_meta[4][64];   // len-1 (31 bits would overflow: see below) packed separately
-    __shared__ uint8_t s_fl[4][64];     // bit0 rev, bit1 anchor_next
+// One workgroup per TILE of TILE_COLS columns. All 21 counters of the tile live in LDS for the whole
+// kernel (ds_add instead of global atomics) and are written out once with coalesced stores, so the
+// counter planes need no memset and see no global atomics. The workgroup's 4 waves walk the tile's
+// (read, op range) pairs; inside a pair, 64 ops at a time: one lane per op for the indel bookkeeping,
+// then the aligned bases of all 64 ops are expanded over the lanes (prefix sum + binary search), so
+// that lanes stay busy whatever the CIGAR run lengths are and base/qual bytes are read coalesced.
+constexpr int PT_WAVES = 8;  // waves per tile workgroup
+__global__ __launch_bounds__(PT_WAVES * 64) void k_pileup_tiles(SumArgs a) {
+    __shared__ int32_t s_cnt[NCNT][TILE_COLS];
+    __shared__ int32_t s_pref[PT_WAVES][64];
+    __shared__ int32_t s_col0[PT_WAVES][64];   // global column of op offset 0
+    __shared__ int64_t s_base[PT_WAVES][64];   // global base index of op offset 0
+    __shared__ int32_t s_i0[PT_WAVES][64];
+    __shared__ int32_t s_meta[PT_WAVES][64];   // len-1
+    __shared__ uint8_t s_fl[PT_WAVES][64];     // bit1 anchor_next
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int64_t c = ((int64_t)blockIdx.x * 4 + wv) * 64 + lane;
-    const OpCtx o = load_op(a, c);  // no early exit on status here: every wave must reach the barrier below
-    int32_t* cnt = a.cnt;
-    const int64_t NC = a.n_cols;
-    const int sbase = C_PLANE + (o.rev ? 8 : 0);
-
-    // (1) indel ops: one lane each
-    if (o.active && o.op == PV_CIGAR_IN) {  // :431-490
-        const int64_t anchor = (int64_t)o.ref_rel - 1;
-        if (anchor >= 0 && anchor < o.R && o.rd >= 1) {
-            const int64_t col = o.col_base + anchor;
-            const int64_t start = o.base0 + o.rd - 1;
-            const int64_t L = (int64_t)o.len + 1;
-            if (start + L > o.seq_end) {
-                set_status(a.diag, PV_ERR_INVALID);
-            } else {
-                int64_t qs = 0;
-                for (int64_t i = 0; i < L; i++) qs += a.in.quals[start + i];
-                const bool qok = (double)qs >= a.p.min_indel_baseq * (double)L;
-                if (qok && (double)a.in.quals[start] < a.p.min_snp_baseq) atomicAdd(&cnt[C_COV * NC + col], 1);  // :453
-                if (1 + L <= PV_MAX_ALLELE_KEY && qok) {
-                    if (is_acgt(up(a.in.ref[col]))) atomicAdd(&cnt[(sbase + 5) * NC + col], -1);
-                    atomicAdd(&cnt[C_INS * NC + col], 1);
-                    a.op_flag[c] = 1;
+    const int64_t tile = blockIdx.x;
+    const int64_t tlo = tile * TILE_COLS, thi = tlo + TILE_COLS - 1;  // global columns of this tile
+    for (int i = threadIdx.x; i < NCNT * TILE_COLS; i += PT_WAVES * 64) (&s_cnt[0][0])[i] = 0;
+    __syncthreads();
+    const int32_t p0 = a.tile_off[tile];
+    const int32_t np = a.tile_cnt[tile];
+    for (int32_t pi = wv; pi < np; pi += PT_WAVES) {
+        const PairRec pr = a.pairs[p0 + pi];
+        const int32_t op_lo = pr.op_lo, op_hi = pr.op_hi;
+        const int32_t col_base = pr.col_base;
+        const int64_t ref_len = pr.ref_len;
+        const int32_t R = pr.R;
+        const int64_t base0 = pr.base0, seq_end = pr.seq_end;
+        const bool rev = pr.rev != 0;
+        const int32_t c_last = pr.c_last;
+        const int sbase = C_PLANE + (rev ? 8 : 0);
+        // this tile's column range relative to the region, clipped to the region
+        int64_t clo = tlo - col_base, chi = thi - col_base;
+        if (clo < 0) clo = 0;
+        if (chi > R - 1) chi = R - 1;
+        for (int32_t cb = op_lo; cb < op_hi; cb += 64) {
+            const int32_t c = cb + lane;
+            int32_t ref_rel = 0, rd = 0, len = 0, op = 15;
+            bool active = false, anchor_next = false;
+            if (c < op_hi) {
+                ref_rel = a.op_ref[c];
+                active = ref_rel != OP_INACTIVE;
+                if (active) {
+                    const uint32_t w = a.in.cigar[c];
+                    op = w & 0xF;
+                    len = (int32_t)(w >> 4);
+                    rd = a.op_rd[c];
+                    if (c < c_last) {
+                        const int nop = a.in.cigar[c + 1] & 0xF;
+                        anchor_next = (nop == PV_CIGAR_IN || nop == PV_CIGAR_DEL);  // :381-391
+                    }
                 }
             }
-        }
-    } else if (o.active && o.op == PV_CIGAR_DEL) {  // :491-555
-        const int64_t anchor = (int64_t)o.ref_rel - 1;
-        if (anchor >= 0 && anchor < o.R) {
-            const int64_t col = o.col_base + anchor;
-            if (is_acgt(up(a.in.ref[col]))) atomicAdd(&cnt[(sbase + 6) * NC + col], -1);  // unconditional, :496
-            int64_t L = (int64_t)o.len + 1;
-            if (anchor + L > o.ref_len) L = o.ref_len - anchor;  // substr truncation, :500
-            if (1 + L <= PV_MAX_ALLELE_KEY) {
-                atomicAdd(&cnt[C_DEL * NC + col], 1);
-                a.op_flag[c] = 1;
+            // (1) indel ops: one lane each; an op belongs to the tile that owns its anchor column
+            if (active && op == PV_CIGAR_IN) {  // :431-490
+                const int64_t anchor = (int64_t)ref_rel - 1;
+                if (anchor >= clo && anchor <= chi && rd >= 1) {
+                    const int lc = (int)(col_base + anchor - tlo);
+                    const int64_t start = base0 + rd - 1;
+                    const int64_t L = (int64_t)len + 1;
+                    if (start + L > seq_end) {
+                        set_status(a.diag, PV_ERR_INVALID);
+                    } else {
+                        int64_t qs = 0;
+                        for (int64_t i = 0; i < L; i++) qs += a.in.quals[start + i];
+                        const bool qok = (double)qs >= a.p.min_indel_baseq * (double)L;
+                        if (qok && (double)a.in.quals[start] < a.p.min_snp_baseq) atomicAdd(&s_cnt[C_COV][lc], 1);  // :453
+                        if (1 + L <= PV_MAX_ALLELE_KEY && qok) {
+                            if (is_acgt(up(a.in.ref[col_base + anchor]))) atomicAdd(&s_cnt[sbase + 5][lc], -1);
+                            atomicAdd(&s_cnt[C_INS][lc], 1);
+                            a.op_flag[c] = 1;
+                        }
+                    }
+                }
+            } else if (active && op == PV_CIGAR_DEL) {  // :491-555
+                const int64_t anchor = (int64_t)ref_rel - 1;
+                if (anchor >= clo && anchor <= chi) {
+                    const int lc = (int)(col_base + anchor - tlo);
+                    if (is_acgt(up(a.in.ref[col_base + anchor]))) atomicAdd(&s_cnt[sbase + 6][lc], -1);  // unconditional, :496
+                    int64_t L = (int64_t)len + 1;
+                    if (anchor + L > ref_len) L = ref_len - anchor;  // substr truncation, :500
+                    if (1 + L <= PV_MAX_ALLELE_KEY) {
+                        atomicAdd(&s_cnt[C_DEL][lc], 1);
+                        a.op_flag[c] = 1;
+                    }
+                }
+                int64_t i0 = clo - ref_rel; if (i0 < 0) i0 = 0;
+                int64_t i1 = chi + 1 - ref_rel; if (i1 > len) i1 = len;
+                for (int64_t i = i0; i < i1; i++) {  // :542-552
+                    const int64_t col = (int64_t)col_base + ref_rel + i;
+                    if (is_acgt(up(a.in.ref[col]))) atomicAdd(&s_cnt[sbase + 7][(int)(col - tlo)], -1);
+                }
             }
-        }
-        int64_t i0 = o.ref_rel < 0 ? -(int64_t)o.ref_rel : 0;
-        int64_t i1 = (int64_t)o.R - o.ref_rel;
-        if (i1 > o.len) i1 = o.len;
-        for (int64_t i = i0; i < i1; i++) {  // :542-552
-            const int64_t col = o.col_base + o.ref_rel + i;
-            if (is_acgt(up(a.in.ref[col]))) atomicAdd(&cnt[(sbase + 7) * NC + col], -1);
-        }
-    }
-
-    // (2) aligned bases: expand the in-region part of every M/=/X op of this chunk over the lanes
-    const bool is_m = o.active && (o.op == PV_CIGAR_MATCH || o.op == PV_CIGAR_EQUAL || o.op == PV_CIGAR_DIFF);
-    int32_t i0 = 0, eff = 0;
-    if (is_m) {
-        int64_t lo = o.ref_rel < 0 ? -(int64_t)o.ref_rel : 0;
-        int64_t hi = (int64_t)o.R - o.ref_rel;
-        if (hi > o.len) hi = o.len;
-        if (hi > lo) { i0 = (int32_t)lo; eff = (int32_t)(hi - lo); }
-    }
-    const int32_t incl = wave_incl_scan32(eff, lane);
-    s_pref[wv][lane] = incl;
-    s_col0[wv][lane] = o.col_base + o.ref_rel;
-    s_base[wv][lane] = o.base0 + o.rd;
-    s_end[wv][lane] = o.seq_end;
-    s_i0[wv][lane] = i0 - (incl - eff);  // so that i = j + s_i0
-    s_meta[wv][lane] = o.len - 1;
-    s_fl[wv][lane] = (uint8_t)((o.rev ? 1 : 0) | (o.anchor_next ? 2 : 0));
-    __syncthreads();
-    const int32_t total = s_pref[wv][63];
-    for (int32_t j = lane; j < total; j += 64) {
-        int lo = 0, hi = 63;  // first lane whose inclusive prefix exceeds j
+            // (2) aligned bases of the chunk's M/=/X ops, clipped to tile and region
+            const bool is_m = active && (op == PV_CIGAR_MATCH || op == PV_CIGAR_EQUAL || op == PV_CIGAR_DIFF);
+            int32_t i0 = 0, eff = 0;
+            if (is_m) {
+                int64_t lo = clo - ref_rel; if (lo < 0) lo = 0;
+                int64_t hi = chi + 1 - ref_rel; if (hi > len) hi = len;
+                if (hi > lo) { i0 = (int32_t)lo; eff = (int32_t)(hi - lo); }
+            }
+            const int32_t incl = wave_incl_scan32(eff, lane);
+            s_pref[wv][lane] = incl;
+            s_col0[wv][lane] = col_base + ref_rel;
+            s_base[wv][lane] = base0 + rd;
+            s_i0[wv][lane] = i0 - (incl - eff);  // so that i = j + s_i0
+            s_meta[wv][lane] = len - 1;
+            s_fl[wv][lane] = (uint8_t)(anchor_next ? 2 : 0);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            const int32_t total = s_pref[wv][63];
+            constexpr int UB = 4;  // bases per lane per trip: all byte loads of a trip are issued before any is used
+            for (int32_t jb = 0; jb < total; jb += 64 * UB) {
+                int32_t ii[UB];
+                int64_t colv[UB];
+                int basev[UB], qv[UB], refv[UB], anc[UB];
+                bool ok[UB];
 #pragma unroll
-        for (int it = 0; it < 6; it++) {
-            const int mid = (lo + hi) >> 1;
-            if (s_pref[wv][mid] > j) hi = mid; else lo = mid + 1;
+                for (int u = 0; u < UB; u++) {
+                    const int32_t j = jb + u * 64 + lane;
+                    ok[u] = j < total;
+                    int lo = 0, hi = 63;  // first lane whose inclusive prefix exceeds j
+#pragma unroll
+                    for (int it = 0; it < 6; it++) {
+                        const int mid = (lo + hi) >> 1;
+                        if (s_pref[wv][mid] > j) hi = mid; else lo = mid + 1;
+                    }
+                    const int ow = lo;
+                    const int32_t i = j + s_i0[wv][ow];
+                    ii[u] = i;
+                    colv[u] = (int64_t)s_col0[wv][ow] + i;
+                    const int64_t bi = s_base[wv][ow] + i;
+                    anc[u] = ((s_fl[wv][ow] & 2) && i == s_meta[wv][ow]) ? 1 : 0;
+                    if (ok[u] && bi >= seq_end) { set_status(a.diag, PV_ERR_INVALID); ok[u] = false; }
+                    basev[u] = ok[u] ? a.in.bases[bi] : 0;
+                    qv[u] = ok[u] ? a.in.quals[bi] : 0;
+                    refv[u] = ok[u] ? a.in.ref[colv[u]] : 0;
+                }
+#pragma unroll
+                for (int u = 0; u < UB; u++) {
+                    const int base = basev[u], refb = refv[u];
+                    const bool qok = ok[u] && ((double)qv[u] >= a.p.min_snp_baseq);
+                    if (!qok) continue;
+                    const int lc = (int)(colv[u] - tlo);
+                    atomicAdd(&s_cnt[C_COV][lc], 1);                                  // :379
+                    if (!anc[u]) atomicAdd(&s_cnt[sbase][lc], -1);                    // :381-391 REFF/REFR
+                    const bool refvalid = is_acgt(up(refb));
+                    if (refvalid) atomicAdd(&s_cnt[sbase + sym_of(base)][lc], -1);   // :396,423
+                    const bool mism = refb != base;                                   // raw bytes, :394
+                    if (mism) atomicAdd(&s_cnt[C_SNP][lc], 1);
+                    const bool rare = mism && !(refvalid && is_acgt(base));
+                    const bool corr = refvalid && base != up(base) && is_acgt(up(base));
+                    if (rare || corr) atomicAdd(&s_cnt[C_RARE][lc], 1);
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __builtin_amdgcn_wave_barrier();  // the wave's staging arrays are rewritten by the next chunk
         }
-        const int ow = lo;
-        const int32_t i = j + s_i0[wv][ow];
-        const int64_t col = (int64_t)s_col0[wv][ow] + i;
-        const int64_t bi = s_base[wv][ow] + i;
-        if (bi >= s_end[wv][ow]) { set_status(a.diag, PV_ERR_INVALID); continue; }
-        const int fl = s_fl[wv][ow];
-        const int base = a.in.bases[bi];
-        const int q = a.in.quals[bi];
-        const int refb = a.in.ref[col];
-        const bool qok = (double)q >= a.p.min_snp_baseq;
-        if (!qok) continue;
-        const int pb = C_PLANE + ((fl & 1) ? 8 : 0);
-        atomicAdd(&cnt[C_COV * NC + col], 1);                                        // :379
-        if (!((fl & 2) && i == s_meta[wv][ow])) atomicAdd(&cnt[pb * NC + col], -1);  // :381-391 REFF/REFR
-        const bool refvalid = is_acgt(up(refb));
-        if (refvalid) atomicAdd(&cnt[(pb + sym_of(base)) * NC + col], -1);          // :396,423
-        const bool mism = refb != base;                                              // raw bytes, :394
-        if (mism) atomicAdd(&cnt[C_SNP * NC + col], 1);
-        const bool rare = mism && !(refvalid && is_acgt(base));
-        const bool corr = refvalid && base != up(base) && is_acgt(up(base));
-        if (rare || corr) atomicAdd(&cnt[C_RARE * NC + col], 1);
+    }
+    __syncthreads();
+    // flush: plane-major global counters, coalesced
+    const int64_t NC = a.n_cols;
+    int64_t ncol = NC - tlo;
+    if (ncol > TILE_COLS) ncol = TILE_COLS;
+    for (int i = threadIdx.x; i < NCNT * TILE_COLS; i += PT_WAVES * 64) {
+        const int k = i / TILE_COLS, lc = i - k * TILE_COLS;
+        if (lc < ncol) a.cnt[(int64_t)k * NC + tlo + lc] = s_cnt[k][lc];
     }
 }
 
@@ -419,6 +543,13 @@ __global__ __launch_bounds__(1024) void k_site_rank(SumArgs a) {
         a.site_region[rank] = upper_bound_i64(a.in.ref_off, a.in.n_regions + 1, col) - 1;
         a.site_nev[rank] = a.cnt[C_INS * NC + col] + a.cnt[C_DEL * NC + col] + a.cnt[C_RARE * NC + col];
         a.site_fill[rank] = 0;
+    }
+}
+
+__global__ void k_check_pairs(SumArgs a) {
+    if (a.diag[D_NPAIRS] > a.max_pairs) {
+        set_status(a.diag, PV_ERR_LIMIT);
+        for (int64_t t = 0; t < a.n_tiles; t++) a.tile_cnt[t] = 0;  // nothing is filled or walked
     }
 }
 
@@ -754,7 +885,7 @@ static inline unsigned int grid_for(int64_t n, int per) { return (unsigned int)(
 // Workspace + launch sequence. Everything asynchronous on `st`.
 static int summarize_launch(pv_ctx* ctx, const pv_batch_in* in, const pv_params* params, int64_t n_reads,
                             int64_t n_bases, int64_t n_cigar, int64_t n_cols, int64_t max_sites, int64_t max_events,
-                            const pv_batch_out* out, int64_t* d_counts, hipStream_t st) {
+                            int64_t max_pairs, const pv_batch_out* out, int64_t* d_counts, hipStream_t st) {
     PV_CHECK(params->candidate_window_size == 32 && params->feature_size == PV_FEATURES, PV_ERR_INVALID,
              "candidate_window_size must be 32 and feature_size 26 (got %d, %d)", params->candidate_window_size,
              params->feature_size);
@@ -776,6 +907,16 @@ static int summarize_launch(pv_ctx* ctx, const pv_batch_in* in, const pv_params*
     if ((rc = pv_get(ctx, "sum.op_read", nc1, &a.op_read))) return rc;
     if ((rc = pv_get(ctx, "sum.op_flag", nc1, &a.op_flag))) return rc;
     if ((rc = pv_get(ctx, "sum.read_region", nr1, &a.read_region))) return rc;
+    a.n_tiles = (n_cols + TILE_COLS - 1) / TILE_COLS;
+    // every read overlaps at most span/TILE_COLS + 2 tiles; the exact pair count is only known on the
+    // device, so bound it: sum over reads of (read span)/TILE + 2 <= (bases + deleted cols)/TILE + 2 reads
+    a.max_pairs = max_pairs;
+    if ((rc = pv_get(ctx, "sum.read_t0", nr1, &a.read_t0))) return rc;
+    if ((rc = pv_get(ctx, "sum.read_t1", nr1, &a.read_t1))) return rc;
+    if ((rc = pv_get(ctx, "sum.tile_cnt", a.n_tiles, &a.tile_cnt))) return rc;
+    if ((rc = pv_get(ctx, "sum.tile_off", a.n_tiles, &a.tile_off))) return rc;
+    if ((rc = pv_get(ctx, "sum.tile_fill", a.n_tiles, &a.tile_fill))) return rc;
+    if ((rc = pv_get(ctx, "sum.pairs", max_pairs, &a.pairs))) return rc;
     if ((rc = pv_get(ctx, "sum.cnt", (size_t)NCNT * n_cols, &a.cnt))) return rc;
     if ((rc = pv_get(ctx, "sum.flags", n_cols, &a.flags))) return rc;
     if ((rc = pv_get(ctx, "sum.site_rank", n_cols, &a.site_rank))) return rc;
@@ -796,9 +937,13 @@ static int summarize_launch(pv_ctx* ctx, const pv_batch_in* in, const pv_params*
 
     pv_prof_scope ps_all(ctx, "summary_pipeline", st);
     k_zero_diag<<<1, 64, 0, st>>>(a.diag);
-    PV_HIP(hipMemsetAsync(a.cnt, 0, (size_t)NCNT * n_cols * sizeof(int32_t), st));
+    PV_HIP(hipMemsetAsync(a.tile_cnt, 0, (size_t)a.n_tiles * sizeof(int32_t), st));
+    PV_HIP(hipMemsetAsync(a.tile_fill, 0, (size_t)a.n_tiles * sizeof(int32_t), st));
     if (n_reads > 0) { pv_prof_scope ps(ctx, "k_cigar_scan", st); k_cigar_scan<<<grid_for(n_reads, 4), 256, 0, st>>>(a); }
-    if (n_cigar > 0) { pv_prof_scope ps(ctx, "k_pileup", st); k_pileup<<<grid_for(n_cigar, 256), 256, 0, st>>>(a); }
+    k_scan_i32<<<1, 1024, 0, st>>>(a.tile_cnt, a.tile_off, a.n_tiles, nullptr, a.n_tiles, &a.diag[D_NPAIRS]);
+    k_check_pairs<<<1, 1, 0, st>>>(a);
+    if (n_reads > 0) { pv_prof_scope ps(ctx, "k_tile_fill", st); k_tile_fill<<<grid_for(n_reads, 4), 256, 0, st>>>(a); }
+    { pv_prof_scope ps(ctx, "k_pileup", st); k_pileup_tiles<<<(unsigned)a.n_tiles, PT_WAVES * 64, 0, st>>>(a); }
     k_site_scan<<<(unsigned)n_blk, 1024, 0, st>>>(a);
     k_scan_i32<<<1, 1024, 0, st>>>(a.blk_cnt, a.blk_off, n_blk, nullptr, n_blk, &a.diag[D_NSITES]);
     k_site_rank<<<(unsigned)n_blk, 1024, 0, st>>>(a);
@@ -815,8 +960,11 @@ static int summarize_launch(pv_ctx* ctx, const pv_batch_in* in, const pv_params*
     return PV_OK;
 }
 
-static void default_limits(int64_t n_cols, int64_t n_cigar, int64_t n_bases, int64_t capacity, int64_t* max_sites,
-                           int64_t* max_events) {
+static void default_limits(int64_t n_cols, int64_t n_cigar, int64_t n_bases, int64_t n_reads, int64_t capacity,
+                           int64_t* max_sites, int64_t* max_events, int64_t* max_pairs) {
+    // a read touches span/TILE_COLS + 2 tiles at most and its in-region span is bounded by its aligned
+    // bases plus deleted columns; deletions are rare, so allow 2x and let the device report overflow
+    *max_pairs = 2 * (n_bases / TILE_COLS) + 3 * n_reads + 64;
     int64_t s = n_cols / 8 + 1024;
     if (s < 2 * capacity) s = 2 * capacity;
     if (s > n_cols) s = n_cols;
@@ -833,8 +981,9 @@ extern "C" int pv_summarize_regions_dev(pv_ctx* ctx, const pv_batch_in* in, cons
     (void)max_region_len;
     PV_HIP(hipSetDevice(ctx->device));
     int64_t ms, me;
-    default_limits(n_ref_bytes, n_cigar, n_bases, out->capacity, &ms, &me);
-    return summarize_launch(ctx, in, params, n_reads, n_bases, n_cigar, n_ref_bytes > 0 ? n_ref_bytes : 1, ms, me, out,
+    int64_t mp;
+    default_limits(n_ref_bytes, n_cigar, n_bases, n_reads, out->capacity, &ms, &me, &mp);
+    return summarize_launch(ctx, in, params, n_reads, n_bases, n_cigar, n_ref_bytes > 0 ? n_ref_bytes : 1, ms, me, mp, out,
                             d_counts, pv_pick_stream(ctx, stream));
 }
 
@@ -904,16 +1053,17 @@ extern "C" int pv_summarize_regions(pv_ctx* ctx, const pv_batch_in* in, const pv
     int64_t* d_counts = nullptr;
     if ((rc = pv_get(ctx, "out.counts", (size_t)4, &d_counts))) return rc;
 
-    int64_t ms, me;
-    default_limits(n_cols, n_cigar, n_bases, cap, &ms, &me);
+    int64_t ms, me, mp;
+    default_limits(n_cols, n_cigar, n_bases, n_reads, cap, &ms, &me, &mp);
     for (int attempt = 0; attempt < 3; attempt++) {
-        rc = summarize_launch(ctx, &d, params, n_reads, n_bases, n_cigar, n_cols, ms, me, &dout, d_counts, st);
+        rc = summarize_launch(ctx, &d, params, n_reads, n_bases, n_cigar, n_cols, ms, me, mp, &dout, d_counts, st);
         if (rc) return rc;
         PV_HIP(hipMemcpyAsync(ctx->h_counts, d_counts, 4 * sizeof(int64_t), hipMemcpyDeviceToHost, st));
         PV_HIP(hipStreamSynchronize(st));
         if (ctx->h_counts[2] == PV_ERR_LIMIT && attempt < 2) {  // workspace heuristics too small: take exact bounds
             ms = n_cols;
             me = n_cigar + n_bases;
+            mp = n_reads * ((n_cols + TILE_COLS - 1) / TILE_COLS + 2);
             continue;
         }
         break;
