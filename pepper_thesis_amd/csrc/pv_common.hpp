@@ -124,3 +124,5 @@ static inline hipStream_t pv_pick_stream(pv_ctx* c, void* stream) { return strea
 
 // rnn_kernels.hip
 void pv_rnn_free(pv_ctx* ctx);
+// rnn_gru.hip
+void pv_rnn_free_p2(pv_ctx* ctx);

@@ -1,20 +1,395 @@
-// rnn_gru.hip — P2 (polisher bi-GRU) plan. Placeholder translation unit: entry points report
-// PV_ERR_STATE until the kernels land (tracked in DESIGN.md).
+// rnn_gru.hip — P2: the polisher's bidirectional-GRU encoder/decoder on gfx950 (MI355X), fp32.
+//
+// Reference semantics (pepper/modules/python/models/simple_model.py:27-42 and the sliding loop of
+// pepper/modules/python/models/predict.py:47-97): a chunk is 1000 pileup columns x 10 features (uint8).
+// 19 windows of 100 columns (stride 50) are pushed through
+//     enc = bi-GRU(10 -> 128)  with h0 = hidden carried from the previous window
+//     dec = bi-GRU(256 -> 128) with h0 = final encoder state of the same direction
+//     logits = Linear(256 -> 5)(dec_out);  acc[i : i+100] += softmax(logits);  hidden = final decoder state
+// and labels = argmax(acc). 3800 strictly sequential GRU steps per chunk.
+//
+// One PERSISTENT workgroup per 32-chunk batch tile runs the whole 19-window loop in a single launch:
+// 8 waves = 4 (forward direction) + 4 (reverse), wave w of a direction owns hidden units [32w,32w+32)
+// for the r, z, n gates, so the cell update is in-register; h lives in registers (update) and in a
+// double-buffered LDS tile (A operand of the next step's MFMA); the gate products run on the f32 MFMA
+// (v_mfma_f32_32x32x2_f32) with host-packed weight fragments streamed from L2 (1.6 MB for the whole
+// model); x_{t+1} is prefetched into registers behind step t's MFMAs. Encoder/decoder outputs of the
+// current window go through a per-tile scratch in HBM/L2 (the decoder needs both directions of the
+// encoder, the classifier both directions of the decoder); dense + softmax + accumulate and the final
+// argmax are fused into the same launch.
 #include "pv_common.hpp"
 
+#include <cstdlib>
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int SEQ = 1000, WIN = 100, JUMP = 50, NWIN = 19, FEAT = 10, NCLS = 5;
+constexpr int HG = 128;          // GRU hidden
+constexpr int ROWS = 32;         // chunks per workgroup
+constexpr int KPE = 16;          // encoder input padded to a multiple of 8
+constexpr int KPD = 2 * HG;      // decoder input
+constexpr int LDH = HG + 4;      // LDS row strides (floats): % 64 == 4 keeps ds_read_b128 conflict-free
+constexpr int LDXD = KPD + 4;
+
+__device__ __forceinline__ float rcpf_(float x) { return __builtin_amdgcn_rcpf(x); }
+__device__ __forceinline__ float sigmoidf_(float x) { return rcpf_(1.0f + __expf(-x)); }
+__device__ __forceinline__ float tanhf_(float x) {
+    const float e = __expf(2.0f * x);
+    return 1.0f - 2.0f * rcpf_(e + 1.0f);
+}
+
+// acc[nt] += A[32 x 8*nkb] . B for 3 gate tiles; see rnn_kernels.hip mma_panel for the fragment layout.
+__device__ __forceinline__ void mma3(f32x16& c0, f32x16& c1, f32x16& c2, const float* __restrict__ A, int lda,
+                                     const float* __restrict__ Bp, int nkb, int lane) {
+    const float* ap = A + (lane & 31) * lda + 4 * (lane >> 5);
+    const f32x4* bp = reinterpret_cast<const f32x4*>(Bp) + lane;
+    f32x4 b0[3], b1[3], a0, a1;
+#pragma unroll
+    for (int nt = 0; nt < 3; nt++) b0[nt] = bp[nt * 64];
+    a0 = *reinterpret_cast<const f32x4*>(ap);
+    int kb = 0;
+#pragma nounroll
+    for (; kb + 1 < nkb; kb += 2) {
+#pragma unroll
+        for (int nt = 0; nt < 3; nt++) b1[nt] = bp[((kb + 1) * 3 + nt) * 64];
+        a1 = *reinterpret_cast<const f32x4*>(ap + 8 * (kb + 1));
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+        {
+            c0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[j], b0[0][j], c0, 0, 0, 0);
+            c1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[j], b0[1][j], c1, 0, 0, 0);
+            c2 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[j], b0[2][j], c2, 0, 0, 0);
+        }
+        if (kb + 2 < nkb) {
+#pragma unroll
+            for (int nt = 0; nt < 3; nt++) b0[nt] = bp[((kb + 2) * 3 + nt) * 64];
+            a0 = *reinterpret_cast<const f32x4*>(ap + 8 * (kb + 2));
+        }
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+        {
+            c0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[j], b1[0][j], c0, 0, 0, 0);
+            c1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[j], b1[1][j], c1, 0, 0, 0);
+            c2 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[j], b1[2][j], c2, 0, 0, 0);
+        }
+    }
+    if (kb < nkb) {
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+        {
+            c0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[j], b0[0][j], c0, 0, 0, 0);
+            c1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[j], b0[1][j], c1, 0, 0, 0);
+            c2 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[j], b0[2][j], c2, 0, 0, 0);
+        }
+    }
+}
+
+struct GruArgs {
+    const uint8_t* images;  // [B,1000,10]
+    const float* enc_wp;    // packed [2 dirs][4 waves][(KPE+HG)/8 kb][3][64][4]
+    const float* dec_wp;    // packed [2 dirs][4 waves][(KPD+HG)/8 kb][3][64][4]
+    const float* enc_bias;  // [2 dirs][4][128]: b_ir+b_hr, b_iz+b_hz, b_in, b_hn
+    const float* dec_bias;
+    const float* dense_w;   // [5,256]
+    const float* dense_b;   // [5]
+    float* enc_out;         // scratch [n_tiles][100][32][256]
+    float* dec_out;         // scratch [n_tiles][100][32][256]
+    float* acc;             // [B,1000,5] (zero-initialised by the caller)
+    uint8_t* labels;        // [B,1000]
+    int64_t B;
+};
+
+// one GRU layer over one 100-column window for this wave's direction
+template <int KP, bool ENC>
+__device__ __forceinline__ void gru_window(const GruArgs& a, int win_start, int dir, int wq, int lane, int tid_dir,
+                                           int64_t b0, int tile, float* xbuf, float* hbuf, int& cur, f32x16& hst,
+                                           const float* wp, const float* bias, const float* x_src, float* out_dst) {
+    constexpr int LDX = KP + 4;
+    constexpr int NKB_X = KP / 8, NKB_H = HG / 8;
+    const int unit = 32 * wq + (lane & 31);
+    const float b_r = bias[0 * HG + unit], b_z = bias[1 * HG + unit], b_in = bias[2 * HG + unit], b_hn = bias[3 * HG + unit];
+    // register staging of x_t for this direction (256 threads per direction)
+    constexpr int V4 = KP / 4;
+    constexpr int XR = ENC ? 1 : (ROWS * V4 + 255) / 256;
+    f32x4 xr[XR];
+    float xe[ENC ? 2 : 1];  // encoder: 32 rows x 16 padded features = 512 floats / 256 threads
+    auto x_load = [&](int t) {
+        if constexpr (ENC) {
+#pragma unroll
+            for (int u = 0; u < 2; u++) {
+                const int i = tid_dir + u * 256;
+                const int row = i / KPE, k = i - row * KPE;
+                int64_t b = b0 + row;
+                if (b >= a.B) b = a.B - 1;
+                xe[u] = k < FEAT ? (float)a.images[(b * SEQ + win_start + t) * FEAT + k] : 0.0f;
+            }
+        } else {
+#pragma unroll
+            for (int u = 0; u < XR; u++) {
+                const int i = tid_dir + u * 256;
+                const int row = i / V4, c4 = i - row * V4;
+                xr[u] = *reinterpret_cast<const f32x4*>(x_src + ((size_t)t * ROWS + row) * KPD + c4 * 4);
+            }
+        }
+    };
+    auto x_store = [&]() {
+        if constexpr (ENC) {
+#pragma unroll
+            for (int u = 0; u < 2; u++) {
+                const int i = tid_dir + u * 256;
+                const int row = i / KPE, k = i - row * KPE;
+                xbuf[row * LDX + k] = xe[u];
+            }
+        } else {
+#pragma unroll
+            for (int u = 0; u < XR; u++) {
+                const int i = tid_dir + u * 256;
+                const int row = i / V4, c4 = i - row * V4;
+                *reinterpret_cast<f32x4*>(xbuf + row * LDX + c4 * 4) = xr[u];
+            }
+        }
+    };
+    x_load(dir ? WIN - 1 : 0);
+    x_store();
+    __syncthreads();
+    for (int s = 0; s < WIN; s++) {
+        const int t = dir ? (WIN - 1 - s) : s;
+        const int nxt = cur ^ 1;
+        if (s + 1 < WIN) x_load(dir ? (WIN - 2 - s) : (s + 1));
+        f32x16 ar, az, anx, anh;  // r and z accumulate both products; n keeps its x and h parts apart
+#pragma unroll
+        for (int r = 0; r < 16; r++) { ar[r] = b_r; az[r] = b_z; anx[r] = b_in; anh[r] = b_hn; }
+        mma3(ar, az, anx, xbuf, LDX, wp, NKB_X, lane);
+        mma3(ar, az, anh, hbuf + cur * ROWS * LDH, LDH, wp + (size_t)NKB_X * 3 * 256, NKB_H, lane);
+        float* hn = hbuf + nxt * ROWS * LDH;
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const float rg = sigmoidf_(ar[r]);
+            const float zg = sigmoidf_(az[r]);
+            const float ng = tanhf_(anx[r] + rg * anh[r]);
+            const float h = (1.0f - zg) * ng + zg * hst[r];
+            hst[r] = h;
+            const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            hn[row * LDH + unit] = h;
+            out_dst[((size_t)t * ROWS + row) * KPD + dir * HG + unit] = h;
+        }
+        cur = nxt;
+        __syncthreads();
+        if (s + 1 < WIN) {
+            x_store();
+            __syncthreads();
+        }
+    }
+    (void)tile;
+}
+
+__global__ __launch_bounds__(512, 2) void k_gru_p2(GruArgs a) {
+    extern __shared__ float smem[];
+    // per direction: hbuf [2][32][LDH], xbuf [32][LDXD]
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int dir = wv >> 2, wq = wv & 3, tid_dir = tid & 255;
+    float* hbuf = smem + dir * (2 * ROWS * LDH + ROWS * LDXD);
+    float* xbuf = hbuf + 2 * ROWS * LDH;
+    const int tile = blockIdx.x;
+    const int64_t b0 = (int64_t)tile * ROWS;
+    float* enc_out = a.enc_out + (size_t)tile * WIN * ROWS * KPD;
+    float* dec_out = a.dec_out + (size_t)tile * WIN * ROWS * KPD;
+    const float* enc_wp = a.enc_wp + ((size_t)(dir * 4 + wq) * ((KPE + HG) / 8)) * 3 * 256;
+    const float* dec_wp = a.dec_wp + ((size_t)(dir * 4 + wq) * ((KPD + HG) / 8)) * 3 * 256;
+    const float* enc_bias = a.enc_bias + dir * 4 * HG;
+    const float* dec_bias = a.dec_bias + dir * 4 * HG;
+
+    for (int i = tid_dir; i < 2 * ROWS * LDH; i += 256) hbuf[i] = 0.0f;  // hidden = zeros (predict.py:55)
+    f32x16 hst;
+#pragma unroll
+    for (int r = 0; r < 16; r++) hst[r] = 0.0f;
+    int cur = 0;
+    __syncthreads();
+
+    for (int w = 0; w < NWIN; w++) {
+        const int ws = w * JUMP;
+        gru_window<KPE, true>(a, ws, dir, wq, lane, tid_dir, b0, tile, xbuf, hbuf, cur, hst, enc_wp, enc_bias, nullptr, enc_out);
+        // decoder h0 = encoder final state of the same direction: hst / hbuf[cur] simply carry over
+        gru_window<KPD, false>(a, ws, dir, wq, lane, tid_dir, b0, tile, xbuf, hbuf, cur, hst, dec_wp, dec_bias, enc_out, dec_out);
+        // dense1 + softmax + accumulate over the window (predict.py:70-89); 3200 (row, t) pairs
+        for (int p = tid; p < ROWS * WIN; p += 512) {
+            const int t = p / ROWS, row = p - t * ROWS;
+            const int64_t b = b0 + row;
+            if (b >= a.B) continue;
+            const float* d = dec_out + ((size_t)t * ROWS + row) * KPD;
+            float lg[NCLS];
+#pragma unroll
+            for (int c = 0; c < NCLS; c++) lg[c] = a.dense_b[c];
+            for (int k = 0; k < KPD; k += 4) {
+                const f32x4 v = *reinterpret_cast<const f32x4*>(d + k);
+#pragma unroll
+                for (int c = 0; c < NCLS; c++) {
+                    const f32x4 wv4 = *reinterpret_cast<const f32x4*>(a.dense_w + c * KPD + k);
+                    lg[c] += v[0] * wv4[0] + v[1] * wv4[1] + v[2] * wv4[2] + v[3] * wv4[3];
+                }
+            }
+            float m = lg[0];
+#pragma unroll
+            for (int c = 1; c < NCLS; c++) m = fmaxf(m, lg[c]);
+            float e[NCLS], sum = 0.0f;
+#pragma unroll
+            for (int c = 0; c < NCLS; c++) { e[c] = expf(lg[c] - m); sum += e[c]; }
+            const float inv = 1.0f / sum;
+            float* ac = a.acc + ((size_t)b * SEQ + ws + t) * NCLS;
+#pragma unroll
+            for (int c = 0; c < NCLS; c++) ac[c] += e[c] * inv;
+        }
+        __syncthreads();
+    }
+    // labels = argmax over the 5 classes, first maximum wins (torch.max, predict.py:91)
+    for (int p = tid; p < ROWS * SEQ; p += 512) {
+        const int row = p / SEQ, pos = p - row * SEQ;
+        const int64_t b = b0 + row;
+        if (b >= a.B) continue;
+        const float* ac = a.acc + ((size_t)b * SEQ + pos) * NCLS;
+        int best = 0;
+        float bv = ac[0];
+#pragma unroll
+        for (int c = 1; c < NCLS; c++) if (ac[c] > bv) { bv = ac[c]; best = c; }
+        a.labels[(size_t)b * SEQ + pos] = (uint8_t)best;
+    }
+}
+
+// gate column of (wave w, tile nt in {r,z,n}, lane) = nt*HG + 32w + (lane&31); K = [x (padded to KP) | h]
+void pack_gru(const pv_rnn_dir* dirs, int K, int KP, std::vector<float>& wp, std::vector<float>& bias) {
+    const int nkb = (KP + HG) / 8;
+    wp.assign((size_t)2 * 4 * nkb * 3 * 256, 0.0f);
+    bias.assign((size_t)2 * 4 * HG, 0.0f);
+    for (int d = 0; d < 2; d++) {
+        for (int u = 0; u < HG; u++) {
+            bias[(size_t)d * 4 * HG + 0 * HG + u] = dirs[d].b_ih[0 * HG + u] + dirs[d].b_hh[0 * HG + u];
+            bias[(size_t)d * 4 * HG + 1 * HG + u] = dirs[d].b_ih[1 * HG + u] + dirs[d].b_hh[1 * HG + u];
+            bias[(size_t)d * 4 * HG + 2 * HG + u] = dirs[d].b_ih[2 * HG + u];
+            bias[(size_t)d * 4 * HG + 3 * HG + u] = dirs[d].b_hh[2 * HG + u];
+        }
+        for (int w = 0; w < 4; w++)
+            for (int kb = 0; kb < nkb; kb++)
+                for (int nt = 0; nt < 3; nt++)
+                    for (int lane = 0; lane < 64; lane++) {
+                        const int n = nt * HG + 32 * w + (lane & 31);
+                        float* dst = &wp[((((size_t)(d * 4 + w) * nkb + kb) * 3 + nt) * 64 + lane) * 4];
+                        for (int j = 0; j < 4; j++) {
+                            const int k = kb * 8 + 4 * (lane >> 5) + j;
+                            float v = 0.0f;
+                            if (k < KP) { if (k < K) v = dirs[d].w_ih[(size_t)n * K + k]; }
+                            else v = dirs[d].w_hh[(size_t)n * HG + (k - KP)];
+                            dst[j] = v;
+                        }
+                    }
+    }
+}
+
+constexpr size_t LDS_P2 = (size_t)2 * (2 * ROWS * LDH + ROWS * LDXD) * sizeof(float);
+
+}  // namespace
+
+struct pv_rnn_p2 {
+    float* enc_wp = nullptr; float* enc_bias = nullptr;
+    float* dec_wp = nullptr; float* dec_bias = nullptr;
+    float* dense_w = nullptr; float* dense_b = nullptr;
+    std::vector<void*> owned;
+};
+
+static int up2(const float* h, size_t n, float** d, std::vector<void*>& owned) {
+    PV_HIP(hipMalloc((void**)d, n * sizeof(float)));
+    owned.push_back(*d);
+    PV_HIP(hipMemcpy(*d, h, n * sizeof(float), hipMemcpyHostToDevice));
+    return PV_OK;
+}
+
+void pv_rnn_free_p2(pv_ctx* ctx) {
+    if (ctx->p2) {
+        for (void* p : ctx->p2->owned) (void)hipFree(p);
+        delete ctx->p2;
+        ctx->p2 = nullptr;
+    }
+}
+
 extern "C" int pv_rnn_load_p2(pv_ctx* ctx, const pv_weights_p2* w, int dtype) {
-    (void)ctx; (void)w; (void)dtype;
-    pv_set_error("P2 (bi-GRU) plan is not built yet");
-    return PV_ERR_STATE;
+    PV_CHECK(ctx && w, PV_ERR_INVALID, "null argument");
+    PV_CHECK(dtype == PV_DTYPE_F32, PV_ERR_INVALID, "dtype %d not implemented (only PV_DTYPE_F32)", dtype);
+    for (int d = 0; d < 2; d++)
+        PV_CHECK(w->encoder[d].w_ih && w->encoder[d].w_hh && w->encoder[d].b_ih && w->encoder[d].b_hh &&
+                     w->decoder[d].w_ih && w->decoder[d].w_hh && w->decoder[d].b_ih && w->decoder[d].b_hh,
+                 PV_ERR_INVALID, "missing GRU tensor");
+    PV_CHECK(w->dense_w && w->dense_b, PV_ERR_INVALID, "missing dense1");
+    PV_HIP(hipSetDevice(ctx->device));
+    if (ctx->p2) {
+        PV_HIP(hipStreamSynchronize(ctx->stream));
+        pv_rnn_free_p2(ctx);
+    }
+    pv_rnn_p2* m = new pv_rnn_p2();
+    ctx->p2 = m;
+    std::vector<float> wp, bias;
+    int rc;
+    pack_gru(w->encoder, FEAT, KPE, wp, bias);
+    if ((rc = up2(wp.data(), wp.size(), &m->enc_wp, m->owned)) || (rc = up2(bias.data(), bias.size(), &m->enc_bias, m->owned))) return rc;
+    pack_gru(w->decoder, KPD, KPD, wp, bias);
+    if ((rc = up2(wp.data(), wp.size(), &m->dec_wp, m->owned)) || (rc = up2(bias.data(), bias.size(), &m->dec_bias, m->owned))) return rc;
+    if ((rc = up2(w->dense_w, (size_t)NCLS * KPD, &m->dense_w, m->owned)) || (rc = up2(w->dense_b, NCLS, &m->dense_b, m->owned))) return rc;
+    PV_HIP(hipFuncSetAttribute((const void*)k_gru_p2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_P2));
+    return PV_OK;
 }
-extern "C" int pv_rnn_forward_p2(pv_ctx* ctx, const uint8_t* images, int64_t B, uint8_t* labels, float* acc) {
-    (void)ctx; (void)images; (void)B; (void)labels; (void)acc;
-    pv_set_error("P2 (bi-GRU) plan is not built yet");
-    return PV_ERR_STATE;
+
+static int p2_launch(pv_ctx* ctx, const uint8_t* d_images, int64_t B, uint8_t* d_labels, float* d_acc, hipStream_t st) {
+    pv_rnn_p2* m = ctx->p2;
+    const int64_t n_tiles = (B + ROWS - 1) / ROWS;
+    GruArgs g;
+    g.images = d_images;
+    g.enc_wp = m->enc_wp; g.dec_wp = m->dec_wp; g.enc_bias = m->enc_bias; g.dec_bias = m->dec_bias;
+    g.dense_w = m->dense_w; g.dense_b = m->dense_b;
+    int rc;
+    if ((rc = pv_get(ctx, "p2.enc_out", (size_t)n_tiles * WIN * ROWS * KPD, &g.enc_out))) return rc;
+    if ((rc = pv_get(ctx, "p2.dec_out", (size_t)n_tiles * WIN * ROWS * KPD, &g.dec_out))) return rc;
+    g.acc = d_acc;
+    if (!g.acc)
+        if ((rc = pv_get(ctx, "p2.acc", (size_t)B * SEQ * NCLS, &g.acc))) return rc;
+    g.labels = d_labels;
+    g.B = B;
+    PV_HIP(hipMemsetAsync(g.acc, 0, (size_t)B * SEQ * NCLS * sizeof(float), st));
+    {
+        pv_prof_scope ps(ctx, "k_gru_p2", st);
+        k_gru_p2<<<(unsigned)n_tiles, 512, LDS_P2, st>>>(g);
+    }
+    PV_HIP(hipGetLastError());
+    return PV_OK;
 }
+
 extern "C" int pv_rnn_forward_p2_dev(pv_ctx* ctx, const uint8_t* d_images, int64_t B, uint8_t* d_labels, float* d_acc,
                                      void* stream) {
-    (void)ctx; (void)d_images; (void)B; (void)d_labels; (void)d_acc; (void)stream;
-    pv_set_error("P2 (bi-GRU) plan is not built yet");
-    return PV_ERR_STATE;
+    PV_CHECK(ctx && d_images && d_labels, PV_ERR_INVALID, "null argument");
+    PV_CHECK(ctx->p2, PV_ERR_STATE, "pv_rnn_load_p2 has not been called on this context");
+    PV_CHECK(B >= 0 && B < (1ll << 22), PV_ERR_INVALID, "batch %lld out of range", (long long)B);
+    if (B == 0) return PV_OK;
+    PV_HIP(hipSetDevice(ctx->device));
+    return p2_launch(ctx, d_images, B, d_labels, d_acc, pv_pick_stream(ctx, stream));
+}
+
+extern "C" int pv_rnn_forward_p2(pv_ctx* ctx, const uint8_t* images, int64_t B, uint8_t* labels, float* acc) {
+    PV_CHECK(ctx && images && labels, PV_ERR_INVALID, "null argument");
+    PV_CHECK(ctx->p2, PV_ERR_STATE, "pv_rnn_load_p2 has not been called on this context");
+    PV_CHECK(B >= 0 && B < (1ll << 22), PV_ERR_INVALID, "batch %lld out of range", (long long)B);
+    if (B == 0) return PV_OK;
+    PV_HIP(hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    uint8_t *d_img, *d_lab;
+    float* d_acc;
+    int rc;
+    if ((rc = pv_get(ctx, "p2.images", (size_t)B * SEQ * FEAT, &d_img))) return rc;
+    if ((rc = pv_get(ctx, "p2.labels", (size_t)B * SEQ, &d_lab))) return rc;
+    if ((rc = pv_get(ctx, "p2.acc", (size_t)B * SEQ * NCLS, &d_acc))) return rc;
+    PV_HIP(hipMemcpyAsync(d_img, images, (size_t)B * SEQ * FEAT, hipMemcpyHostToDevice, st));
+    if ((rc = p2_launch(ctx, d_img, B, d_lab, d_acc, st))) return rc;
+    PV_HIP(hipMemcpyAsync(labels, d_lab, (size_t)B * SEQ, hipMemcpyDeviceToHost, st));
+    if (acc) PV_HIP(hipMemcpyAsync(acc, d_acc, (size_t)B * SEQ * NCLS * sizeof(float), hipMemcpyDeviceToHost, st));
+    PV_HIP(hipStreamSynchronize(st));
+    return PV_OK;
 }

@@ -471,9 +471,6 @@ struct pv_rnn_p1 {
     int nw = 8;  // waves per LSTM workgroup (PV_LSTM_WAVES=4|8)
     std::vector<void*> owned;
 };
-struct pv_rnn_p2 {
-    std::vector<void*> owned;
-};
 
 static int dev_upload(const std::vector<float>& h, float** d, std::vector<void*>& owned) {
     PV_HIP(hipMalloc((void**)d, h.size() * sizeof(float)));
@@ -494,11 +491,7 @@ void pv_rnn_free(pv_ctx* ctx) {
         delete ctx->p1;
         ctx->p1 = nullptr;
     }
-    if (ctx->p2) {
-        for (void* p : ctx->p2->owned) (void)hipFree(p);
-        delete ctx->p2;
-        ctx->p2 = nullptr;
-    }
+    pv_rnn_free_p2(ctx);
 }
 
 extern "C" int pv_rnn_load_p1(pv_ctx* ctx, const pv_weights_p1* w, int dtype) {

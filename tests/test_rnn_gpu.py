@@ -73,3 +73,52 @@ def test_forward_before_load_fails():
         c.forward_p1(np.zeros((1, 33, 26), np.int8))
     assert e.value.code == _ffi.PV_ERR_STATE
     c.close()
+
+
+# ---- P2: bi-GRU polisher model, 19-window sliding loop with hidden carry --------------------------------
+TOL_ACC = 1e-4  # accumulated softmax (sum of up to two windows' probabilities)
+
+
+def _check_labels(labels, acc_ref, labels_ref):
+    """labels must equal the reference's wherever its top-2 accumulated scores are further apart than the tolerance"""
+    diff = labels != labels_ref
+    if diff.any():
+        top2 = np.sort(acc_ref, axis=2)[..., -2:]
+        assert ((top2[..., 1] - top2[..., 0])[diff] < 2 * TOL_ACC).all()
+    assert diff.mean() < 2e-3
+
+
+@pytest.mark.parametrize("tag", ["p2", "p2sharp"])
+def test_p2_matches_reference_golden(hip_ctx, gold, tag):
+    w = synth.make_weights_p2(int(gold[tag + "/seed"][0]), float(gold[tag + "/gain"][0]))
+    hip_ctx.load_p2(w)
+    labels, acc = hip_ctx.forward_p2(gold[tag + "/images"], want_acc=True)
+    np.testing.assert_allclose(acc, gold[tag + "/acc"], atol=TOL_ACC, rtol=0)
+    _check_labels(labels, gold[tag + "/acc"], gold[tag + "/labels"])
+
+
+@pytest.mark.parametrize("B", [1, 33, 70])
+def test_p2_ragged_batches_vs_oracle(hip_ctx, B):
+    w = synth.make_weights_p2(31, 3.0)
+    hip_ctx.load_p2(w)
+    x = synth.synth_p2_images(500 + B, B)
+    labels, acc = hip_ctx.forward_p2(x, want_acc=True)
+    nb = min(B, 6)
+    sel = np.r_[0:nb // 2, B - (nb - nb // 2):B] if B > nb else np.arange(B)
+    lr, ar = rnn_oracle.p2_forward(w, x[sel], np.float64)
+    np.testing.assert_allclose(acc[sel], ar, atol=TOL_ACC, rtol=0)
+    _check_labels(labels[sel], ar, lr)
+    # every position is covered by one or two windows: accumulated probabilities sum to 1 or 2
+    s = acc.sum(2)
+    assert np.allclose(s[:, :50], 1, atol=1e-4) and np.allclose(s[:, 50:950], 2, atol=1e-4) and np.allclose(s[:, 950:], 1, atol=1e-4)
+
+
+def test_p2_extremes_and_labels_only(hip_ctx):
+    w = synth.make_weights_p2(31, 3.0)
+    hip_ctx.load_p2(w)
+    x = np.zeros((3, 1000, 10), np.uint8)
+    x[1] = 254
+    x[2, ::2] = 254
+    labels = hip_ctx.forward_p2(x)
+    lr, ar = rnn_oracle.p2_forward(w, x, np.float64)
+    _check_labels(labels, ar, lr)
