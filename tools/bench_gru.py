@@ -1,0 +1,33 @@
+#!/usr/bin/env python3
+"""Micro-benchmark of the P2 (bi-GRU polisher) kernel. Usage: bench_gru.py [B] [iters]"""
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from pepper_thesis_amd import _ffi, runtime, synth  # noqa: E402
+
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
+iters = int(sys.argv[2]) if len(sys.argv) > 2 else 3
+ctx = runtime.Context(0)
+ctx.load_p2(synth.make_weights_p2(4321))
+x = torch.from_numpy(synth.synth_p2_images(1, B)).cuda()
+labels = torch.zeros((B, 1000), dtype=torch.uint8, device="cuda")
+lib = _ffi.load()
+
+
+def fwd():
+    _ffi.check(lib.pv_rnn_forward_p2_dev(ctx.handle, x.data_ptr(), B, labels.data_ptr(), None, None))
+
+
+fwd()
+ctx.synchronize()
+ctx.profile_begin()
+for _ in range(iters):
+    fwd()
+prof = ctx.profile_end()
+ms = prof["k_gru_p2"][0] / prof["k_gru_p2"][1]
+flop = 80_435_200 * 19 * B
+print("B=%d chunks: %.2f ms -> %.0f chunks/s, %.0f 100-col windows/s, %.2f TFLOP/s (fp32 peak 157.3)" %
+      (B, ms, B / ms * 1e3, 19 * B / ms * 1e3, flop / ms / 1e9))
