@@ -132,18 +132,36 @@ def main():
     ctx = runtime.Context(local_rank)
     ctx.load_p1(weights)
     dbatch = DeviceBatch(batch, dev)
-    win = torch.from_numpy(pad).to(dev)                               # [4096,33,26] int8, builder writes the front
-    dout = DeviceOut(CALLERS * BATCH, CALLERS * BATCH * 16, dev, images=win)
+    # Two window buffers: the image builder of group g+1 (stream s_build) overlaps the RNN of group g
+    # (stream s_rnn); events order builder(g) -> rnn(g) and rnn(g) -> builder(g+2) (buffer reuse).
+    wins = [torch.from_numpy(pad).to(dev) for _ in range(2)]          # [4096,33,26] int8, builder writes the front
+    douts = [DeviceOut(CALLERS * BATCH, CALLERS * BATCH * 16, dev, images=w) for w in wins]
     probs = torch.zeros((groups, CALLERS * BATCH, 3), dtype=torch.float32, device=dev)
+    s_build, s_rnn = torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)
+    ev_built = [torch.cuda.Event() for _ in range(2)]
+    ev_used = [torch.cuda.Event() for _ in range(2)]
     torch.cuda.synchronize()
+    state = {"n": 0}
 
     def group(g):
-        ctx.summarize_dev(dbatch, P, dout)
-        ctx.forward_p1_dev(win.data_ptr(), CALLERS * BATCH, probs[g % groups].data_ptr())
+        k = state["n"] & 1
+        if state["n"] >= 2:
+            s_build.wait_event(ev_used[k])
+        ctx.summarize_dev(dbatch, P, douts[k], stream=s_build.cuda_stream)
+        ev_built[k].record(s_build)
+        s_rnn.wait_event(ev_built[k])
+        ctx.forward_p1_dev(wins[k].data_ptr(), CALLERS * BATCH, probs[g % groups].data_ptr(), stream=s_rnn.cuda_stream)
+        ev_used[k].record(s_rnn)
+        state["n"] += 1
+
+    def drain():
+        s_build.synchronize()
+        s_rnn.synchronize()
 
     for g in range(wgroups):
         group(g)
-    ctx.synchronize()
+    drain()
+    dout = douts[0]
     n_windows_region = dout.n_out()
     assert dout.status() == 0, "device status %d" % dout.status()
     assert n_windows_region <= CALLERS * BATCH, "regions yield %d windows > %d" % (n_windows_region, CALLERS * BATCH)
@@ -158,9 +176,9 @@ def main():
         group(g)
     gathered = None
     if dist is not None:
-        ctx.synchronize()
+        drain()
         gathered = gather_predictions(probs.view(-1, 3), dst=0)
-    ctx.synchronize()
+    drain()
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
