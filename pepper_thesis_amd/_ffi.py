@@ -11,7 +11,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libpepper_hip.so")
+LIB_PATH = os.environ.get("PEPPER_HIP_LIB") or os.path.join(_HERE, "csrc", "libpepper_hip.so")  # env override: A/B builds
 
 c_i64_p = C.POINTER(C.c_int64)
 c_i32_p = C.POINTER(C.c_int32)

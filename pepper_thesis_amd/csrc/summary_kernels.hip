@@ -27,6 +27,8 @@
 // bytewise exactly as std::string operator< would compare "<type digit><bytes>".
 #include "pv_common.hpp"
 
+#include <cmath>
+
 namespace {
 
 constexpr int NCNT = 21;
@@ -82,6 +84,7 @@ struct SumArgs {
     PairRec* pairs;      // [n_pairs]
     int64_t n_tiles;
     int64_t max_pairs;
+    int32_t qmin_snp;    // smallest integer quality q with (double)q >= min_snp_baseq (exact: q is an integer)
     int32_t* cnt;
     uint8_t* flags;
     int32_t* site_rank;
@@ -270,75 +273,134 @@ __device__ __forceinline__ OpCtx load_op(const SumArgs& a, int64_t c) {
 
 // One workgroup per TILE of TILE_COLS columns. All 21 counters of the tile live in LDS for the whole
 // kernel (ds_add instead of global atomics) and are written out once with coalesced stores, so the
-// counter planes need no memset and see no global atomics. The workgroup's 4 waves walk the tile's
-// (read, op range) pairs; inside a pair, 64 ops at a time: one lane per op for the indel bookkeeping,
-// then the aligned bases of all 64 ops are expanded over the lanes (prefix sum + binary search), so
-// that lanes stay busy whatever the CIGAR run lengths are and base/qual bytes are read coalesced.
-constexpr int PT_WAVES = 8;  // waves per tile workgroup
-__global__ __launch_bounds__(PT_WAVES * 64) void k_pileup_tiles(SumArgs a) {
-    __shared__ int32_t s_cnt[NCNT][TILE_COLS];
-    __shared__ int32_t s_pref[PT_WAVES][64];
-    __shared__ int32_t s_col0[PT_WAVES][64];   // global column of op offset 0
-    __shared__ int64_t s_base[PT_WAVES][64];   // global base index of op offset 0
-    __shared__ int32_t s_i0[PT_WAVES][64];
-    __shared__ int32_t s_meta[PT_WAVES][64];   // len-1
-    __shared__ uint8_t s_fl[PT_WAVES][64];     // bit1 anchor_next
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+// counter planes need no memset and see no global atomics.
+// The tile's work is FLATTENED across the whole workgroup so that no latency chain is per read:
+//   pair batch  : up to PT_PB (read, op-range) pair records -> LDS, block prefix sum of their op counts
+//   op batch    : one THREAD per op over all pairs of the batch (512 ops at a time): CIGAR word, start
+//                 column and read index are fetched with independent loads; indel bookkeeping per thread;
+//                 block-wide prefix sum of the in-tile aligned-base counts
+//   expansion   : the aligned bases of the 512 ops are dealt to the threads 4 consecutive bases at a
+//                 time (one LDS binary search per 4 bases, all 12 byte loads issued before first use),
+//                 so lanes stay busy whatever the CIGAR run lengths are and bytes are read coalesced.
+constexpr int PT_THREADS = 512;
+constexpr int PT_PB = 128;  // pairs per batch
+constexpr int PT_BPL = 4;   // bases per thread per trip (strided by the block size)
+
+__device__ __forceinline__ int block_incl_scan512(int v, int* s_wsum, int tid) {
+    const int lane = tid & 63, wv = tid >> 6;
+    const int inc = wave_incl_scan32(v, lane);
+    if (lane == 63) s_wsum[wv] = inc;
+    __syncthreads();
+    int off = 0;
+#pragma unroll
+    for (int k = 0; k < PT_THREADS / 64; k++) off += (k < wv) ? s_wsum[k] : 0;
+    __syncthreads();
+    return inc + off;
+}
+
+// LDS counters of the tile kernel (all non-negative; converted to the global plane-major layout at
+// flush time). The common case - a quality-passing A/C/G/T base over an A/C/G/T reference - costs ONE
+// ds_add: coverage and the REFF/REFR planes are derived as sums (every counted base lands in exactly
+// one symbol plane), anchors / odd symbols / non-ACGT reference columns use the side counters.
+enum {
+    L_P = 0,      // [2 strands][4]: base A,C,G,T counted over a valid reference
+    L_X = 8,      // [2]: counted bases that are NOT in L_P (odd symbol, or reference not ACGT)
+    L_O = 10,     // [2][3]: planes I, D, * (ops and odd symbols)
+    L_ANC = 16,   // [2]: counted bases that anchor an indel (no REFF/REFR decrement, :381-391)
+    L_COVI = 18,  // coverage bumps of the insert-anchor rule (:452-454)
+    L_SNP = 19, L_INS = 20, L_DEL = 21, L_RARE = 22, L_N = 23
+};
+
+__global__ __launch_bounds__(PT_THREADS) void k_pileup_tiles(SumArgs a) {
+    __shared__ int32_t s_cnt[L_N][TILE_COLS];
+    __shared__ uint8_t s_ref[TILE_COLS];     // the tile's reference bytes
+    __shared__ uint8_t s_lut[256];           // byte class: bits0-2 plane symbol 1..7, 8 = upper ACGT, 16 = lower acgt, 32 = valid reference
+    __shared__ uint16_t s_blk[PT_THREADS * TILE_COLS / 64 + 1];  // op that owns the first base of every 64-base block
+    // per-op staging (one op batch)
+    __shared__ int32_t s_pref[PT_THREADS];   // inclusive prefix of in-tile aligned bases
+    __shared__ int32_t s_col0[PT_THREADS];   // global column of op offset 0
+    __shared__ int64_t s_base[PT_THREADS];   // global base index of op offset 0
+    __shared__ int32_t s_i0[PT_THREADS];     // i = j + s_i0
+    __shared__ int32_t s_meta[PT_THREADS];   // len-1
+    __shared__ uint8_t s_opfl[PT_THREADS];   // bit0 rev, bit1 anchor_next
+    __shared__ uint8_t s_opair[PT_THREADS];  // pair slot of the op (for seq_end)
+    // per-pair staging (one pair batch)
+    __shared__ int32_t p_off[PT_PB + 1];     // exclusive prefix of op counts
+    __shared__ int32_t p_oplo[PT_PB], p_colbase[PT_PB], p_R[PT_PB], p_clast[PT_PB], p_reflen[PT_PB], p_rev[PT_PB];
+    __shared__ int64_t p_base0[PT_PB], p_seqend[PT_PB];
+    __shared__ int32_t s_wsum[PT_THREADS / 64];
+    const int tid = threadIdx.x;
     const int64_t tile = blockIdx.x;
     const int64_t tlo = tile * TILE_COLS, thi = tlo + TILE_COLS - 1;  // global columns of this tile
-    for (int i = threadIdx.x; i < NCNT * TILE_COLS; i += PT_WAVES * 64) (&s_cnt[0][0])[i] = 0;
-    __syncthreads();
+    for (int i = tid; i < L_N * TILE_COLS; i += PT_THREADS) (&s_cnt[0][0])[i] = 0;
+    for (int i = tid; i < TILE_COLS; i += PT_THREADS) s_ref[i] = (tlo + i < a.n_cols) ? a.in.ref[tlo + i] : (uint8_t)'N';
+    if (tid < 256) s_lut[tid] = (uint8_t)(sym_of(tid) | (is_acgt(tid) ? 8 : 0) | ((tid != up(tid) && is_acgt(up(tid))) ? 16 : 0) | (is_acgt(up(tid)) ? 32 : 0));
     const int32_t p0 = a.tile_off[tile];
     const int32_t np = a.tile_cnt[tile];
-    for (int32_t pi = wv; pi < np; pi += PT_WAVES) {
-        const PairRec pr = a.pairs[p0 + pi];
-        const int32_t op_lo = pr.op_lo, op_hi = pr.op_hi;
-        const int32_t col_base = pr.col_base;
-        const int64_t ref_len = pr.ref_len;
-        const int32_t R = pr.R;
-        const int64_t base0 = pr.base0, seq_end = pr.seq_end;
-        const bool rev = pr.rev != 0;
-        const int32_t c_last = pr.c_last;
-        const int sbase = C_PLANE + (rev ? 8 : 0);
-        // this tile's column range relative to the region, clipped to the region
-        int64_t clo = tlo - col_base, chi = thi - col_base;
-        if (clo < 0) clo = 0;
-        if (chi > R - 1) chi = R - 1;
-        for (int32_t cb = op_lo; cb < op_hi; cb += 64) {
-            const int32_t c = cb + lane;
-            int32_t ref_rel = 0, rd = 0, len = 0, op = 15;
-            bool active = false, anchor_next = false;
-            if (c < op_hi) {
-                ref_rel = a.op_ref[c];
-                active = ref_rel != OP_INACTIVE;
+    __syncthreads();
+    for (int32_t pb = 0; pb < np; pb += PT_PB) {
+        const int npb = (np - pb) < PT_PB ? (np - pb) : PT_PB;
+        // ---- pair batch -> LDS -----------------------------------------------------------------------
+        int nops = 0;
+        if (tid < npb) {
+            const PairRec pr = a.pairs[p0 + pb + tid];
+            nops = pr.op_hi - pr.op_lo;
+            p_oplo[tid] = pr.op_lo; p_colbase[tid] = pr.col_base; p_R[tid] = pr.R; p_clast[tid] = pr.c_last;
+            p_reflen[tid] = pr.ref_len; p_rev[tid] = pr.rev; p_base0[tid] = pr.base0; p_seqend[tid] = pr.seq_end;
+        }
+        const int incl_ops = block_incl_scan512(nops, s_wsum, tid);
+        if (tid < npb) p_off[tid + 1] = incl_ops;
+        if (tid == 0) p_off[0] = 0;
+        __syncthreads();
+        const int total_ops = p_off[npb];
+        for (int ob = 0; ob < total_ops; ob += PT_THREADS) {
+            // ---- op batch: one thread per op -----------------------------------------------------------
+            const int k = ob + tid;
+            int32_t ref_rel = 0, rd = 0, len = 0, op = 15, col_base = 0;
+            bool active = false, anchor_next = false, rev = false;
+            int pslot = 0;
+            int32_t c = 0;
+            int64_t clo = 0, chi = -1;
+            if (k < total_ops) {
+                int lo = 0, hi = npb;  // last pair slot with p_off[slot] <= k
+                while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (p_off[mid] <= k) lo = mid; else hi = mid; }
+                pslot = lo;
+                c = p_oplo[pslot] + (k - p_off[pslot]);
+                const int32_t c_last = p_clast[pslot];
+                const int32_t rr = a.op_ref[c];
+                const uint32_t w = a.in.cigar[c];
+                const int32_t rdv = a.op_rd[c];
+                const uint32_t wn = a.in.cigar[c < c_last ? c + 1 : c];
+                col_base = p_colbase[pslot];
+                rev = p_rev[pslot] != 0;
+                active = rr != OP_INACTIVE;
                 if (active) {
-                    const uint32_t w = a.in.cigar[c];
-                    op = w & 0xF;
-                    len = (int32_t)(w >> 4);
-                    rd = a.op_rd[c];
-                    if (c < c_last) {
-                        const int nop = a.in.cigar[c + 1] & 0xF;
-                        anchor_next = (nop == PV_CIGAR_IN || nop == PV_CIGAR_DEL);  // :381-391
-                    }
+                    ref_rel = rr; rd = rdv; op = w & 0xF; len = (int32_t)(w >> 4);
+                    const int nop = wn & 0xF;
+                    anchor_next = (c < c_last) && (nop == PV_CIGAR_IN || nop == PV_CIGAR_DEL);  // :381-391
                 }
+                clo = tlo - col_base; chi = thi - col_base;  // tile columns relative to the region, clipped to it
+                if (clo < 0) clo = 0;
+                if (chi > p_R[pslot] - 1) chi = p_R[pslot] - 1;
             }
-            // (1) indel ops: one lane each; an op belongs to the tile that owns its anchor column
+            const int so = L_O + (rev ? 3 : 0);
+            // (1) indel ops; an op belongs to the tile that owns its anchor column
             if (active && op == PV_CIGAR_IN) {  // :431-490
                 const int64_t anchor = (int64_t)ref_rel - 1;
                 if (anchor >= clo && anchor <= chi && rd >= 1) {
                     const int lc = (int)(col_base + anchor - tlo);
-                    const int64_t start = base0 + rd - 1;
+                    const int64_t start = p_base0[pslot] + rd - 1;
                     const int64_t L = (int64_t)len + 1;
-                    if (start + L > seq_end) {
+                    if (start + L > p_seqend[pslot]) {
                         set_status(a.diag, PV_ERR_INVALID);
                     } else {
                         int64_t qs = 0;
                         for (int64_t i = 0; i < L; i++) qs += a.in.quals[start + i];
                         const bool qok = (double)qs >= a.p.min_indel_baseq * (double)L;
-                        if (qok && (double)a.in.quals[start] < a.p.min_snp_baseq) atomicAdd(&s_cnt[C_COV][lc], 1);  // :453
+                        if (qok && (double)a.in.quals[start] < a.p.min_snp_baseq) atomicAdd(&s_cnt[L_COVI][lc], 1);  // :453
                         if (1 + L <= PV_MAX_ALLELE_KEY && qok) {
-                            if (is_acgt(up(a.in.ref[col_base + anchor]))) atomicAdd(&s_cnt[sbase + 5][lc], -1);
-                            atomicAdd(&s_cnt[C_INS][lc], 1);
+                            if (is_acgt(up(s_ref[lc]))) atomicAdd(&s_cnt[so + 0][lc], 1);
+                            atomicAdd(&s_cnt[L_INS][lc], 1);
                             a.op_flag[c] = 1;
                         }
                     }
@@ -347,22 +409,22 @@ __global__ __launch_bounds__(PT_WAVES * 64) void k_pileup_tiles(SumArgs a) {
                 const int64_t anchor = (int64_t)ref_rel - 1;
                 if (anchor >= clo && anchor <= chi) {
                     const int lc = (int)(col_base + anchor - tlo);
-                    if (is_acgt(up(a.in.ref[col_base + anchor]))) atomicAdd(&s_cnt[sbase + 6][lc], -1);  // unconditional, :496
+                    if (is_acgt(up(s_ref[lc]))) atomicAdd(&s_cnt[so + 1][lc], 1);  // unconditional, :496
                     int64_t L = (int64_t)len + 1;
-                    if (anchor + L > ref_len) L = ref_len - anchor;  // substr truncation, :500
+                    if (anchor + L > p_reflen[pslot]) L = p_reflen[pslot] - anchor;  // substr truncation, :500
                     if (1 + L <= PV_MAX_ALLELE_KEY) {
-                        atomicAdd(&s_cnt[C_DEL][lc], 1);
+                        atomicAdd(&s_cnt[L_DEL][lc], 1);
                         a.op_flag[c] = 1;
                     }
                 }
                 int64_t i0 = clo - ref_rel; if (i0 < 0) i0 = 0;
                 int64_t i1 = chi + 1 - ref_rel; if (i1 > len) i1 = len;
                 for (int64_t i = i0; i < i1; i++) {  // :542-552
-                    const int64_t col = (int64_t)col_base + ref_rel + i;
-                    if (is_acgt(up(a.in.ref[col]))) atomicAdd(&s_cnt[sbase + 7][(int)(col - tlo)], -1);
+                    const int lc2 = (int)((int64_t)col_base + ref_rel + i - tlo);
+                    if (is_acgt(up(s_ref[lc2]))) atomicAdd(&s_cnt[so + 2][lc2], 1);
                 }
             }
-            // (2) aligned bases of the chunk's M/=/X ops, clipped to tile and region
+            // (2) aligned bases of the batch's M/=/X ops, clipped to tile and region
             const bool is_m = active && (op == PV_CIGAR_MATCH || op == PV_CIGAR_EQUAL || op == PV_CIGAR_DIFF);
             int32_t i0 = 0, eff = 0;
             if (is_m) {
@@ -370,73 +432,107 @@ __global__ __launch_bounds__(PT_WAVES * 64) void k_pileup_tiles(SumArgs a) {
                 int64_t hi = chi + 1 - ref_rel; if (hi > len) hi = len;
                 if (hi > lo) { i0 = (int32_t)lo; eff = (int32_t)(hi - lo); }
             }
-            const int32_t incl = wave_incl_scan32(eff, lane);
-            s_pref[wv][lane] = incl;
-            s_col0[wv][lane] = col_base + ref_rel;
-            s_base[wv][lane] = base0 + rd;
-            s_i0[wv][lane] = i0 - (incl - eff);  // so that i = j + s_i0
-            s_meta[wv][lane] = len - 1;
-            s_fl[wv][lane] = (uint8_t)(anchor_next ? 2 : 0);
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-            const int32_t total = s_pref[wv][63];
-            constexpr int UB = 4;  // bases per lane per trip: all byte loads of a trip are issued before any is used
-            for (int32_t jb = 0; jb < total; jb += 64 * UB) {
-                int32_t ii[UB];
-                int64_t colv[UB];
-                int basev[UB], qv[UB], refv[UB], anc[UB];
-                bool ok[UB];
+            const int32_t incl = block_incl_scan512(eff, s_wsum, tid);
+            s_pref[tid] = incl;
+            s_col0[tid] = col_base + ref_rel;
+            s_base[tid] = (k < total_ops ? p_base0[pslot] : 0) + rd;
+            s_i0[tid] = i0 - (incl - eff);
+            s_meta[tid] = len - 1;
+            s_opfl[tid] = (uint8_t)((rev ? 1 : 0) | (anchor_next ? 2 : 0));
+            s_opair[tid] = (uint8_t)pslot;
+            for (int32_t bb = (incl - eff + 63) >> 6; (bb << 6) < incl; bb++) s_blk[bb] = (uint16_t)tid;  // blocks starting inside this op
+            __syncthreads();
+#ifdef ABL_NOEXP
+            const int32_t total = 0;
+#else
+            const int32_t total = s_pref[PT_THREADS - 1];
+#endif
+            // ---- expansion: PT_BPL consecutive bases per thread per trip -----------------------------------
+            for (int32_t jb = 0; jb < total; jb += PT_THREADS * PT_BPL) {
+                int64_t colv[PT_BPL];
+                int basev[PT_BPL], qv[PT_BPL], refv[PT_BPL], fl[PT_BPL];
+                bool ok[PT_BPL];
 #pragma unroll
-                for (int u = 0; u < UB; u++) {
-                    const int32_t j = jb + u * 64 + lane;
+                for (int u = 0; u < PT_BPL; u++) {
+                    // consecutive lanes take consecutive bases: conflict-free ds_add, coalesced byte loads
+                    const int32_t j = jb + u * PT_THREADS + tid;
                     ok[u] = j < total;
-                    int lo = 0, hi = 63;  // first lane whose inclusive prefix exceeds j
-#pragma unroll
-                    for (int it = 0; it < 6; it++) {
-                        const int mid = (lo + hi) >> 1;
-                        if (s_pref[wv][mid] > j) hi = mid; else lo = mid + 1;
-                    }
-                    const int ow = lo;
-                    const int32_t i = j + s_i0[wv][ow];
-                    ii[u] = i;
-                    colv[u] = (int64_t)s_col0[wv][ow] + i;
-                    const int64_t bi = s_base[wv][ow] + i;
-                    anc[u] = ((s_fl[wv][ow] & 2) && i == s_meta[wv][ow]) ? 1 : 0;
-                    if (ok[u] && bi >= seq_end) { set_status(a.diag, PV_ERR_INVALID); ok[u] = false; }
+                    int owc = ok[u] ? s_blk[j >> 6] : 0;  // owner of the block's first base, then a short probe
+                    while (ok[u] && s_pref[owc] <= j) owc++;
+                    const int32_t i = j + s_i0[owc];
+                    colv[u] = (int64_t)s_col0[owc] + i;
+                    const int64_t bi = s_base[owc] + i;
+                    const int f = s_opfl[owc];
+                    fl[u] = (f & 1) | (((f & 2) && i == s_meta[owc]) ? 2 : 0);  // bit0 rev, bit1 "is the anchor base"
+                    if (ok[u] && bi >= p_seqend[s_opair[owc]]) { set_status(a.diag, PV_ERR_INVALID); ok[u] = false; }
+#ifdef ABL_NOLOAD
+                    basev[u] = 65 + (int)(bi & 3); qv[u] = 20; refv[u] = 65 + (int)(colv[u] & 3);
+#else
                     basev[u] = ok[u] ? a.in.bases[bi] : 0;
                     qv[u] = ok[u] ? a.in.quals[bi] : 0;
-                    refv[u] = ok[u] ? a.in.ref[colv[u]] : 0;
+                    refv[u] = ok[u] ? s_ref[(int)(colv[u] - tlo)] : 0;
+#endif
                 }
 #pragma unroll
-                for (int u = 0; u < UB; u++) {
+                for (int u = 0; u < PT_BPL; u++) {
                     const int base = basev[u], refb = refv[u];
-                    const bool qok = ok[u] && ((double)qv[u] >= a.p.min_snp_baseq);
+                    const bool qok = ok[u] && (qv[u] >= a.qmin_snp);
                     if (!qok) continue;
                     const int lc = (int)(colv[u] - tlo);
-                    atomicAdd(&s_cnt[C_COV][lc], 1);                                  // :379
-                    if (!anc[u]) atomicAdd(&s_cnt[sbase][lc], -1);                    // :381-391 REFF/REFR
-                    const bool refvalid = is_acgt(up(refb));
-                    if (refvalid) atomicAdd(&s_cnt[sbase + sym_of(base)][lc], -1);   // :396,423
-                    const bool mism = refb != base;                                   // raw bytes, :394
-                    if (mism) atomicAdd(&s_cnt[C_SNP][lc], 1);
-                    const bool rare = mism && !(refvalid && is_acgt(base));
-                    const bool corr = refvalid && base != up(base) && is_acgt(up(base));
-                    if (rare || corr) atomicAdd(&s_cnt[C_RARE][lc], 1);
+#ifdef ABL_NOATOM
+                    if (base == 1234567) atomicAdd(&s_cnt[C_COV][lc], refb);
+                    continue;
+#endif
+                    const int st = fl[u] & 1;
+                    const int cb = s_lut[base];
+                    const bool refvalid = (s_lut[refb] & 32) != 0;
+                    const int sy = cb & 7;                                           // 1..7
+                    if (refvalid && sy <= 4) {
+                        atomicAdd(&s_cnt[L_P + 4 * st + (sy - 1)][lc], 1);           // :379 + :381-391 + :396,423 in one
+                    } else {
+                        atomicAdd(&s_cnt[L_X + st][lc], 1);
+                        if (refvalid) atomicAdd(&s_cnt[L_O + 3 * st + (sy - 5)][lc], 1);
+                    }
+                    if (fl[u] & 2) atomicAdd(&s_cnt[L_ANC + st][lc], 1);
+                    const bool mism = refb != base;                                  // raw bytes, :394
+                    if (mism) atomicAdd(&s_cnt[L_SNP][lc], 1);
+                    const bool rare = mism && !(refvalid && (cb & 8));
+                    const bool corr = refvalid && (cb & 16);
+                    if (rare || corr) atomicAdd(&s_cnt[L_RARE][lc], 1);
                 }
             }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-            __builtin_amdgcn_wave_barrier();  // the wave's staging arrays are rewritten by the next chunk
+            __syncthreads();  // staging arrays are rewritten by the next op batch
         }
+        __syncthreads();  // pair arrays are rewritten by the next pair batch
     }
     __syncthreads();
-    // flush: plane-major global counters, coalesced
+    // flush: derive the global plane-major counters (negative counts, as the reference keeps them)
     const int64_t NC = a.n_cols;
     int64_t ncol = NC - tlo;
     if (ncol > TILE_COLS) ncol = TILE_COLS;
-    for (int i = threadIdx.x; i < NCNT * TILE_COLS; i += PT_WAVES * 64) {
-        const int k = i / TILE_COLS, lc = i - k * TILE_COLS;
-        if (lc < ncol) a.cnt[(int64_t)k * NC + tlo + lc] = s_cnt[k][lc];
+    for (int lc = tid; lc < ncol; lc += PT_THREADS) {
+        const int64_t g = tlo + lc;
+        int cov = s_cnt[L_COVI][lc];
+#pragma unroll
+        for (int st = 0; st < 2; st++) {
+            int sp = 0;
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const int v = s_cnt[L_P + 4 * st + k][lc];
+                sp += v;
+                a.cnt[(int64_t)(C_PLANE + 8 * st + 1 + k) * NC + g] = -v;
+            }
+            const int counted = sp + s_cnt[L_X + st][lc];
+            cov += counted;
+            a.cnt[(int64_t)(C_PLANE + 8 * st) * NC + g] = -(counted - s_cnt[L_ANC + st][lc]);
+#pragma unroll
+            for (int k = 0; k < 3; k++) a.cnt[(int64_t)(C_PLANE + 8 * st + 5 + k) * NC + g] = -s_cnt[L_O + 3 * st + k][lc];
+        }
+        a.cnt[(int64_t)C_COV * NC + g] = cov;
+        a.cnt[(int64_t)C_SNP * NC + g] = s_cnt[L_SNP][lc];
+        a.cnt[(int64_t)C_INS * NC + g] = s_cnt[L_INS][lc];
+        a.cnt[(int64_t)C_DEL * NC + g] = s_cnt[L_DEL][lc];
+        a.cnt[(int64_t)C_RARE * NC + g] = s_cnt[L_RARE][lc];
     }
 }
 
@@ -908,6 +1004,10 @@ static int summarize_launch(pv_ctx* ctx, const pv_batch_in* in, const pv_params*
     if ((rc = pv_get(ctx, "sum.op_flag", nc1, &a.op_flag))) return rc;
     if ((rc = pv_get(ctx, "sum.read_region", nr1, &a.read_region))) return rc;
     a.n_tiles = (n_cols + TILE_COLS - 1) / TILE_COLS;
+    {
+        const double t = params->min_snp_baseq;
+        a.qmin_snp = t <= 0.0 ? 0 : (t > 255.0 ? 256 : (int32_t)ceil(t));
+    }
     // every read overlaps at most span/TILE_COLS + 2 tiles; the exact pair count is only known on the
     // device, so bound it: sum over reads of (read span)/TILE + 2 <= (bases + deleted cols)/TILE + 2 reads
     a.max_pairs = max_pairs;
@@ -943,7 +1043,7 @@ static int summarize_launch(pv_ctx* ctx, const pv_batch_in* in, const pv_params*
     k_scan_i32<<<1, 1024, 0, st>>>(a.tile_cnt, a.tile_off, a.n_tiles, nullptr, a.n_tiles, &a.diag[D_NPAIRS]);
     k_check_pairs<<<1, 1, 0, st>>>(a);
     if (n_reads > 0) { pv_prof_scope ps(ctx, "k_tile_fill", st); k_tile_fill<<<grid_for(n_reads, 4), 256, 0, st>>>(a); }
-    { pv_prof_scope ps(ctx, "k_pileup", st); k_pileup_tiles<<<(unsigned)a.n_tiles, PT_WAVES * 64, 0, st>>>(a); }
+    { pv_prof_scope ps(ctx, "k_pileup", st); k_pileup_tiles<<<(unsigned)a.n_tiles, PT_THREADS, 0, st>>>(a); }
     k_site_scan<<<(unsigned)n_blk, 1024, 0, st>>>(a);
     k_scan_i32<<<1, 1024, 0, st>>>(a.blk_cnt, a.blk_off, n_blk, nullptr, n_blk, &a.diag[D_NSITES]);
     k_site_rank<<<(unsigned)n_blk, 1024, 0, st>>>(a);
