@@ -1,0 +1,95 @@
+"""`run_inference` on the MI355X path: image HDF5 files in, prediction HDF5 files out.
+
+Mirrors pepper_variant/modules/python/RunInference.py:125-138 -> distributed_gpu (:24-91) ->
+predict_distributed_gpu.predict (models/predict_distributed_gpu.py:19-74): every `*.hdf5` in the image
+directory is read (dataloader_predict.py:46-78), windows go through the P1 network in batches and the
+results are written as `predictions/batch_<k>` groups (DataStorePredict.py:49-66) that the unmodified
+`find_candidates` consumes. Flags keep the reference's names (RunInferenceArguments.py:7-124).
+
+  python -m pepper_thesis_amd.run_inference -i IMAGE_DIR -m MODEL -o OUTPUT_DIR [-bs 512] [-per_gpu 8] [-d_ids 0]
+
+MODEL is the reference's checkpoint (torch.save dict with 'model_state_dict', ModelHander.py:18-44; loaded
+with weights_only=True) or an .npz of the same state dict. With several ranks (torchrun) files are dealt
+round-robin (RunInference.py:101-106) and every rank writes pepper_prediction_<rank>.hdf.
+"""
+import argparse
+import glob
+import os
+import sys
+import time
+from datetime import datetime
+
+import numpy as np
+
+
+def log(msg):
+    sys.stderr.write("[" + datetime.now().strftime("%m-%d-%Y %H:%M:%S") + "] INFO: " + msg + "\n")
+    sys.stderr.flush()
+
+
+def load_state_dict(model_path: str) -> dict:
+    if model_path.endswith(".npz"):
+        with np.load(model_path, allow_pickle=False) as z:
+            return {k: z[k] for k in z.files}
+    import torch
+    ckpt = torch.load(model_path, map_location="cpu", weights_only=True)
+    sd = ckpt["model_state_dict"] if isinstance(ckpt, dict) and "model_state_dict" in ckpt else ckpt
+    return {k: v.detach().cpu().numpy() for k, v in sd.items()}
+
+
+def predict_files(ctx, state_dict, input_files, output_file, batch_size=512, callers=8):
+    """predict() of predict_distributed_gpu.py:19-74 for a list of image files -> one prediction file"""
+    from .hdf5io import ImageStore, PredictionStore
+    from .predict import Predictor
+    predictor = Predictor(ctx, state_dict, "p1")
+    n_windows, batch_no = 0, 0
+    with PredictionStore(output_file, "w") as out:
+        for path in input_files:
+            with ImageStore(path, "r") as store:
+                parts = [store.read_summary(name) for name in store.summaries()]
+            if not parts:
+                continue
+            cat = {k: np.concatenate([p[k] for p in parts]) for k in parts[0]}
+            probs = predictor.predict(cat["images"], batch_size, callers)
+            for i in range(0, len(probs), batch_size):
+                sl = slice(i, i + batch_size)
+                out.write_prediction(batch_no, cat["contigs"][sl], cat["positions"][sl], cat["depths"][sl],
+                                     cat["candidates"][sl], cat["candidate_frequency"][sl], probs[sl].astype(np.float64))
+                batch_no += 1
+            n_windows += len(probs)
+    return n_windows
+
+
+def main(argv=None):
+    ap = argparse.ArgumentParser(prog="run_inference")
+    ap.add_argument("-i", "--image_dir", required=True)
+    ap.add_argument("-m", "--model_path", required=True)
+    ap.add_argument("-o", "--output_dir", required=True)
+    ap.add_argument("-bs", "--batch_size", type=int, default=512)
+    ap.add_argument("-per_gpu", "--callers_per_gpu", type=int, default=8)
+    ap.add_argument("-d_ids", "--device_ids", type=str, default=None)
+    ap.add_argument("-g", "--gpu", action="store_true", default=True)
+    ap.add_argument("-t", "--threads", type=int, default=8)
+    ap.add_argument("-w", "--num_workers", type=int, default=0)
+    args = ap.parse_args(argv)
+    from .dist import shard_regions
+    from .runtime import Context
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    devs = [int(d) for d in args.device_ids.split(",")] if args.device_ids else None
+    device = devs[rank % len(devs)] if devs else int(os.environ.get("LOCAL_RANK", "0"))
+    files = sorted(glob.glob(os.path.join(args.image_dir, "*.hdf5")))
+    mine = [files[i] for i in shard_regions(len(files), rank, world)]
+    os.makedirs(args.output_dir, exist_ok=True)
+    name = "pepper_prediction.hdf" if world == 1 else "pepper_prediction_%d.hdf" % rank
+    t0 = time.time()
+    log("INFERENCE STARTING ON DEVICE %d: %d FILES" % (device, len(mine)))
+    ctx = Context(device)
+    n = predict_files(ctx, load_state_dict(args.model_path), mine, os.path.join(args.output_dir, name),
+                      args.batch_size, args.callers_per_gpu)
+    ctx.close()
+    log("FINISHED PREDICTION: %d WINDOWS IN %.2f SEC" % (n, time.time() - t0))
+
+
+if __name__ == "__main__":
+    main()

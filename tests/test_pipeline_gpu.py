@@ -1,0 +1,45 @@
+"""GPU: make_images -> image HDF5 -> run_inference -> prediction HDF5, end to end against the oracles
+(the file formats are the reference's; the consumer find_candidates would read these files as is)."""
+import os
+
+import numpy as np
+import pytest
+
+from pepper_thesis_amd import hdf5io, make_images, run_inference, synth
+from pepper_thesis_amd.batch import PRESETS, pack_regions
+
+pytestmark = pytest.mark.gpu
+
+
+def test_make_images_then_run_inference(hip_ctx, oracle_lib, tmp_path):
+    from oracle import rnn_oracle
+    P = PRESETS["ont_r9_guppy5_sup"]
+    intervals = [("chr20", 1_000_000 + 2800 * k, 1_000_000 + 2800 * (k + 1)) for k in range(3)]
+    regs = []
+    for k, (contig, start, end) in enumerate(intervals):
+        rs, re_, cs, ce = make_images.interval_arithmetic(start, end)
+        r = synth.synth_region(40 + k, region_len=re_ - rs + 1, depth=30, read_len=900, site_every=45, ref_start=rs, safe=0)
+        r.cand_start, r.cand_end, r.contig = cs, ce, contig
+        regs.append(r)
+    batch = pack_regions(regs)
+    img_dir, out_dir = tmp_path / "images", tmp_path / "predictions"
+    os.makedirs(img_dir)
+    n = make_images.write_image_file(hip_ctx, str(img_dir / "pepper_variants_images_thread_0.hdf5"), batch, intervals, P)
+    exp = oracle_lib.summarize(batch, P)
+    assert n == len(exp) > 50
+    w = synth.make_weights_p1(3, 2.0)
+    np.savez(str(tmp_path / "model.npz"), **w)
+    run_inference.main(["-i", str(img_dir), "-m", str(tmp_path / "model.npz"), "-o", str(out_dir), "-bs", "64", "-per_gpu", "2"])
+    with hdf5io.PredictionStore(str(out_dir / "pepper_prediction.hdf"), "r") as st:
+        batches = dict(st.batches())
+    keys = sorted(batches, key=lambda s: int(s.split("_")[1]))
+    pos = np.concatenate([batches[k]["positions"] for k in keys])
+    cand = np.concatenate([batches[k]["candidates"] for k in keys])[:, 0].tolist()
+    probs = np.concatenate([batches[k]["base_prediction"] for k in keys])
+    assert all(batches[k]["base_prediction"].shape[0] <= 64 for k in keys)
+    # image files group by interval name; h5 lists groups alphabetically = numeric order here
+    np.testing.assert_array_equal(pos, exp.position.astype(np.int32))
+    assert cand == exp.candidates
+    ref = rnn_oracle.p1_forward(w, exp.images, np.float64)
+    np.testing.assert_allclose(probs, ref, atol=1e-4, rtol=0)
+    assert probs.dtype == np.float64
