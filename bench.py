@@ -105,12 +105,38 @@ def pmc_traffic():
     return out
 
 
+def p2_secondary(ctx, dev):
+    """secondary figures for the bi-GRU polisher plan (north_star's '1000 x 100 x feature' shape): the 19-window
+    sliding loop over [B,1000,10] chunks at the SURVEY 8(d) batch (64 chunks), at 1000 chunks and at a
+    chip-filling batch. Not part of `value`."""
+    import torch
+    from pepper_thesis_amd import _ffi, synth
+    ctx.load_p2(synth.make_weights_p2(4321))
+    lib = _ffi.load()
+    out = {"flop_per_100col_window": 80_435_200, "windows_per_chunk": 19}
+    for B in (64, 1000, 8192):
+        x = torch.from_numpy(synth.synth_p2_images(7, B)).to(dev)
+        labels = torch.zeros((B, 1000), dtype=torch.uint8, device=dev)
+        _ffi.check(lib.pv_rnn_forward_p2_dev(ctx.handle, x.data_ptr(), B, labels.data_ptr(), None, None))
+        ctx.synchronize()
+        ctx.profile_begin()
+        for _ in range(2):
+            _ffi.check(lib.pv_rnn_forward_p2_dev(ctx.handle, x.data_ptr(), B, labels.data_ptr(), None, None))
+        ms, n = ctx.profile_end()["k_gru_p2"]
+        ms /= n
+        out["B%d" % B] = {"ms": ms, "chunks_per_s": B / ms * 1e3, "windows_100col_per_s": 19 * B / ms * 1e3,
+                          "tflops": 80_435_200 * 19 * B / ms / 1e9, "frac_of_f32_peak": 80_435_200 * 19 * B / ms / 1e9 / PEAK_F32_TFLOPS}
+        del x, labels
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=64)
     ap.add_argument("--warmup", type=int, default=8)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-p2", action="store_true", help="skip the secondary bi-GRU (P2) figures")
     args = ap.parse_args()
 
     import torch
@@ -253,6 +279,11 @@ def main():
             "kernel_ms": {k: v[0] / max(v[1], 1) for k, v in prof.items()},
             "rnn_model_tflops": FLOP_PER_WINDOW * value / 1e12,
         }
+        if world == 1 and not args.no_p2:
+            try:
+                out["p2_bigru"] = p2_secondary(ctx, dev)
+            except Exception as e:
+                out["p2_bigru"] = {"error": repr(e)}
         if world == 1 and not args.no_cpu_baseline:
             try:
                 out["cpu_baseline"] = cpu_baseline(weights, regions[0], min(len(os.sched_getaffinity(0)), 16))

@@ -40,12 +40,12 @@ for d in ("pmc_mfma", "pmc_fetch", "pmc_write"):
 with open(os.path.join(dst, "%s_pmc_per_launch.csv" % tag), "w") as f:
     w = csv.writer(f)
     w.writerow(["kernel", "SQ_VALU_MFMA_BUSY_CYCLES", "SQ_WAVE_CYCLES(quad)", "SQ_BUSY_CU_CYCLES", "GRBM_GUI_ACTIVE(sum 8 XCD)",
-                "mfma_util=MFMA_BUSY/(4*WAVE_CYCLES)", "FETCH_SIZE_KiB", "hbm_read_bytes_raw", "hbm_read_bytes_x2(gfx950 wide loads)",
+                "mfma_util=MFMA_BUSY/(4*SQ_BUSY_CU_CYCLES)", "FETCH_SIZE_KiB", "hbm_read_bytes_raw", "hbm_read_bytes_x2(gfx950 wide loads)",
                 "WRITE_SIZE_KiB", "hbm_write_bytes"])
     for k, r in rows.items():
         mf, wc = r.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0), r.get("SQ_WAVE_CYCLES", 0.0)
         fs_, ws = r.get("FETCH_SIZE", 0.0), r.get("WRITE_SIZE", 0.0)
         w.writerow([k.replace("(anonymous namespace)::", "")[:70], "%.0f" % mf, "%.0f" % wc, "%.0f" % r.get("SQ_BUSY_CU_CYCLES", 0),
-                    "%.0f" % r.get("GRBM_GUI_ACTIVE", 0), "%.3f" % (mf / (4 * wc) if wc else 0), "%.1f" % fs_, "%.0f" % (fs_ * 1024),
+                    "%.0f" % r.get("GRBM_GUI_ACTIVE", 0), "%.3f" % (mf / (4 * r.get("SQ_BUSY_CU_CYCLES", 0)) if r.get("SQ_BUSY_CU_CYCLES", 0) else 0), "%.1f" % fs_, "%.0f" % (fs_ * 1024),
                     "%.0f" % (fs_ * 2048), "%.1f" % ws, "%.0f" % (ws * 1024)])
 print("wrote profiles/%s_*" % tag)
