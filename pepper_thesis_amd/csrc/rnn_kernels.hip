@@ -34,8 +34,7 @@ constexpr int H = 256;            // LSTM hidden
 constexpr int ROWS = 32;          // batch rows per workgroup (one MFMA M-tile)
 constexpr int HEAD_N = 512;
 constexpr int HEAD_K = T_STEPS * 2 * H;  // 16896
-constexpr int HEAD_SPLITS = 11;          // 3 time steps (1536 k) per split
-constexpr int HEAD_STEPS_PER_SPLIT = 3;
+constexpr int HEAD_MAX_SPLITS = 33;      // split-K factor of linear_1 is chosen per launch from {1, 3, 11, 33}
 
 // v_exp_f32 / v_rcp_f32 (1 ulp) instead of the IEEE division sequence: ~3x fewer VALU instructions in the
 // cell update; absolute error of sigmoid/tanh stays ~1e-7 (tests pin 2e-5 on layer outputs).
@@ -287,9 +286,11 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void k_lstm_layer(LstmArgs a) {
 struct HeadArgs {
     const float* dec;     // [B,33,512]
     const float* w1p;     // packed linear_1 [4 waves][2112 kb][4][64][4]
-    float* part;          // [HEAD_SPLITS][B][512]
+    float* part;          // [splits][B][512]
     int64_t B;
     int n_tiles;
+    int splits;           // divides 33
+    int steps_per_split;
 };
 
 __global__ __launch_bounds__(256, 1) void k_head_splitk(HeadArgs a) {
@@ -298,15 +299,15 @@ __global__ __launch_bounds__(256, 1) void k_head_splitk(HeadArgs a) {
     extern __shared__ float smem[];
     float* abuf = smem;  // [32][LDA]
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int tile = blockIdx.x / HEAD_SPLITS, split = blockIdx.x - tile * HEAD_SPLITS;
+    const int tile = blockIdx.x / a.splits, split = blockIdx.x - tile * a.splits;
     const int64_t b0 = (int64_t)tile * ROWS;
     f32x16 acc[4];
 #pragma unroll
     for (int nt = 0; nt < 4; nt++)
 #pragma unroll
         for (int r = 0; r < 16; r++) acc[nt][r] = 0.0f;
-    for (int st = 0; st < HEAD_STEPS_PER_SPLIT; st++) {
-        const int t = split * HEAD_STEPS_PER_SPLIT + st;
+    for (int st = 0; st < a.steps_per_split; st++) {
+        const int t = split * a.steps_per_split + st;
         constexpr int V4 = KC / 4;
         __syncthreads();
 #pragma unroll 4
@@ -334,7 +335,8 @@ __global__ __launch_bounds__(256, 1) void k_head_splitk(HeadArgs a) {
 }
 
 struct TailArgs {
-    const float* part;   // [HEAD_SPLITS][B][512]
+    const float* part;   // [splits][B][512]
+    int splits;
     const float* b1;     // [512]
     const float* wp[4];  // packed linear_2..5 [4 waves][64 kb][4][64][4]
     const float* b[4];   // [512]
@@ -358,8 +360,8 @@ __global__ __launch_bounds__(256, 1) void k_head_tail(TailArgs a) {
         int64_t b = b0 + row;
         if (b >= a.B) b = a.B - 1;
         float v = a.b1[n];
-#pragma unroll
-        for (int s = 0; s < HEAD_SPLITS; s++) v += a.part[((size_t)s * a.B + b) * HEAD_N + n];
+#pragma unroll 11
+        for (int s = 0; s < a.splits; s++) v += a.part[((size_t)s * a.B + b) * HEAD_N + n];
         y0[row * LDY + n] = seluf_(v);
     }
     __syncthreads();
@@ -560,10 +562,13 @@ static int p1_forward_launch(pv_ctx* ctx, const int8_t* d_images, int64_t B, flo
         else k_lstm_layer<512, false, 4><<<lstm_grid, 256, LDS_DEC, st>>>(d);
     }
     HeadArgs h;
-    h.dec = dec_out; h.w1p = m->w1p; h.part = part; h.B = B; h.n_tiles = n_tiles;
-    { pv_prof_scope ps(ctx, "k_head_splitk", st); k_head_splitk<<<(unsigned)(n_tiles * HEAD_SPLITS), 256, LDS_SPLITK, st>>>(h); }
+    // split-K factor: 11 slabs of 3 time steps; 33 single-step slabs only for batches too small to fill the chip
+    int splits = ((int64_t)n_tiles * 11 >= ctx->num_cu) ? 11 : 33;
+    if (const char* e = getenv("PV_HEAD_SPLITS")) { const int v = atoi(e); if (v == 1 || v == 3 || v == 11 || v == 33) splits = v; }
+    h.dec = dec_out; h.w1p = m->w1p; h.part = part; h.B = B; h.n_tiles = n_tiles; h.splits = splits; h.steps_per_split = T_STEPS / splits;
+    { pv_prof_scope ps(ctx, "k_head_splitk", st); k_head_splitk<<<(unsigned)(n_tiles * splits), 256, LDS_SPLITK, st>>>(h); }
     TailArgs t;
-    t.part = part; t.b1 = m->b1;
+    t.part = part; t.b1 = m->b1; t.splits = splits;
     for (int i = 0; i < 4; i++) { t.wp[i] = m->wlp[i]; t.b[i] = m->bl[i]; }
     t.wo = m->wo; t.bo = m->bo; t.probs = d_probs; t.B = B;
     { pv_prof_scope ps(ctx, "k_head_tail", st); k_head_tail<<<(unsigned)n_tiles, 256, LDS_TAIL, st>>>(t); }
@@ -575,7 +580,7 @@ static int p1_workspace(pv_ctx* ctx, int64_t B, float** enc, float** dec, float*
     int rc;
     if ((rc = pv_get(ctx, "p1.enc_out", (size_t)B * T_STEPS * 2 * H, enc))) return rc;
     if ((rc = pv_get(ctx, "p1.dec_out", (size_t)B * T_STEPS * 2 * H, dec))) return rc;
-    if ((rc = pv_get(ctx, "p1.part", (size_t)HEAD_SPLITS * B * HEAD_N, part))) return rc;
+    if ((rc = pv_get(ctx, "p1.part", (size_t)HEAD_MAX_SPLITS * B * HEAD_N, part))) return rc;
     return PV_OK;
 }
 
