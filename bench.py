@@ -29,7 +29,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 BATCH = 512
-CALLERS = 8                      # steps fused per launch chain
+CALLERS = int(os.environ.get("PV_BENCH_CALLERS", "8"))   # steps fused per launch chain (callers_per_gpu analogue)
 REGION_LEN = 100_200             # 100 kb interval + 2 x 100 safe bases (AlignmentSummarizer.py:181-182)
 DEPTH = 60
 READ_LEN = 10_000
