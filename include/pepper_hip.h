@@ -207,6 +207,12 @@ int pv_rnn_forward_p2(pv_ctx* ctx, const uint8_t* images, int64_t B, uint8_t* la
 int pv_rnn_forward_p2_dev(pv_ctx* ctx, const uint8_t* d_images, int64_t B, uint8_t* d_labels, float* d_acc,
                           void* stream);
 
+/* P2, one model call: TransducerGRU.forward(x, hidden) (pepper/modules/python/models/simple_model.py:27-42,
+ * called once per window by predict.py:65). images uint8 [B,100,10], hidden_in float [B,2,128] (NULL = zeros)
+ * -> logits float [B,100,5] (before softmax), hidden_out float [B,2,128] (may be NULL). HOST pointers. */
+int pv_rnn_forward_p2_window(pv_ctx* ctx, const uint8_t* images, const float* hidden_in, int64_t B, float* logits,
+                             float* hidden_out);
+
 /* Per-kernel timing for the benchmark's roofline leg: between pv_profile_begin and pv_profile_end every
  * kernel the context launches is bracketed by HIP events on its launch stream. pv_profile_end
  * synchronises the device and returns the number of distinct kernels; names_buf receives their names

@@ -97,9 +97,14 @@ struct GruArgs {
     const float* dense_b;   // [5]
     float* enc_out;         // scratch [n_tiles][100][32][256]
     float* dec_out;         // scratch [n_tiles][100][32][256]
-    float* acc;             // [B,1000,5] (zero-initialised by the caller)
-    uint8_t* labels;        // [B,1000]
+    float* acc;             // [B,seq,5] (zero-initialised by the caller)
+    uint8_t* labels;        // [B,seq] or NULL
     int64_t B;
+    int seq;                // columns per chunk (1000; 100 for a single TransducerGRU.forward)
+    int nwin;               // windows of 100 columns, stride 50 (19; 1)
+    const float* hidden_in; // [B,2,128] or NULL (zeros)
+    float* hidden_out;      // [B,2,128] or NULL
+    float* logits;          // [B,100,5] raw dense1 output of the LAST window, or NULL
 };
 
 // one GRU layer over one 100-column window for this wave's direction
@@ -124,7 +129,7 @@ __device__ __forceinline__ void gru_window(const GruArgs& a, int win_start, int 
                 const int row = i / KPE, k = i - row * KPE;
                 int64_t b = b0 + row;
                 if (b >= a.B) b = a.B - 1;
-                xe[u] = k < FEAT ? (float)a.images[(b * SEQ + win_start + t) * FEAT + k] : 0.0f;
+                xe[u] = k < FEAT ? (float)a.images[(b * a.seq + win_start + t) * FEAT + k] : 0.0f;
             }
         } else {
 #pragma unroll
@@ -208,8 +213,21 @@ __global__ __launch_bounds__(512, 2) void k_gru_p2(GruArgs a) {
     for (int r = 0; r < 16; r++) hst[r] = 0.0f;
     int cur = 0;
     __syncthreads();
+    if (a.hidden_in) {  // TransducerGRU.forward(x, hidden): hidden [B,2,H], index 0 = forward (simple_model.py:28)
+        const int unit = 32 * wq + (lane & 31);
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            int64_t b = b0 + row;
+            if (b >= a.B) b = a.B - 1;
+            const float h = a.hidden_in[(b * 2 + dir) * HG + unit];
+            hst[r] = h;
+            hbuf[row * LDH + unit] = h;
+        }
+        __syncthreads();
+    }
 
-    for (int w = 0; w < NWIN; w++) {
+    for (int w = 0; w < a.nwin; w++) {
         const int ws = w * JUMP;
         gru_window<KPE, true>(a, ws, dir, wq, lane, tid_dir, b0, tile, xbuf, hbuf, cur, hst, enc_wp, enc_bias, nullptr, enc_out);
         // decoder h0 = encoder final state of the same direction: hst / hbuf[cur] simply carry over
@@ -238,23 +256,35 @@ __global__ __launch_bounds__(512, 2) void k_gru_p2(GruArgs a) {
 #pragma unroll
             for (int c = 0; c < NCLS; c++) { e[c] = expf(lg[c] - m); sum += e[c]; }
             const float inv = 1.0f / sum;
-            float* ac = a.acc + ((size_t)b * SEQ + ws + t) * NCLS;
+            float* ac = a.acc + ((size_t)b * a.seq + ws + t) * NCLS;
 #pragma unroll
             for (int c = 0; c < NCLS; c++) ac[c] += e[c] * inv;
+            if (a.logits && w == a.nwin - 1) {
+#pragma unroll
+                for (int c = 0; c < NCLS; c++) a.logits[((size_t)b * WIN + t) * NCLS + c] = lg[c];
+            }
         }
         __syncthreads();
     }
     // labels = argmax over the 5 classes, first maximum wins (torch.max, predict.py:91)
-    for (int p = tid; p < ROWS * SEQ; p += 512) {
-        const int row = p / SEQ, pos = p - row * SEQ;
+    if (a.hidden_out) {  // final decoder state (the next window's encoder h0, simple_model.py:41)
+        const int unit = 32 * wq + (lane & 31);
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const int64_t b = b0 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            if (b < a.B) a.hidden_out[(b * 2 + dir) * HG + unit] = hst[r];
+        }
+    }
+    for (int p = tid; a.labels && p < ROWS * a.seq; p += 512) {
+        const int row = p / a.seq, pos = p - row * a.seq;
         const int64_t b = b0 + row;
         if (b >= a.B) continue;
-        const float* ac = a.acc + ((size_t)b * SEQ + pos) * NCLS;
+        const float* ac = a.acc + ((size_t)b * a.seq + pos) * NCLS;
         int best = 0;
         float bv = ac[0];
 #pragma unroll
         for (int c = 1; c < NCLS; c++) if (ac[c] > bv) { bv = ac[c]; best = c; }
-        a.labels[(size_t)b * SEQ + pos] = (uint8_t)best;
+        a.labels[(size_t)b * a.seq + pos] = (uint8_t)best;
     }
 }
 
@@ -339,7 +369,9 @@ extern "C" int pv_rnn_load_p2(pv_ctx* ctx, const pv_weights_p2* w, int dtype) {
     return PV_OK;
 }
 
-static int p2_launch(pv_ctx* ctx, const uint8_t* d_images, int64_t B, uint8_t* d_labels, float* d_acc, hipStream_t st) {
+static int p2_launch(pv_ctx* ctx, const uint8_t* d_images, int64_t B, uint8_t* d_labels, float* d_acc, hipStream_t st,
+                     int seq = SEQ, int nwin = NWIN, const float* d_hidden_in = nullptr, float* d_hidden_out = nullptr,
+                     float* d_logits = nullptr) {
     pv_rnn_p2* m = ctx->p2;
     const int64_t n_tiles = (B + ROWS - 1) / ROWS;
     GruArgs g;
@@ -351,10 +383,11 @@ static int p2_launch(pv_ctx* ctx, const uint8_t* d_images, int64_t B, uint8_t* d
     if ((rc = pv_get(ctx, "p2.dec_out", (size_t)n_tiles * WIN * ROWS * KPD, &g.dec_out))) return rc;
     g.acc = d_acc;
     if (!g.acc)
-        if ((rc = pv_get(ctx, "p2.acc", (size_t)B * SEQ * NCLS, &g.acc))) return rc;
+        if ((rc = pv_get(ctx, "p2.acc", (size_t)B * seq * NCLS, &g.acc))) return rc;
     g.labels = d_labels;
     g.B = B;
-    PV_HIP(hipMemsetAsync(g.acc, 0, (size_t)B * SEQ * NCLS * sizeof(float), st));
+    g.seq = seq; g.nwin = nwin; g.hidden_in = d_hidden_in; g.hidden_out = d_hidden_out; g.logits = d_logits;
+    PV_HIP(hipMemsetAsync(g.acc, 0, (size_t)B * seq * NCLS * sizeof(float), st));
     {
         pv_prof_scope ps(ctx, "k_gru_p2", st);
         k_gru_p2<<<(unsigned)n_tiles, 512, LDS_P2, st>>>(g);
@@ -390,6 +423,36 @@ extern "C" int pv_rnn_forward_p2(pv_ctx* ctx, const uint8_t* images, int64_t B, 
     if ((rc = p2_launch(ctx, d_img, B, d_lab, d_acc, st))) return rc;
     PV_HIP(hipMemcpyAsync(labels, d_lab, (size_t)B * SEQ, hipMemcpyDeviceToHost, st));
     if (acc) PV_HIP(hipMemcpyAsync(acc, d_acc, (size_t)B * SEQ * NCLS * sizeof(float), hipMemcpyDeviceToHost, st));
+    PV_HIP(hipStreamSynchronize(st));
+    return PV_OK;
+}
+
+// One TransducerGRU.forward(x, hidden) of the polisher model (pepper/modules/python/models/simple_model.py:27-42),
+// i.e. the operator the reference's sliding loop calls once per window (predict.py:65): images uint8
+// [B,100,10], hidden_in [B,2,128] (NULL = zeros) -> logits [B,100,5], hidden_out [B,2,128]. HOST pointers.
+extern "C" int pv_rnn_forward_p2_window(pv_ctx* ctx, const uint8_t* images, const float* hidden_in, int64_t B, float* logits,
+                                        float* hidden_out) {
+    PV_CHECK(ctx && images && logits, PV_ERR_INVALID, "null argument");
+    PV_CHECK(ctx->p2, PV_ERR_STATE, "pv_rnn_load_p2 has not been called on this context");
+    PV_CHECK(B >= 0 && B < (1ll << 22), PV_ERR_INVALID, "batch %lld out of range", (long long)B);
+    if (B == 0) return PV_OK;
+    PV_HIP(hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    uint8_t* d_img;
+    float *d_hin = nullptr, *d_hout, *d_log, *d_acc;
+    int rc;
+    if ((rc = pv_get(ctx, "p2w.images", (size_t)B * WIN * FEAT, &d_img))) return rc;
+    if ((rc = pv_get(ctx, "p2w.hout", (size_t)B * 2 * HG, &d_hout))) return rc;
+    if ((rc = pv_get(ctx, "p2w.logits", (size_t)B * WIN * NCLS, &d_log))) return rc;
+    if ((rc = pv_get(ctx, "p2w.acc", (size_t)B * WIN * NCLS, &d_acc))) return rc;
+    PV_HIP(hipMemcpyAsync(d_img, images, (size_t)B * WIN * FEAT, hipMemcpyHostToDevice, st));
+    if (hidden_in) {
+        if ((rc = pv_get(ctx, "p2w.hin", (size_t)B * 2 * HG, &d_hin))) return rc;
+        PV_HIP(hipMemcpyAsync(d_hin, hidden_in, (size_t)B * 2 * HG * sizeof(float), hipMemcpyHostToDevice, st));
+    }
+    if ((rc = p2_launch(ctx, d_img, B, nullptr, d_acc, st, WIN, 1, d_hin, d_hout, d_log))) return rc;
+    PV_HIP(hipMemcpyAsync(logits, d_log, (size_t)B * WIN * NCLS * sizeof(float), hipMemcpyDeviceToHost, st));
+    if (hidden_out) PV_HIP(hipMemcpyAsync(hidden_out, d_hout, (size_t)B * 2 * HG * sizeof(float), hipMemcpyDeviceToHost, st));
     PV_HIP(hipStreamSynchronize(st));
     return PV_OK;
 }

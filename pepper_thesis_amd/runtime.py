@@ -131,6 +131,19 @@ class Context:
                                               None if acc is None else acc.ctypes.data))
         return (labels, acc) if want_acc else labels
 
+    def forward_p2_window(self, images: np.ndarray, hidden: Optional[np.ndarray] = None):
+        """TransducerGRU.forward(x, hidden): images uint8 [B,100,10], hidden [B,2,128] or None -> (logits [B,100,5], hidden [B,2,128])"""
+        x = np.ascontiguousarray(images, dtype=np.uint8)
+        assert x.ndim == 3 and x.shape[1:] == (100, 10), x.shape
+        B = x.shape[0]
+        h_in = None if hidden is None else np.ascontiguousarray(hidden, dtype=np.float32)
+        assert h_in is None or h_in.shape == (B, 2, 128)
+        logits = np.zeros((B, 100, 5), np.float32)
+        h_out = np.zeros((B, 2, 128), np.float32)
+        _ffi.check(self.lib.pv_rnn_forward_p2_window(self.handle, x.ctypes.data, None if h_in is None else h_in.ctypes.data, B,
+                                                     logits.ctypes.data, h_out.ctypes.data))
+        return logits, h_out
+
     # ---- device-resident forms (the fused pipeline / benchmark) -----------------------------------------
     def summarize_dev(self, dbatch: "DeviceBatch", params: Params, dout: "DeviceOut", stream: int = 0):
         """asynchronous; every array lives in HBM (see device.py). Counters land in dout.counts."""

@@ -122,3 +122,22 @@ def test_p2_extremes_and_labels_only(hip_ctx):
     labels = hip_ctx.forward_p2(x)
     lr, ar = rnn_oracle.p2_forward(w, x, np.float64)
     _check_labels(labels, ar, lr)
+
+
+def test_p2_single_window_operator(hip_ctx, gold):
+    """the model call the reference's loop makes per window: logits + carried hidden (predict.py:65)"""
+    tag = "p2"
+    w = synth.make_weights_p2(int(gold[tag + "/seed"][0]))
+    hip_ctx.load_p2(w)
+    x = gold[tag + "/images"]
+    logits, h = hip_ctx.forward_p2_window(x[:, :100])
+    np.testing.assert_allclose(logits, gold[tag + "/first_logits"], atol=5e-5, rtol=0)
+    # chain 4 windows through the operator, carrying hidden on the host, against the float64 oracle
+    w64 = {k: v.astype(np.float64) for k, v in w.items()}
+    hid = np.zeros((2, x.shape[0], 128))
+    hgpu = None
+    for i in range(0, 200, 50):
+        lg, hid = rnn_oracle.p2_window(w64, x[:, i:i + 100].astype(np.float64), hid)
+        lgpu, hgpu = hip_ctx.forward_p2_window(x[:, i:i + 100], hgpu)
+        np.testing.assert_allclose(lgpu, lg, atol=1e-4, rtol=0)
+        np.testing.assert_allclose(hgpu, hid.transpose(1, 0, 2), atol=5e-5, rtol=0)
