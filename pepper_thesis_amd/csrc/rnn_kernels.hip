@@ -99,8 +99,10 @@ struct LstmArgs {
     const float* wp;      // packed [2 dirs][NW waves][nkb][32/NW tiles][64][4]
     const float* bias;    // [2][1024] b_ih + b_hh
     float* out;           // [B,33,512]
+    float* out_packed;    // optional [n_tiles][33][64 kb][64 lanes][4]: A-fragment order of the next layer's x operand
     int64_t B;
     int n_tiles;
+    unsigned long long* stamps;  // diagnostic builds (-DPV_STAMPS) only
     int ablate;  // diagnostics only (PV_ABLATE): 1 = trivial cell update, 2 = stage x_t only at step 0, 4 = no global h store
 };
 
@@ -124,7 +126,11 @@ __device__ __forceinline__ void mma_dual(f32x16 (&acc)[NT], const float* __restr
 #pragma nounroll
     for (; kb + 1 < nkb; kb += 2) {
 #pragma unroll
+#ifndef ABL_NOBLOAD
         for (int nt = 0; nt < NT; nt++) b1[nt] = bp[((kb + 1) * NT + nt) * 64];
+#else
+        for (int nt = 0; nt < NT; nt++) { b1[nt] = b0[nt]; asm volatile("" : "+v"(b1[nt])); }
+#endif
         a1 = *reinterpret_cast<const f32x4*>((kb + 1 < nkb1 ? ap1 : ap2) + 8 * (kb + 1));
 #pragma unroll
         for (int j = 0; j < 4; j++)
@@ -132,7 +138,11 @@ __device__ __forceinline__ void mma_dual(f32x16 (&acc)[NT], const float* __restr
             for (int nt = 0; nt < NT; nt++) acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[j], b0[nt][j], acc[nt], 0, 0, 0);
         if (kb + 2 < nkb) {
 #pragma unroll
+#ifndef ABL_NOBLOAD
             for (int nt = 0; nt < NT; nt++) b0[nt] = bp[((kb + 2) * NT + nt) * 64];
+#else
+            for (int nt = 0; nt < NT; nt++) { b0[nt] = b1[nt]; asm volatile("" : "+v"(b0[nt])); }
+#endif
             a0 = *reinterpret_cast<const f32x4*>((kb + 2 < nkb1 ? ap1 : ap2) + 8 * (kb + 2));
         }
 #pragma unroll
@@ -148,10 +158,55 @@ __device__ __forceinline__ void mma_dual(f32x16 (&acc)[NT], const float* __restr
     }
 }
 
+// Same contract as mma_dual, but the B fragments run in a ring of FOUR register sets and are requested
+// TWO k-blocks ahead of their use (A fragments, from LDS, one block ahead). Requires (nkb1 + nkb2) % 4 == 0.
+template <int NT>
+__device__ __forceinline__ void mma_dual_ring4(f32x16 (&acc)[NT], const float* __restrict__ A1, int lda1, int nkb1,
+                                               const float* __restrict__ A2, int lda2, int nkb2,
+                                               const float* __restrict__ Bp, const f32x4 (&bres)[NT], int lane) {
+    const float* ap1 = A1 + (lane & 31) * lda1 + 4 * (lane >> 5);
+    const float* ap2 = A2 + (lane & 31) * lda2 + 4 * (lane >> 5) - 8 * nkb1;
+    const f32x4* bp = reinterpret_cast<const f32x4*>(Bp) + lane;
+    const int nkb = nkb1 + nkb2;
+    f32x4 bq[4][NT], aq[2];
+#define R4_B(slot, kbv) { _Pragma("unroll") for (int nt = 0; nt < NT; nt++) bq[slot][nt] = bp[((kbv) * NT + nt) * 64]; }
+#define R4_A(slot, kbv) { aq[slot] = *reinterpret_cast<const f32x4*>(((kbv) < nkb1 ? ap1 : ap2) + 8 * (kbv)); }
+#define R4_M(bs, as)                                                                    \
+    {                                                                                   \
+        _Pragma("unroll") for (int j = 0; j < 4; j++)                                   \
+            _Pragma("unroll") for (int nt = 0; nt < NT; nt++)                           \
+                acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(aq[as][j], bq[bs][nt][j], acc[nt], 0, 0, 0); \
+    }
+#pragma unroll
+    for (int nt = 0; nt < NT; nt++) bq[0][nt] = bres[nt];
+    R4_B(1, 1)
+    R4_A(0, 0)
+#pragma nounroll
+    for (int kb = 0; kb < nkb; kb += 4) {
+        R4_B(2, kb + 2)
+        R4_A(1, kb + 1)
+        R4_M(0, 0)
+        R4_B(3, kb + 3)
+        R4_A(0, kb + 2)
+        R4_M(1, 1)
+        if (kb + 4 < nkb) R4_B(0, kb + 4)
+        R4_A(1, kb + 3)
+        R4_M(2, 0)
+        if (kb + 4 < nkb) {
+            R4_B(1, kb + 5)
+            R4_A(0, kb + 4)
+        }
+        R4_M(3, 1)
+    }
+#undef R4_B
+#undef R4_A
+#undef R4_M
+}
+
 // KP = padded input width (multiple of 8): 32 for the encoder (26 real), 512 for the decoder.
 // NW = waves per workgroup: 8 (two per SIMD: one wave's LDS/L2 waits and cell update hide behind the
 // other's MFMAs) or 4 (one per SIMD).
-template <int KP, bool INT8, int NW>
+template <int KP, bool INT8, int NW, bool PACKED>
 __global__ __launch_bounds__(NW * 64, NW / 4) void k_lstm_layer(LstmArgs a) {
     constexpr int LDX = KP + 4, LDH = H + 4;
     constexpr int NKB_X = KP / 8, NKB_H = H / 8;
@@ -236,9 +291,16 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void k_lstm_layer(LstmArgs a) {
     x_store();
     __syncthreads();
 
+#ifdef PV_STAMPS
+    unsigned long long st_m = 0, st_c = 0, st_b = 0, st_s = 0, t0s, t1s;
+#define STAMPL(v) { __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) :: "memory"); __builtin_amdgcn_sched_barrier(0); }
+#endif
     for (int s = 0; s < T_STEPS; s++) {
         const int t = dir ? (T_STEPS - 1 - s) : s;
         const int cur = s & 1, nxt = cur ^ 1;
+#ifdef PV_STAMPS
+        STAMPL(t0s)
+#endif
         if (s + 1 < T_STEPS && !(a.ablate & 2)) x_load(dir ? (T_STEPS - 2 - s) : (s + 1));
         // ---- gates = bias + [x_t | h_{t-1}] . [W_ih | W_hh]^T -------------------------------------
         f32x16 acc[NT];
@@ -246,7 +308,18 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void k_lstm_layer(LstmArgs a) {
         for (int nt = 0; nt < NT; nt++)
 #pragma unroll
             for (int r = 0; r < 16; r++) acc[nt][r] = bs[nt];
-        mma_dual<NT>(acc, xbuf, LDX, NKB_X, hbuf + cur * ROWS * LDH, LDH, NKB_H, wp, bres, lane);
+        if constexpr (NW == 8) {
+#ifdef PV_RING4
+            mma_dual_ring4<NT>(acc, xbuf, LDX, NKB_X, hbuf + cur * ROWS * LDH, LDH, NKB_H, wp, bres, lane);
+#else
+            mma_dual<NT>(acc, xbuf, LDX, NKB_X, hbuf + cur * ROWS * LDH, LDH, NKB_H, wp, bres, lane);
+#endif
+        } else {
+            mma_dual<NT>(acc, xbuf, LDX, NKB_X, hbuf + cur * ROWS * LDH, LDH, NKB_H, wp, bres, lane);
+        }
+#ifdef PV_STAMPS
+        STAMPL(t1s) st_m += t1s - t0s; t0s = t1s;
+#endif
         // ---- cell update (PyTorch gate order i,f,g,o; nt = gate*S2 + sub-tile) ---------------------
         float* hn = hbuf + nxt * ROWS * LDH;
 #pragma unroll
@@ -258,8 +331,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void k_lstm_layer(LstmArgs a) {
                     const float h = acc[0 * S2 + s2][r] * 1e-3f + acc[1 * S2 + s2][r] * 1e-3f + acc[2 * S2 + s2][r] * 1e-3f + acc[3 * S2 + s2][r] * 1e-3f;
                     const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
                     hn[row * LDH + unit] = h;
-                    const int64_t b = b0 + row;
-                    if (b < a.B && !(a.ablate & 4)) a.out[(b * T_STEPS + t) * (int64_t)(2 * H) + dir * H + unit] = h;
+                    if (!(a.ablate & 4)) a.out[((size_t)(b0 + row) * T_STEPS + t) * (2 * H) + dir * H + unit] = h;
                     continue;
                 }
                 const float ig = sigmoidf_(acc[0 * S2 + s2][r]);
@@ -271,16 +343,198 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void k_lstm_layer(LstmArgs a) {
                 const float h = og * tanhf_(c);
                 const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
                 hn[row * LDH + unit] = h;
-                const int64_t b = b0 + row;
-                if (b < a.B && !(a.ablate & 4)) a.out[(b * T_STEPS + t) * (int64_t)(2 * H) + dir * H + unit] = h;
+                // outputs are padded to whole 32-row tiles: unconditional stores, uniform base + 32-bit lane offset
+                if constexpr (PACKED) {  // fragment order: [kb = col/8][lane = (col%8/4)*32 + row][col%4]
+                    const unsigned col = dir * H + unit;
+                    float* pk = a.out_packed + ((size_t)tile * T_STEPS + t) * 64 * 256;
+                    pk[(col >> 3) * 256 + ((((col >> 2) & 1) * 32 + row) << 2) + (col & 3)] = h;
+                } else {
+                    float* ob = a.out + ((size_t)b0 * T_STEPS + t) * (2 * H) + dir * H;
+                    ob[(unsigned)row * (T_STEPS * 2 * H) + (unsigned)unit] = h;
+                }
             }
         }
+#ifdef PV_STAMPS
+        STAMPL(t1s) st_c += t1s - t0s; t0s = t1s;
+#endif
         __syncthreads();  // everyone is done reading xbuf / hbuf[cur]; hbuf[nxt] is complete
+#ifdef PV_STAMPS
+        STAMPL(t1s) st_b += t1s - t0s; t0s = t1s;
+#endif
         if (s + 1 < T_STEPS && !(a.ablate & 2)) {
             x_store();
             __syncthreads();
         }
+#ifdef PV_STAMPS
+        STAMPL(t1s) st_s += t1s - t0s;
+#endif
     }
+#ifdef PV_STAMPS
+    if (lane == 0 && a.stamps) {
+        unsigned long long* o = a.stamps + ((size_t)blockIdx.x * 8 + wv) * 4;
+        o[0] = st_m; o[1] = st_c; o[2] = st_b; o[3] = st_s;
+    }
+#endif
+}
+
+
+// ---- decoder LSTM, staggered ------------------------------------------------------------------------------
+// Same math and weight packing as k_lstm_layer<512,false,8>, different choreography:
+//  * the x operand (encoder output) is read straight from HBM/L2 in A-fragment order (the encoder writes a
+//    packed copy), one coalesced 1-KB load per wave per k-block, prefetched like the weights: no x tile in
+//    LDS, no staging barriers;
+//  * the only per-step synchronisation is the h exchange, done with a monotonic LDS counter instead of
+//    s_barrier: a wave may run its x-part MFMAs of step s+1 as soon as its own cell update of step s is
+//    done, and waits only before the h-part;
+//  * waves 4-7 (the SIMD partners of waves 0-3) start half an x-part late, so one partner's cell update
+//    (VALU) overlaps the other's x-part (MFMA) instead of both idling the matrix pipe together.
+struct DecArgs {
+    const float* xp;      // packed encoder output [n_tiles][33][64][64][4]
+    const float* wp;      // packed [2 dirs][8 waves][96 kb][4 tiles][64][4]
+    const float* bias;    // [2][1024]
+    float* out;           // [B,33,512]
+    int64_t B;
+    int n_tiles;
+    int stagger;          // s_sleep(127) iterations for waves 4-7
+    unsigned long long* stamps;  // diagnostic builds (-DPV_STAMPS) only: [grid][8 waves][4] phase cycle sums
+};
+
+__global__ __launch_bounds__(512, 2) void k_lstm_dec_stagger(DecArgs a) {
+    constexpr int LDH = H + 4;
+    constexpr int NKB_X = 64, NKB_H = H / 8, NT = 4, UW = 32;
+    extern __shared__ float smem[];
+    float* hbuf = smem;  // [2][32][LDH]
+    __shared__ int s_hdone;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int xcd = blockIdx.x & 7;
+    const int dir = xcd & 1;
+    const int tile = (blockIdx.x >> 3) * 4 + (xcd >> 1);
+    if (tile >= a.n_tiles) return;
+    const int64_t b0 = (int64_t)tile * ROWS;
+    const f32x4* wp = reinterpret_cast<const f32x4*>(a.wp + ((size_t)(dir * 8 + wv) * (NKB_X + NKB_H)) * NT * 256) + lane;
+    const f32x4* xp = reinterpret_cast<const f32x4*>(a.xp + (size_t)tile * T_STEPS * NKB_X * 256) + lane;
+    const float* bias = a.bias + dir * 4 * H;
+    for (int i = tid; i < 2 * ROWS * LDH; i += 512) hbuf[i] = 0.0f;
+    if (tid == 0) s_hdone = 0;
+    f32x16 cst;
+#pragma unroll
+    for (int r = 0; r < 16; r++) cst[r] = 0.0f;
+    float bs[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; nt++) bs[nt] = bias[nt * H + UW * wv + (lane & 31)];
+    __syncthreads();
+    if (wv >= 4)
+        for (int i = 0; i < a.stagger; i++) __builtin_amdgcn_s_sleep(127);
+    const float* ah_base = hbuf + (lane & 31) * LDH + 4 * (lane >> 5);
+
+#ifdef PV_STAMPS
+    unsigned long long st_x = 0, st_w = 0, st_h = 0, st_c = 0, t0s, t1s;
+#define STAMP(v) { __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) :: "memory"); __builtin_amdgcn_sched_barrier(0); }
+#else
+#define STAMP(v)
+#endif
+    for (int s = 0; s < T_STEPS; s++) {
+        const int t = dir ? (T_STEPS - 1 - s) : s;
+        const int cur = s & 1, nxt = cur ^ 1;
+#ifdef PV_STAMPS
+        STAMP(t0s)
+#endif
+        const f32x4* xs = xp + (size_t)t * NKB_X * 64;
+        f32x16 acc[NT];
+#pragma unroll
+        for (int nt = 0; nt < NT; nt++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[nt][r] = bs[nt];
+        // ---- x part: both operands stream from L2/HBM, one k-block ahead (two register sets, compiler-scheduled)
+        f32x4 b0v[NT], b1v[NT], a0, a1;
+#pragma unroll
+        for (int nt = 0; nt < NT; nt++) b0v[nt] = wp[nt * 64];
+        a0 = xs[0];
+#pragma nounroll
+        for (int kb = 0; kb < NKB_X; kb += 2) {
+#pragma unroll
+            for (int nt = 0; nt < NT; nt++) b1v[nt] = wp[((kb + 1) * NT + nt) * 64];
+            a1 = xs[(kb + 1) * 64];
+#pragma unroll
+            for (int j = 0; j < 4; j++)
+#pragma unroll
+                for (int nt = 0; nt < NT; nt++) acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[j], b0v[nt][j], acc[nt], 0, 0, 0);
+#pragma unroll
+            for (int nt = 0; nt < NT; nt++) b0v[nt] = wp[((kb + 2) * NT + nt) * 64];  // kb+2 == NKB_X: first h block
+            if (kb + 2 < NKB_X) a0 = xs[(kb + 2) * 64];
+#pragma unroll
+            for (int j = 0; j < 4; j++)
+#pragma unroll
+                for (int nt = 0; nt < NT; nt++) acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[j], b1v[nt][j], acc[nt], 0, 0, 0);
+        }
+#ifdef PV_STAMPS
+        STAMP(t1s) st_x += t1s - t0s; t0s = t1s;
+#endif
+        // ---- wait for h_{s-1} of every wave ------------------------------------------------------------------
+        if (s > 0) {
+            const int need = 8 * s;
+            while (__hip_atomic_load(&s_hdone, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < need) __builtin_amdgcn_s_sleep(1);
+            asm volatile("" ::: "memory");  // LDS has no cache: program order is enough, and a fence would also drain vmcnt
+        }
+#ifdef PV_STAMPS
+        STAMP(t1s) st_w += t1s - t0s; t0s = t1s;
+#endif
+        // ---- h part: A from LDS, B keeps streaming -------------------------------------------------------------
+        const float* ah = ah_base + cur * ROWS * LDH;
+        a0 = *reinterpret_cast<const f32x4*>(ah);
+#pragma nounroll
+        for (int kb = 0; kb < NKB_H; kb += 2) {
+#pragma unroll
+            for (int nt = 0; nt < NT; nt++) b1v[nt] = wp[((NKB_X + kb + 1) * NT + nt) * 64];
+            a1 = *reinterpret_cast<const f32x4*>(ah + 8 * (kb + 1));
+#pragma unroll
+            for (int j = 0; j < 4; j++)
+#pragma unroll
+                for (int nt = 0; nt < NT; nt++) acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[j], b0v[nt][j], acc[nt], 0, 0, 0);
+            if (kb + 2 < NKB_H) {
+#pragma unroll
+                for (int nt = 0; nt < NT; nt++) b0v[nt] = wp[((NKB_X + kb + 2) * NT + nt) * 64];
+                a0 = *reinterpret_cast<const f32x4*>(ah + 8 * (kb + 2));
+            }
+#pragma unroll
+            for (int j = 0; j < 4; j++)
+#pragma unroll
+                for (int nt = 0; nt < NT; nt++) acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[j], b1v[nt][j], acc[nt], 0, 0, 0);
+        }
+#ifdef PV_STAMPS
+        STAMP(t1s) st_h += t1s - t0s; t0s = t1s;
+#endif
+        // ---- cell update ---------------------------------------------------------------------------------------
+        float* hn = hbuf + nxt * ROWS * LDH;
+        const int unit = UW * wv + (lane & 31);
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const float ig = sigmoidf_(acc[0][r]);
+            const float fg = sigmoidf_(acc[1][r]);
+            const float gg = tanhf_(acc[2][r]);
+            const float og = sigmoidf_(acc[3][r]);
+            const float c = fg * cst[r] + ig * gg;
+            cst[r] = c;
+            const float h = og * tanhf_(c);
+            const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            hn[row * LDH + unit] = h;
+            float* ob = a.out + ((size_t)b0 * T_STEPS + t) * (2 * H) + dir * H;  // rows padded to the tile: no bounds branch
+            ob[(unsigned)row * (T_STEPS * 2 * H) + (unsigned)unit] = h;
+        }
+        // publish: this wave's slice of h_s is in LDS. Only the LDS queue has to drain (it is in-order per wave);
+        // a workgroup release fence would also wait for the h stores and the prefetched operands (vmcnt(0)).
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (lane == 0) __hip_atomic_fetch_add(&s_hdone, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#ifdef PV_STAMPS
+        STAMP(t1s) st_c += t1s - t0s;
+#endif
+    }
+#ifdef PV_STAMPS
+    if (lane == 0 && a.stamps) {
+        unsigned long long* o = a.stamps + ((size_t)blockIdx.x * 8 + wv) * 4;
+        o[0] = st_x; o[1] = st_w; o[2] = st_h; o[3] = st_c;
+    }
+#endif
 }
 
 struct HeadArgs {
@@ -459,6 +713,7 @@ static void pack_linear(const float* W, int K, std::vector<float>& wp) {
 
 static constexpr size_t LDS_ENC = (size_t)(ROWS * (32 + 4) + 2 * ROWS * (H + 4)) * sizeof(float);
 static constexpr size_t LDS_DEC = (size_t)(ROWS * (2 * H + 4) + 2 * ROWS * (H + 4)) * sizeof(float);
+static constexpr size_t LDS_DEC_STAGGER = (size_t)(2 * ROWS * (H + 4)) * sizeof(float);
 static constexpr size_t LDS_SPLITK = (size_t)ROWS * (2 * H + 4) * sizeof(float);
 static constexpr size_t LDS_TAIL = (size_t)2 * ROWS * (HEAD_N + 4) * sizeof(float);
 
@@ -471,6 +726,8 @@ struct pv_rnn_p1 {
     float* wo = nullptr; float* bo = nullptr;
     int dtype = PV_DTYPE_F32;
     int nw = 8;  // waves per LSTM workgroup (PV_LSTM_WAVES=4|8)
+    int dec_stagger = -1;  // PV_DEC_STAGGER: -1 (default) = barrier decoder k_lstm_layer<512>; >= 0 = experimental flag-synchronised
+                           // decoder k_lstm_dec_stagger with that many sleep units of stagger (measured slower: DESIGN.md section 6)
     std::vector<void*> owned;
 };
 
@@ -519,6 +776,8 @@ extern "C" int pv_rnn_load_p1(pv_ctx* ctx, const pv_weights_p1* w, int dtype) {
     std::vector<float> wp, bias;
     int rc;
     if (const char* e = getenv("PV_LSTM_WAVES")) m->nw = (atoi(e) == 4) ? 4 : 8;
+    if (const char* e = getenv("PV_DEC_STAGGER")) m->dec_stagger = atoi(e);
+    if (m->nw != 8) m->dec_stagger = -1;
     pack_lstm(w->encoder, F_IN, 32, m->nw, wp, bias);
     if ((rc = dev_upload(wp, &m->enc_wp, m->owned)) || (rc = dev_upload(bias, &m->enc_bias, m->owned))) return rc;
     pack_lstm(w->decoder, 2 * H, 2 * H, m->nw, wp, bias);
@@ -532,34 +791,60 @@ extern "C" int pv_rnn_load_p1(pv_ctx* ctx, const pv_weights_p1* w, int dtype) {
     }
     if ((rc = dev_upload(w->out_w, 3 * HEAD_N, &m->wo, m->owned)) || (rc = dev_upload(w->out_b, 3, &m->bo, m->owned))) return rc;
     // opt in to > 64 KB of dynamic LDS (exact sizes; static LDS counts against the 160 KB too)
-    PV_HIP(hipFuncSetAttribute((const void*)k_lstm_layer<32, true, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_ENC));
-    PV_HIP(hipFuncSetAttribute((const void*)k_lstm_layer<512, false, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_DEC));
-    PV_HIP(hipFuncSetAttribute((const void*)k_lstm_layer<32, true, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_ENC));
-    PV_HIP(hipFuncSetAttribute((const void*)k_lstm_layer<512, false, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_DEC));
+    PV_HIP(hipFuncSetAttribute((const void*)k_lstm_layer<32, true, 4, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_ENC));
+    PV_HIP(hipFuncSetAttribute((const void*)k_lstm_layer<512, false, 4, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_DEC));
+    PV_HIP(hipFuncSetAttribute((const void*)k_lstm_layer<32, true, 8, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_ENC));
+    PV_HIP(hipFuncSetAttribute((const void*)k_lstm_layer<32, true, 8, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_ENC));
+    PV_HIP(hipFuncSetAttribute((const void*)k_lstm_layer<512, false, 8, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_DEC));
+    PV_HIP(hipFuncSetAttribute((const void*)k_lstm_dec_stagger, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_DEC_STAGGER));
     PV_HIP(hipFuncSetAttribute((const void*)k_head_splitk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_SPLITK));
     PV_HIP(hipFuncSetAttribute((const void*)k_head_tail, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_TAIL));
     return PV_OK;
 }
 
 static int p1_forward_launch(pv_ctx* ctx, const int8_t* d_images, int64_t B, float* d_probs, float* enc_out,
-                             float* dec_out, float* part, hipStream_t st) {
+                             float* dec_out, float* part, hipStream_t st, float* enc_packed = nullptr) {
     pv_rnn_p1* m = ctx->p1;
     const int n_tiles = (int)((B + ROWS - 1) / ROWS);
     const unsigned lstm_grid = (unsigned)(((n_tiles + 3) / 4) * 8);
     LstmArgs e;
     e.ablate = getenv("PV_ABLATE") ? atoi(getenv("PV_ABLATE")) : 0;
+    e.stamps = nullptr;
+    const bool stag = m->dec_stagger >= 0 && enc_packed != nullptr;
     e.x_i8 = d_images; e.x_f32 = nullptr; e.wp = m->enc_wp; e.bias = m->enc_bias; e.out = enc_out; e.B = B; e.n_tiles = n_tiles;
+    e.out_packed = stag ? enc_packed : nullptr;
     {
         pv_prof_scope ps(ctx, "k_lstm_layer_enc", st);
-        if (m->nw == 8) k_lstm_layer<32, true, 8><<<lstm_grid, 512, LDS_ENC, st>>>(e);
-        else k_lstm_layer<32, true, 4><<<lstm_grid, 256, LDS_ENC, st>>>(e);
+        if (m->nw == 8 && stag) k_lstm_layer<32, true, 8, true><<<lstm_grid, 512, LDS_ENC, st>>>(e);
+        else if (m->nw == 8) k_lstm_layer<32, true, 8, false><<<lstm_grid, 512, LDS_ENC, st>>>(e);
+        else k_lstm_layer<32, true, 4, false><<<lstm_grid, 256, LDS_ENC, st>>>(e);
     }
     LstmArgs d = e;
     d.x_i8 = nullptr; d.x_f32 = enc_out; d.wp = m->dec_wp; d.bias = m->dec_bias; d.out = dec_out;
+    d.out_packed = nullptr;
+#ifdef PV_STAMPS
     {
+        unsigned long long* sp = nullptr;
+        if (pv_get(ctx, "p1.stamps", (size_t)lstm_grid * 8 * 4, &sp) == PV_OK) d.stamps = sp;
+    }
+#endif
+    if (stag) {
+        DecArgs da;
+        da.xp = enc_packed; da.wp = m->dec_wp; da.bias = m->dec_bias; da.out = dec_out; da.B = B; da.n_tiles = n_tiles;
+        da.stagger = m->dec_stagger;
+        da.stamps = nullptr;
+#ifdef PV_STAMPS
+        {
+            unsigned long long* sp = nullptr;
+            if (pv_get(ctx, "p1.stamps", (size_t)lstm_grid * 8 * 4, &sp) == PV_OK) da.stamps = sp;
+        }
+#endif
         pv_prof_scope ps(ctx, "k_lstm_layer_dec", st);
-        if (m->nw == 8) k_lstm_layer<512, false, 8><<<lstm_grid, 512, LDS_DEC, st>>>(d);
-        else k_lstm_layer<512, false, 4><<<lstm_grid, 256, LDS_DEC, st>>>(d);
+        k_lstm_dec_stagger<<<lstm_grid, 512, LDS_DEC_STAGGER, st>>>(da);
+    } else {
+        pv_prof_scope ps(ctx, "k_lstm_layer_dec", st);
+        if (m->nw == 8) k_lstm_layer<512, false, 8, false><<<lstm_grid, 512, LDS_DEC, st>>>(d);
+        else k_lstm_layer<512, false, 4, false><<<lstm_grid, 256, LDS_DEC, st>>>(d);
     }
     HeadArgs h;
     // split-K factor: 11 slabs of 3 time steps; 33 single-step slabs only for batches too small to fill the chip
@@ -576,10 +861,15 @@ static int p1_forward_launch(pv_ctx* ctx, const int8_t* d_images, int64_t B, flo
     return PV_OK;
 }
 
-static int p1_workspace(pv_ctx* ctx, int64_t B, float** enc, float** dec, float** part) {
+static int p1_workspace(pv_ctx* ctx, int64_t B, float** enc, float** dec, float** part, float** enc_packed = nullptr) {
     int rc;
-    if ((rc = pv_get(ctx, "p1.enc_out", (size_t)B * T_STEPS * 2 * H, enc))) return rc;
-    if ((rc = pv_get(ctx, "p1.dec_out", (size_t)B * T_STEPS * 2 * H, dec))) return rc;
+    if (enc_packed) {
+        const size_t n_tiles = (size_t)((B + ROWS - 1) / ROWS);
+        if ((rc = pv_get(ctx, "p1.enc_packed", n_tiles * T_STEPS * 64 * 256, enc_packed))) return rc;
+    }
+    const size_t Bp = (size_t)((B + ROWS - 1) / ROWS) * ROWS;  // LSTM kernels store whole 32-row tiles
+    if ((rc = pv_get(ctx, "p1.enc_out", Bp * T_STEPS * 2 * H, enc))) return rc;
+    if ((rc = pv_get(ctx, "p1.dec_out", Bp * T_STEPS * 2 * H, dec))) return rc;
     if ((rc = pv_get(ctx, "p1.part", (size_t)HEAD_MAX_SPLITS * B * HEAD_N, part))) return rc;
     return PV_OK;
 }
@@ -591,9 +881,10 @@ extern "C" int pv_rnn_forward_p1_dev(pv_ctx* ctx, const int8_t* d_images, int64_
     if (B == 0) return PV_OK;
     PV_HIP(hipSetDevice(ctx->device));
     float *enc, *dec, *part;
-    int rc = p1_workspace(ctx, B, &enc, &dec, &part);
+    float* encp = nullptr;
+    int rc = p1_workspace(ctx, B, &enc, &dec, &part, ctx->p1->dec_stagger >= 0 ? &encp : nullptr);
     if (rc) return rc;
-    return p1_forward_launch(ctx, d_images, B, d_probs, enc, dec, part, pv_pick_stream(ctx, stream));
+    return p1_forward_launch(ctx, d_images, B, d_probs, enc, dec, part, pv_pick_stream(ctx, stream), encp);
 }
 
 extern "C" int pv_rnn_forward_p1_debug(pv_ctx* ctx, const int8_t* images, int64_t B, float* probs, float* enc_out,
@@ -606,12 +897,15 @@ extern "C" int pv_rnn_forward_p1_debug(pv_ctx* ctx, const int8_t* images, int64_
     hipStream_t st = ctx->stream;
     float *enc, *dec, *part, *d_probs;
     int8_t* d_img;
-    int rc = p1_workspace(ctx, B, &enc, &dec, &part);
+    // the encoder tap needs the row-major encoder output, which only the barrier decoder path produces
+    float* encp = nullptr;
+    const bool want_packed = ctx->p1->dec_stagger >= 0 && !enc_out;
+    int rc = p1_workspace(ctx, B, &enc, &dec, &part, want_packed ? &encp : nullptr);
     if (rc) return rc;
     if ((rc = pv_get(ctx, "p1.images", (size_t)B * PV_WINDOW_BYTES, &d_img))) return rc;
     if ((rc = pv_get(ctx, "p1.probs", (size_t)B * 3, &d_probs))) return rc;
     PV_HIP(hipMemcpyAsync(d_img, images, (size_t)B * PV_WINDOW_BYTES, hipMemcpyHostToDevice, st));
-    if ((rc = p1_forward_launch(ctx, d_img, B, d_probs, enc, dec, part, st))) return rc;
+    if ((rc = p1_forward_launch(ctx, d_img, B, d_probs, enc, dec, part, st, encp))) return rc;
     PV_HIP(hipMemcpyAsync(probs, d_probs, (size_t)B * 3 * sizeof(float), hipMemcpyDeviceToHost, st));
     const size_t nb = (size_t)B * T_STEPS * 2 * H * sizeof(float);
     if (enc_out) PV_HIP(hipMemcpyAsync(enc_out, enc, nb, hipMemcpyDeviceToHost, st));
@@ -625,3 +919,14 @@ extern "C" int pv_rnn_forward_p1(pv_ctx* ctx, const int8_t* images, int64_t B, f
 }
 
 // ---- P2 (bi-GRU polisher model): see rnn_gru.hip ----------------------------------------------------
+
+#ifdef PV_STAMPS
+// diagnostic builds only: copy the phase stamps of the last staggered-decoder launch to the host
+extern "C" int pv_debug_read_stamps(pv_ctx* ctx, unsigned long long* out, int64_t n) {
+    unsigned long long* sp = nullptr;
+    if (pv_get(ctx, "p1.stamps", (size_t)n, &sp)) return PV_ERR_HIP;
+    PV_HIP(hipDeviceSynchronize());
+    PV_HIP(hipMemcpy(out, sp, (size_t)n * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    return PV_OK;
+}
+#endif
