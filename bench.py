@@ -192,6 +192,10 @@ def main():
     torch.cuda.synchronize()
     state = {"n": 0}
 
+    overlap = os.environ.get("PV_BENCH_OVERLAP", "1") != "0"
+    if not overlap:
+        s_build = s_rnn  # one stream: builder and RNN of a group run back to back
+
     def group(g):
         k = state["n"] & 1
         if state["n"] >= 2:

@@ -43,3 +43,22 @@ def test_make_images_then_run_inference(hip_ctx, oracle_lib, tmp_path):
     ref = rnn_oracle.p1_forward(w, exp.images, np.float64)
     np.testing.assert_allclose(probs, ref, atol=1e-4, rtol=0)
     assert probs.dtype == np.float64
+
+
+def test_identical_call_decisions(hip_ctx):
+    """north_star: 'identical candidate-variant calls'. The consumer's hard decisions (genotype argmax, p-value
+    thresholds, integer phred cut-offs) computed from the GPU probabilities equal those computed from the
+    float64 oracle, except possibly for windows within the 1e-4 tolerance of a decision edge."""
+    from oracle import rnn_oracle
+    from pepper_thesis_amd import calls
+    w = synth.make_weights_p1(21, 3.0)  # sharp head: probabilities spread over (0,1)
+    hip_ctx.load_p1(w)
+    x = synth.synth_windows(22, 1024)
+    cands = ["%d%s" % (1 + i % 3, "ACGT"[i % 4]) for i in range(len(x))]
+    got = hip_ctx.forward_p1(x)
+    ref = rnn_oracle.p1_forward(w, x, np.float64)
+    r = calls.compare(got, ref, cands, tol=1e-4)
+    assert r["mismatches_off_edge"] == 0, r
+    assert r["mismatches"] <= 0.01 * r["n"], r
+    sig = calls.decision_signature(ref, cands)
+    assert len(set(sig[:, 0].tolist())) >= 2  # the test is not degenerate: more than one genotype occurs
