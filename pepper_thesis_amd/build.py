@@ -23,7 +23,23 @@ def _stale(target, deps):
     return any(os.path.getmtime(d) > t for d in deps)
 
 
+IO_LIB = os.path.join(CSRC, "libpepper_io.so")
+
+
+def build_io(force=False, verbose=False):
+    """libpepper_io.so: native BAM/BAI + FASTA/FAI readers (host C++, zlib only)"""
+    src = os.path.join(CSRC, "pv_io.cpp")
+    hdr = os.path.normpath(os.path.join(CSRC, "..", "..", "include", "pepper_io.h"))
+    if force or _stale(IO_LIB, [src, hdr]):
+        cmd = [os.environ.get("CXX", "g++"), "-std=c++17", "-O2", "-fPIC", "-shared", "-Wall", "-o", IO_LIB, src, "-lz"]
+        if verbose:
+            print(" ".join(cmd), file=sys.stderr)
+        subprocess.check_call(cmd)
+    return IO_LIB
+
+
 def build(force=False, verbose=False):
+    build_io(force, verbose)
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     if not os.path.exists(hipcc):
         hipcc = "hipcc"

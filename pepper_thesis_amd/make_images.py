@@ -60,3 +60,89 @@ def write_image_file(ctx, path: str, batch: RegionBatch, intervals: Sequence[Tup
             store.write_summary("%s_%d_%d" % (contig, start, end), [contig] * sel.size, out.position[sel], out.depth[sel],
                                 [[out.candidates[i]] for i in sel], out.cand_freq[sel].reshape(-1, 1), out.images[sel])
     return len(out)
+
+
+# ---- `make_images` from BAM + FASTA (native readers) ---------------------------------------------------
+
+def parse_region(region: str):
+    """'chr20', 'chr20:1000-2000' (ImageGenerationUI.py:138-151) -> (contig, start|None, end|None)"""
+    if ":" not in region:
+        return region, None, None
+    contig, span = region.split(":")
+    a, b = span.replace(",", "").split("-")
+    return contig, int(a), int(b)
+
+
+def generate_images(ctx, bam_path: str, fasta_path: str, output_dir: str, params: Params, region: str = None,
+                    region_size: int = 100_000, min_mapq: int = 5, include_supplementary: bool = False,
+                    downsample_rate: float = 1.0, intervals_per_call: int = 8, rank: int = 0, world: int = 1) -> int:
+    """generate_images (ImageGenerationUI.py:277-345) on the MI355X path: intervals of region_size, interval i handled
+    by rank i % world (:211), `intervals_per_call` intervals per builder launch chain, one HDF5 file per rank."""
+    import os
+    from .bamio import BamHandler, FastaHandler, region_from_files
+    from .batch import pack_regions
+    from .hdf5io import ImageStore
+    bam, fasta = BamHandler(bam_path), FastaHandler(fasta_path)
+    if region:
+        todo = []
+        for part in region.split(","):
+            contig, a, b = parse_region(part)
+            if a is None:
+                a, b = 0, fasta.get_chromosome_sequence_length(contig)
+            todo += split_intervals(contig, a, b, region_size)
+    else:
+        names = [n for n in fasta.get_chromosome_names() if n in set(bam.get_chromosome_sequence_names())]
+        todo = [iv for n in names for iv in split_intervals(n, 0, fasta.get_chromosome_sequence_length(n), region_size)]
+    mine = [iv for i, iv in enumerate(todo) if i % world == rank]
+    os.makedirs(output_dir, exist_ok=True)
+    n_windows = 0
+    with ImageStore(os.path.join(output_dir, "pepper_variants_images_thread_%d.hdf5" % rank), "w") as store:
+        for k in range(0, len(mine), intervals_per_call):
+            ivs = mine[k:k + intervals_per_call]
+            regs = [region_from_files(bam, fasta, c, a, b, min_mapq, include_supplementary, downsample_rate) for c, a, b in ivs]
+            keep = [i for i, r in enumerate(regs) if r.reads]  # "no group when no reads" (AlignmentSummarizer.py:212-213)
+            if not keep:
+                continue
+            out = ctx.summarize(pack_regions([regs[i] for i in keep]), params)
+            for g, i in enumerate(keep):
+                contig, start, end = ivs[i]
+                sel = np.flatnonzero(out.region == g)
+                if sel.size == 0:
+                    continue
+                store.write_summary("%s_%d_%d" % (contig, start, end), [contig] * sel.size, out.position[sel], out.depth[sel],
+                                    [[out.candidates[j]] for j in sel], out.cand_freq[sel].reshape(-1, 1), out.images[sel])
+            n_windows += len(out)
+    return n_windows
+
+
+def main(argv=None):
+    import argparse
+    import os
+    from .batch import PRESETS
+    from .runtime import Context
+    ap = argparse.ArgumentParser(prog="make_images")
+    ap.add_argument("-b", "--bam", required=True)
+    ap.add_argument("-f", "--fasta", required=True)
+    ap.add_argument("-o", "--output_dir", required=True)
+    ap.add_argument("-r", "--region", default=None)
+    ap.add_argument("--region_size", type=int, default=100_000)
+    ap.add_argument("-d", "--downsample_rate", type=float, default=1.0)
+    ap.add_argument("--include_supplementary", action="store_true")
+    ap.add_argument("--min_mapq", type=int, default=5)
+    ap.add_argument("-t", "--threads", type=int, default=1)
+    g = ap.add_mutually_exclusive_group(required=True)
+    for name in PRESETS:
+        g.add_argument("--" + name, action="store_true")
+    args = ap.parse_args(argv)
+    preset = next(n for n in PRESETS if getattr(args, n))
+    rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+    ctx = Context(int(os.environ.get("LOCAL_RANK", "0")))
+    n = generate_images(ctx, args.bam, args.fasta, args.output_dir, PRESETS[preset], args.region, args.region_size,
+                        args.min_mapq, args.include_supplementary, args.downsample_rate, rank=rank, world=world)
+    ctx.close()
+    import sys
+    sys.stderr.write("INFO: FINISHED IMAGE GENERATION: %d WINDOWS\n" % n)
+
+
+if __name__ == "__main__":
+    main()

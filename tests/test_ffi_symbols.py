@@ -48,3 +48,15 @@ def test_product_does_not_import_oracle():
             if f.endswith((".py", ".hip", ".hpp", ".cpp", ".h")):
                 text = open(os.path.join(dirpath, f), errors="ignore").read()
                 assert not pat.search(text), f
+
+
+def test_io_library_exports_its_header():
+    """include/pepper_io.h <-> libpepper_io.so"""
+    from pepper_thesis_amd import bamio
+    build.build_io()
+    lib_ = bamio.load()
+    hdr = open(os.path.join(ROOT, "include", "pepper_io.h")).read()
+    declared = set(re.findall(r"\b(pvio_[a-z0-9_]+)\s*\(", hdr))
+    assert declared == {n for n, _, _ in bamio.IO_SYMBOLS}
+    for n in declared:
+        assert hasattr(lib_, n)

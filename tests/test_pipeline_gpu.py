@@ -62,3 +62,53 @@ def test_identical_call_decisions(hip_ctx):
     assert r["mismatches"] <= 0.01 * r["n"], r
     sig = calls.decision_signature(ref, cands)
     assert len(set(sig[:, 0].tolist())) >= 2  # the test is not degenerate: more than one genotype occurs
+
+
+def test_bam_to_predictions_end_to_end(hip_ctx, oracle_lib, tmp_path):
+    """BAM + FASTA -> make_images (native readers + HIP builder) -> run_inference (HIP RNN) -> prediction HDF5;
+    the windows equal the oracle's on the same clipped reads"""
+    import bam_writer as bw
+    from pepper_thesis_amd import bamio, build
+    build.build_io()
+    rng = np.random.default_rng(11)
+    ref = "".join(rng.choice(list("ACGT"), size=60_000))
+    bw.write_fasta(str(tmp_path / "ref.fa"), [("chr20", ref)])
+    recs = bw.random_records(rng, 600, 60_000, tid=0, mean_len=2500, allow_skip=False)
+    # read bases follow the reference with a few mismatches so that real candidate sites appear
+    for r in recs:
+        seq, qi, rp = list(r["seq"]), 0, r["pos"]
+        for op, ln in r["cigar"]:
+            if op in (0, 7, 8):
+                for i in range(ln):
+                    if rp + i < len(ref) and rng.random() > 0.04:
+                        seq[qi + i] = ref[rp + i]
+                qi += ln; rp += ln
+            elif op in (1, 4):
+                qi += ln
+            elif op in (2, 3):
+                rp += ln
+        r["seq"] = "".join(seq)
+        r["mapq"] = 60
+        r["flag"] &= 0x10
+    bw.write_bam(str(tmp_path / "reads.bam"), [("chr20", len(ref))], recs)
+    P = PRESETS["ont_r9_guppy5_sup"]
+    n = make_images.generate_images(hip_ctx, str(tmp_path / "reads.bam"), str(tmp_path / "ref.fa"), str(tmp_path / "images"), P,
+                                    region="chr20:5000-45000", region_size=10_000, intervals_per_call=3)
+    # expected: the same intervals through the oracle
+    b, f = bamio.BamHandler(str(tmp_path / "reads.bam")), bamio.FastaHandler(str(tmp_path / "ref.fa"))
+    ivs = make_images.split_intervals("chr20", 5000, 45000, 10_000)
+    assert ivs == [("chr20", 5000, 15000), ("chr20", 15000, 25000), ("chr20", 25000, 35000), ("chr20", 35000, 45000)]
+    exp = oracle_lib.summarize(pack_regions([bamio.region_from_files(b, f, c, a, e) for c, a, e in ivs]), P)
+    assert n == len(exp) > 100
+    with hdf5io.ImageStore(str(tmp_path / "images" / "pepper_variants_images_thread_0.hdf5"), "r") as st:
+        names = st.summaries()
+        parts = {nm: st.read_summary(nm) for nm in names}
+    assert sorted(names) == sorted("%s_%d_%d" % iv for iv in ivs)
+    got_imgs = np.concatenate([parts["%s_%d_%d" % iv]["images"] for iv in ivs])
+    np.testing.assert_array_equal(got_imgs, exp.images)
+    w = synth.make_weights_p1(3, 2.0)
+    np.savez(str(tmp_path / "model.npz"), **w)
+    run_inference.main(["-i", str(tmp_path / "images"), "-m", str(tmp_path / "model.npz"), "-o", str(tmp_path / "pred")])
+    with hdf5io.PredictionStore(str(tmp_path / "pred" / "pepper_prediction.hdf"), "r") as st:
+        total = sum(bt["base_prediction"].shape[0] for _, bt in st.batches())
+    assert total == n
