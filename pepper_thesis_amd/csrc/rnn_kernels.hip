@@ -27,6 +27,8 @@ namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 
 constexpr int T_STEPS = 33;
 constexpr int F_IN = 26;
@@ -99,6 +101,8 @@ struct LstmArgs {
     const float* wp;      // packed [2 dirs][NW waves][nkb][32/NW tiles][64][4]
     const float* bias;    // [2][1024] b_ih + b_hh
     float* out;           // [B,33,512]
+    float* out_cm;        // optional chunk-major copy [512/32][Bp*33][32] (A operand of the bf16x3 decoder GEMM)
+    int64_t cm_rows;      // Bp*33
     float* out_packed;    // optional [n_tiles][33][64 kb][64 lanes][4]: A-fragment order of the next layer's x operand
     int64_t B;
     int n_tiles;
@@ -349,8 +353,13 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void k_lstm_layer(LstmArgs a) {
                     float* pk = a.out_packed + ((size_t)tile * T_STEPS + t) * 64 * 256;
                     pk[(col >> 3) * 256 + ((((col >> 2) & 1) * 32 + row) << 2) + (col & 3)] = h;
                 } else {
-                    float* ob = a.out + ((size_t)b0 * T_STEPS + t) * (2 * H) + dir * H;
-                    ob[(unsigned)row * (T_STEPS * 2 * H) + (unsigned)unit] = h;
+                    const size_t obase = ((size_t)b0 * T_STEPS + t) * (2 * H) + dir * H;
+                    const unsigned ooff = (unsigned)row * (T_STEPS * 2 * H) + (unsigned)unit;
+                    (a.out + obase)[ooff] = h;
+                    if (a.out_cm) {
+                        const unsigned col = dir * H + unit;
+                        a.out_cm[((size_t)(col >> 5) * a.cm_rows + (size_t)(b0 + row) * T_STEPS + t) * 32 + (col & 31)] = h;
+                    }
                 }
             }
         }
@@ -589,8 +598,9 @@ __global__ __launch_bounds__(256, 1) void k_head_splitk(HeadArgs a) {
 }
 
 struct TailArgs {
-    const float* part;   // [splits][B][512]
+    const float* part;   // [splits][part_rows][512]
     int splits;
+    int64_t part_rows;   // rows per slab (B, or the tile-padded batch in bf16 mode)
     const float* b1;     // [512]
     const float* wp[4];  // packed linear_2..5 [4 waves][64 kb][4][64][4]
     const float* b[4];   // [512]
@@ -615,7 +625,7 @@ __global__ __launch_bounds__(256, 1) void k_head_tail(TailArgs a) {
         if (b >= a.B) b = a.B - 1;
         float v = a.b1[n];
 #pragma unroll 11
-        for (int s = 0; s < a.splits; s++) v += a.part[((size_t)s * a.B + b) * HEAD_N + n];
+        for (int s = 0; s < a.splits; s++) v += a.part[((size_t)s * a.part_rows + b) * HEAD_N + n];
         y0[row * LDY + n] = seluf_(v);
     }
     __syncthreads();
@@ -670,6 +680,195 @@ __global__ __launch_bounds__(256, 1) void k_head_tail(TailArgs a) {
     }
 }
 
+// ---- PV_DTYPE_BF16_INPUT_GEMM: the non-recurrent products on the bf16 MFMA with a 3-term split ------------------
+// x = x_hi + x_lo, w = w_hi + w_lo (bf16 each); x.w ~= x_hi.w_hi + x_hi.w_lo + x_lo.w_hi, accumulated in fp32: relative
+// error ~2^-17 per term (the dropped lo.lo term), i.e. fp32-class results (softmax error ~7e-6 measured) at 3/16 of the
+// f32-MFMA cost. Plain bf16 operands miss the 1e-4 bar (3.5e-3). Used for the decoder input projection
+// G[b,t,:] = W_ih . enc_out[b,t,:] + b (both directions, N = 2048, K = 512) and for linear_1 (N = 512, K = 16896);
+// the recurrent h-part, the cell update and linear_2..5 stay fp32.
+struct GemmArgs {
+    const float* Ac;      // activations fp32, CHUNK-MAJOR [K/32][M][32]: one BK slice of a row tile is 16 KB contiguous
+    const __bf16* Wh;     // weights bf16 hi, chunk-major [K/32][N][32]
+    const __bf16* Wl;     // weights bf16 lo, chunk-major
+    const float* bias;    // [N] or NULL
+    float* C;             // [splits][M, N]
+    int64_t M;
+    int N, K, splits;
+};
+
+// C tile 128 x 128 per workgroup (4 waves as 2 x 2, 64 x 64 each), BK = 32, double-buffered LDS, register staging.
+__global__ __launch_bounds__(256, 2) void k_gemm_bf16x3(GemmArgs g) {
+    constexpr int BM = 128, BN = 128, BK = 32, LD = 40;  // LD: bf16 elements per LDS row (80 B: conflict-free b128 reads)
+    extern __shared__ __bf16 sm16[];
+    __bf16* sAh = sm16;                    // [2][BM*LD]
+    __bf16* sAl = sAh + 2 * BM * LD;
+    __bf16* sBh = sAl + 2 * BM * LD;       // [2][BN*LD]
+    __bf16* sBl = sBh + 2 * BN * LD;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, wr = wv >> 1, wc = wv & 1;
+    const int n_tiles_n = g.N / BN;
+    const int64_t mt = blockIdx.x / n_tiles_n;
+    const int nt_ = blockIdx.x - (int)(mt * n_tiles_n);
+    const int64_t m0 = mt * BM;
+    const int n0 = nt_ * BN;
+    const int kslice = g.K / g.splits;
+    const int kbeg = blockIdx.y * kslice;
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; a++)
+#pragma unroll
+        for (int b = 0; b < 2; b++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[a][b][r] = 0.0f;
+    f32x4 ra[4];  // 16 fp32 activations
+    f32x4 rb[4];  // 4 x 8 bf16 weights (hi, hi, lo, lo segments)
+    auto g_load = [&](int k0) {
+        const int kc = k0 >> 5;
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int idx = tid + u * 256, row = idx >> 3, c4 = idx & 7;
+            int64_t m = m0 + row;
+            if (m >= g.M) m = g.M - 1;
+            ra[u] = *reinterpret_cast<const f32x4*>(g.Ac + ((size_t)kc * g.M + m) * 32 + c4 * 4);
+            const int arr = idx >> 9, sidx = idx & 511, brow = sidx >> 2, c8 = sidx & 3;
+            rb[u] = *reinterpret_cast<const f32x4*>((arr ? g.Wl : g.Wh) + ((size_t)kc * g.N + n0 + brow) * 32 + c8 * 8);
+        }
+    };
+    auto s_store = [&](int buf) {
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int idx = tid + u * 256, row = idx >> 3, c4 = idx & 7;
+            bf16x4 hi, lo;
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                hi[j] = (__bf16)ra[u][j];
+                lo[j] = (__bf16)(ra[u][j] - (float)hi[j]);
+            }
+            *reinterpret_cast<bf16x4*>(sAh + buf * BM * LD + row * LD + c4 * 4) = hi;
+            *reinterpret_cast<bf16x4*>(sAl + buf * BM * LD + row * LD + c4 * 4) = lo;
+            const int arr = idx >> 9, sidx = idx & 511, brow = sidx >> 2, c8 = sidx & 3;
+            *reinterpret_cast<f32x4*>((arr ? sBl : sBh) + buf * BN * LD + brow * LD + c8 * 8) = rb[u];
+        }
+    };
+    const int nk = kslice / BK;
+    g_load(kbeg);
+    s_store(0);
+    __syncthreads();
+    for (int kt = 0; kt < nk; kt++) {
+        const int buf = kt & 1;
+        if (kt + 1 < nk) g_load(kbeg + (kt + 1) * BK);
+        const __bf16* pAh = sAh + buf * BM * LD + (wr * 64 + (lane & 31)) * LD + 8 * (lane >> 5);
+        const __bf16* pAl = sAl + buf * BM * LD + (wr * 64 + (lane & 31)) * LD + 8 * (lane >> 5);
+        const __bf16* pBh = sBh + buf * BN * LD + (wc * 64 + (lane & 31)) * LD + 8 * (lane >> 5);
+        const __bf16* pBl = sBl + buf * BN * LD + (wc * 64 + (lane & 31)) * LD + 8 * (lane >> 5);
+#pragma unroll
+        for (int ks = 0; ks < 2; ks++) {
+            bf16x8 ah[2], al[2], bh[2], bl[2];
+#pragma unroll
+            for (int q = 0; q < 2; q++) {
+                ah[q] = *reinterpret_cast<const bf16x8*>(pAh + q * 32 * LD + ks * 16);
+                al[q] = *reinterpret_cast<const bf16x8*>(pAl + q * 32 * LD + ks * 16);
+                bh[q] = *reinterpret_cast<const bf16x8*>(pBh + q * 32 * LD + ks * 16);
+                bl[q] = *reinterpret_cast<const bf16x8*>(pBl + q * 32 * LD + ks * 16);
+            }
+#pragma unroll
+            for (int a = 0; a < 2; a++)
+#pragma unroll
+                for (int b = 0; b < 2; b++) {
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[a], bh[b], acc[a][b], 0, 0, 0);
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[a], bl[b], acc[a][b], 0, 0, 0);
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[a], bh[b], acc[a][b], 0, 0, 0);
+                }
+        }
+        if (kt + 1 < nk) s_store(buf ^ 1);
+        __syncthreads();
+    }
+    float* C = g.C + (size_t)blockIdx.y * g.M * g.N;
+#pragma unroll
+    for (int a = 0; a < 2; a++)
+#pragma unroll
+        for (int b = 0; b < 2; b++) {
+            const int n = n0 + wc * 64 + b * 32 + (lane & 31);
+            const float bv = g.bias ? g.bias[n] : 0.0f;
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int64_t m = m0 + wr * 64 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                if (m < g.M) C[m * g.N + n] = acc[a][b][r] + bv;
+            }
+        }
+}
+
+// decoder recurrence on pre-computed input projections G (fp32 [Bp*33, 2048], bias included): per step only the
+// h part runs on the f32 MFMA; G is fetched into registers at the start of the step and added in the cell update.
+struct RecArgs {
+    const float* G;       // [Bp, 33, 2][1024]  (row (b,t), columns dir*1024 + gate*256 + unit)
+    const float* wp;      // packed decoder weights [2 dirs][8 waves][96 kb][4][64][4] (the h part starts at k-block 64)
+    float* out;           // [Bp, 33, 512]
+    float* out_cm;        // chunk-major copy [16896/32][Bp][32] (A operand of the linear_1 GEMM)
+    int64_t cm_rows;      // Bp
+    int n_tiles;
+};
+
+__global__ __launch_bounds__(512, 2) void k_lstm_rec_g(RecArgs a) {
+    constexpr int LDH = H + 4, NKB_X = 64, NKB_H = H / 8, NT = 4, UW = 32;
+    extern __shared__ float smem[];
+    float* hbuf = smem;  // [2][32][LDH]
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int xcd = blockIdx.x & 7;
+    const int dir = xcd & 1;
+    const int tile = (blockIdx.x >> 3) * 4 + (xcd >> 1);
+    if (tile >= a.n_tiles) return;
+    const int64_t b0 = (int64_t)tile * ROWS;
+    const float* wph = a.wp + ((size_t)(dir * 8 + wv) * (NKB_X + NKB_H) + NKB_X) * NT * 256;
+    for (int i = tid; i < 2 * ROWS * LDH; i += 512) hbuf[i] = 0.0f;
+    f32x16 cst;
+#pragma unroll
+    for (int r = 0; r < 16; r++) cst[r] = 0.0f;
+    f32x4 bres[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; nt++) bres[nt] = reinterpret_cast<const f32x4*>(wph)[nt * 64 + lane];
+    const int unit = UW * wv + (lane & 31);
+    __syncthreads();
+    for (int s = 0; s < T_STEPS; s++) {
+        const int t = dir ? (T_STEPS - 1 - s) : s;
+        const int cur = s & 1, nxt = cur ^ 1;
+        // input projections of this step: 64 values per lane, in flight during the h-part MFMAs
+        const float* gb = a.G + ((size_t)b0 * T_STEPS + t) * 2048 + dir * 1024 + unit;
+        float gx[NT][16];
+#pragma unroll
+        for (int nt = 0; nt < NT; nt++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const unsigned row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                gx[nt][r] = gb[row * (unsigned)(T_STEPS * 2048) + nt * H];
+            }
+        f32x16 acc[NT];
+#pragma unroll
+        for (int nt = 0; nt < NT; nt++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[nt][r] = 0.0f;
+        mma_dual<NT>(acc, hbuf + cur * ROWS * LDH, LDH, NKB_H, hbuf, LDH, 0, wph, bres, lane);
+        float* hn = hbuf + nxt * ROWS * LDH;
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const float ig = sigmoidf_(acc[0][r] + gx[0][r]);
+            const float fg = sigmoidf_(acc[1][r] + gx[1][r]);
+            const float gg = tanhf_(acc[2][r] + gx[2][r]);
+            const float og = sigmoidf_(acc[3][r] + gx[3][r]);
+            const float c = fg * cst[r] + ig * gg;
+            cst[r] = c;
+            const float h = og * tanhf_(c);
+            const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            hn[row * LDH + unit] = h;
+            const size_t obase = ((size_t)b0 * T_STEPS + t) * (2 * H) + dir * H;
+            const unsigned ooff = (unsigned)row * (T_STEPS * 2 * H) + (unsigned)unit;
+            (a.out + obase)[ooff] = h;
+            const unsigned col = t * (2 * H) + dir * H + unit;  // flattened [t][512] index = K index of linear_1
+            a.out_cm[((size_t)(col >> 5) * a.cm_rows + (size_t)(b0 + row)) * 32 + (col & 31)] = h;
+        }
+        __syncthreads();
+    }
+}
+
 // ---- host-side weight packing -----------------------------------------------------------------------
 // LSTM layer, NW waves per workgroup: NT = 32/NW tiles per wave, S2 = NT/4 sub-tiles;
 // gate column of (wave w, tile nt, lane) = (nt/S2)*H + (H/NW)*w + 32*(nt%S2) + (lane&31)
@@ -714,6 +913,7 @@ static void pack_linear(const float* W, int K, std::vector<float>& wp) {
 static constexpr size_t LDS_ENC = (size_t)(ROWS * (32 + 4) + 2 * ROWS * (H + 4)) * sizeof(float);
 static constexpr size_t LDS_DEC = (size_t)(ROWS * (2 * H + 4) + 2 * ROWS * (H + 4)) * sizeof(float);
 static constexpr size_t LDS_DEC_STAGGER = (size_t)(2 * ROWS * (H + 4)) * sizeof(float);
+static constexpr size_t LDS_GEMM = (size_t)4 * 2 * 128 * 40 * 2;  // 4 operand arrays x 2 buffers x 128 rows x 40 bf16
 static constexpr size_t LDS_SPLITK = (size_t)ROWS * (2 * H + 4) * sizeof(float);
 static constexpr size_t LDS_TAIL = (size_t)2 * ROWS * (HEAD_N + 4) * sizeof(float);
 
@@ -725,11 +925,45 @@ struct pv_rnn_p1 {
     float* bl[4] = {nullptr, nullptr, nullptr, nullptr};
     float* wo = nullptr; float* bo = nullptr;
     int dtype = PV_DTYPE_F32;
+    // PV_DTYPE_BF16_INPUT_GEMM: bf16 hi/lo splits of the decoder W_ih (both directions, [2048,512]) and linear_1 ([512,16896])
+    __bf16* dec_wih_h = nullptr; __bf16* dec_wih_l = nullptr; float* dec_bias_cat = nullptr;
+    __bf16* w1_h = nullptr; __bf16* w1_l = nullptr;
     int nw = 8;  // waves per LSTM workgroup (PV_LSTM_WAVES=4|8)
     int dec_stagger = -1;  // PV_DEC_STAGGER: -1 (default) = barrier decoder k_lstm_layer<512>; >= 0 = experimental flag-synchronised
                            // decoder k_lstm_dec_stagger with that many sleep units of stagger (measured slower: DESIGN.md section 6)
     std::vector<void*> owned;
 };
+
+static inline uint16_t f2bf_bits(float x) {  // round to nearest even
+    uint32_t u;
+    memcpy(&u, &x, 4);
+    return (uint16_t)((u + 0x7FFFu + ((u >> 16) & 1u)) >> 16);
+}
+static inline float bf_bits2f(uint16_t h) {
+    const uint32_t u = (uint32_t)h << 16;
+    float f;
+    memcpy(&f, &u, 4);
+    return f;
+}
+// w [N, K] row-major -> (hi, lo) bf16 with w ~= hi + lo, stored chunk-major [K/32][N][32]
+static int dev_upload_split(const float* w, size_t N, size_t K, __bf16** d_hi, __bf16** d_lo, std::vector<void*>& owned) {
+    const size_t n = N * K;
+    std::vector<uint16_t> hi(n), lo(n);
+    for (size_t r = 0; r < N; r++)
+        for (size_t k = 0; k < K; k++) {
+            const float v = w[r * K + k];
+            const size_t o = ((k >> 5) * N + r) * 32 + (k & 31);
+            hi[o] = f2bf_bits(v);
+            lo[o] = f2bf_bits(v - bf_bits2f(hi[o]));
+        }
+    PV_HIP(hipMalloc((void**)d_hi, n * 2));
+    owned.push_back(*d_hi);
+    PV_HIP(hipMalloc((void**)d_lo, n * 2));
+    owned.push_back(*d_lo);
+    PV_HIP(hipMemcpy(*d_hi, hi.data(), n * 2, hipMemcpyHostToDevice));
+    PV_HIP(hipMemcpy(*d_lo, lo.data(), n * 2, hipMemcpyHostToDevice));
+    return PV_OK;
+}
 
 static int dev_upload(const std::vector<float>& h, float** d, std::vector<void*>& owned) {
     PV_HIP(hipMalloc((void**)d, h.size() * sizeof(float)));
@@ -755,7 +989,7 @@ void pv_rnn_free(pv_ctx* ctx) {
 
 extern "C" int pv_rnn_load_p1(pv_ctx* ctx, const pv_weights_p1* w, int dtype) {
     PV_CHECK(ctx && w, PV_ERR_INVALID, "null argument");
-    PV_CHECK(dtype == PV_DTYPE_F32, PV_ERR_INVALID, "dtype %d not implemented (only PV_DTYPE_F32)", dtype);
+    PV_CHECK(dtype == PV_DTYPE_F32 || dtype == PV_DTYPE_BF16_INPUT_GEMM, PV_ERR_INVALID, "unknown dtype %d", dtype);
     for (int d = 0; d < 2; d++) {
         PV_CHECK(w->encoder[d].w_ih && w->encoder[d].w_hh && w->encoder[d].b_ih && w->encoder[d].b_hh &&
                      w->decoder[d].w_ih && w->decoder[d].w_hh && w->decoder[d].b_ih && w->decoder[d].b_hh,
@@ -790,6 +1024,18 @@ extern "C" int pv_rnn_load_p1(pv_ctx* ctx, const pv_weights_p1* w, int dtype) {
             return rc;
     }
     if ((rc = dev_upload(w->out_w, 3 * HEAD_N, &m->wo, m->owned)) || (rc = dev_upload(w->out_b, 3, &m->bo, m->owned))) return rc;
+    if (dtype == PV_DTYPE_BF16_INPUT_GEMM) {
+        std::vector<float> wcat((size_t)2048 * 512), bcat(2048);
+        for (int d = 0; d < 2; d++) {
+            memcpy(&wcat[(size_t)d * 1024 * 512], w->decoder[d].w_ih, (size_t)1024 * 512 * sizeof(float));
+            for (int n = 0; n < 1024; n++) bcat[d * 1024 + n] = w->decoder[d].b_ih[n] + w->decoder[d].b_hh[n];
+        }
+        if ((rc = dev_upload_split(wcat.data(), 2048, 512, &m->dec_wih_h, &m->dec_wih_l, m->owned))) return rc;
+        if ((rc = dev_upload(bcat, &m->dec_bias_cat, m->owned))) return rc;
+        if ((rc = dev_upload_split(w->linear_w[0], HEAD_N, HEAD_K, &m->w1_h, &m->w1_l, m->owned))) return rc;
+        PV_HIP(hipFuncSetAttribute((const void*)k_gemm_bf16x3, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_GEMM));
+        PV_HIP(hipFuncSetAttribute((const void*)k_lstm_rec_g, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_DEC_STAGGER));
+    }
     // opt in to > 64 KB of dynamic LDS (exact sizes; static LDS counts against the 160 KB too)
     PV_HIP(hipFuncSetAttribute((const void*)k_lstm_layer<32, true, 4, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_ENC));
     PV_HIP(hipFuncSetAttribute((const void*)k_lstm_layer<512, false, 4, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_DEC));
@@ -810,14 +1056,60 @@ static int p1_forward_launch(pv_ctx* ctx, const int8_t* d_images, int64_t B, flo
     LstmArgs e;
     e.ablate = getenv("PV_ABLATE") ? atoi(getenv("PV_ABLATE")) : 0;
     e.stamps = nullptr;
-    const bool stag = m->dec_stagger >= 0 && enc_packed != nullptr;
+    const bool stag = m->dec_stagger >= 0 && enc_packed != nullptr && m->dtype == PV_DTYPE_F32;
     e.x_i8 = d_images; e.x_f32 = nullptr; e.wp = m->enc_wp; e.bias = m->enc_bias; e.out = enc_out; e.B = B; e.n_tiles = n_tiles;
     e.out_packed = stag ? enc_packed : nullptr;
+    e.out_cm = nullptr; e.cm_rows = 0;
+    struct { float *enc_cm, *dec_cm; } bf = {nullptr, nullptr};
+    if (m->dtype == PV_DTYPE_BF16_INPUT_GEMM) {
+        const size_t nel = (size_t)n_tiles * ROWS * T_STEPS * 2 * H;
+        int rcb;
+        if ((rcb = pv_get(ctx, "p1.enc_cm", nel, &bf.enc_cm)) || (rcb = pv_get(ctx, "p1.dec_cm", nel, &bf.dec_cm))) return rcb;
+        e.out_cm = bf.enc_cm; e.cm_rows = (int64_t)n_tiles * ROWS * T_STEPS;
+    }
     {
         pv_prof_scope ps(ctx, "k_lstm_layer_enc", st);
         if (m->nw == 8 && stag) k_lstm_layer<32, true, 8, true><<<lstm_grid, 512, LDS_ENC, st>>>(e);
         else if (m->nw == 8) k_lstm_layer<32, true, 8, false><<<lstm_grid, 512, LDS_ENC, st>>>(e);
         else k_lstm_layer<32, true, 4, false><<<lstm_grid, 256, LDS_ENC, st>>>(e);
+    }
+    if (m->dtype == PV_DTYPE_BF16_INPUT_GEMM) {
+        // decoder: G = enc_out . W_ih^T + b on the bf16 MFMA (3-term split), then the fp32 recurrence on G
+        const int64_t Bp = (int64_t)n_tiles * ROWS, M = Bp * T_STEPS;
+        float* G = nullptr;
+        int rc2 = pv_get(ctx, "p1.G", (size_t)M * 2048, &G);
+        if (rc2) return rc2;
+        GemmArgs ga;
+        ga.Ac = bf.enc_cm; ga.Wh = m->dec_wih_h; ga.Wl = m->dec_wih_l; ga.bias = m->dec_bias_cat; ga.C = G;
+        ga.M = M; ga.N = 2048; ga.K = 2 * H; ga.splits = 1;
+        {
+            pv_prof_scope ps(ctx, "k_gemm_bf16x3_dec", st);
+            k_gemm_bf16x3<<<dim3((unsigned)(((M + 127) / 128) * (2048 / 128)), 1), 256, LDS_GEMM, st>>>(ga);
+        }
+        RecArgs ra;
+        ra.G = G; ra.wp = m->dec_wp; ra.out = dec_out; ra.out_cm = bf.dec_cm; ra.cm_rows = Bp; ra.n_tiles = n_tiles;
+        {
+            pv_prof_scope ps(ctx, "k_lstm_rec_g", st);
+            k_lstm_rec_g<<<lstm_grid, 512, LDS_DEC_STAGGER, st>>>(ra);
+        }
+        // linear_1 as a split-K bf16x3 GEMM into slabs [splits][Bp][512]
+        const int64_t mtiles = (Bp + 127) / 128;
+        int gs = 1;
+        while (gs < 8 && mtiles * 4 * gs < ctx->num_cu && (HEAD_K / 32) % (gs * 2) == 0) gs *= 2;
+        GemmArgs gl;
+        gl.Ac = bf.dec_cm; gl.Wh = m->w1_h; gl.Wl = m->w1_l; gl.bias = nullptr; gl.C = part;
+        gl.M = Bp; gl.N = HEAD_N; gl.K = HEAD_K; gl.splits = gs;
+        {
+            pv_prof_scope ps(ctx, "k_gemm_bf16x3_lin1", st);
+            k_gemm_bf16x3<<<dim3((unsigned)(mtiles * 4), (unsigned)gs), 256, LDS_GEMM, st>>>(gl);
+        }
+        TailArgs tb;
+        tb.part = part; tb.b1 = m->b1; tb.splits = gs; tb.part_rows = Bp;
+        for (int i = 0; i < 4; i++) { tb.wp[i] = m->wlp[i]; tb.b[i] = m->bl[i]; }
+        tb.wo = m->wo; tb.bo = m->bo; tb.probs = d_probs; tb.B = B;
+        { pv_prof_scope ps(ctx, "k_head_tail", st); k_head_tail<<<(unsigned)n_tiles, 256, LDS_TAIL, st>>>(tb); }
+        PV_HIP(hipGetLastError());
+        return PV_OK;
     }
     LstmArgs d = e;
     d.x_i8 = nullptr; d.x_f32 = enc_out; d.wp = m->dec_wp; d.bias = m->dec_bias; d.out = dec_out;
@@ -853,7 +1145,7 @@ static int p1_forward_launch(pv_ctx* ctx, const int8_t* d_images, int64_t B, flo
     h.dec = dec_out; h.w1p = m->w1p; h.part = part; h.B = B; h.n_tiles = n_tiles; h.splits = splits; h.steps_per_split = T_STEPS / splits;
     { pv_prof_scope ps(ctx, "k_head_splitk", st); k_head_splitk<<<(unsigned)(n_tiles * splits), 256, LDS_SPLITK, st>>>(h); }
     TailArgs t;
-    t.part = part; t.b1 = m->b1; t.splits = splits;
+    t.part = part; t.b1 = m->b1; t.splits = splits; t.part_rows = B;
     for (int i = 0; i < 4; i++) { t.wp[i] = m->wlp[i]; t.b[i] = m->bl[i]; }
     t.wo = m->wo; t.bo = m->bo; t.probs = d_probs; t.B = B;
     { pv_prof_scope ps(ctx, "k_head_tail", st); k_head_tail<<<(unsigned)n_tiles, 256, LDS_TAIL, st>>>(t); }
@@ -870,7 +1162,7 @@ static int p1_workspace(pv_ctx* ctx, int64_t B, float** enc, float** dec, float*
     const size_t Bp = (size_t)((B + ROWS - 1) / ROWS) * ROWS;  // LSTM kernels store whole 32-row tiles
     if ((rc = pv_get(ctx, "p1.enc_out", Bp * T_STEPS * 2 * H, enc))) return rc;
     if ((rc = pv_get(ctx, "p1.dec_out", Bp * T_STEPS * 2 * H, dec))) return rc;
-    if ((rc = pv_get(ctx, "p1.part", (size_t)HEAD_MAX_SPLITS * B * HEAD_N, part))) return rc;
+    if ((rc = pv_get(ctx, "p1.part", (size_t)HEAD_MAX_SPLITS * Bp * HEAD_N, part))) return rc;
     return PV_OK;
 }
 

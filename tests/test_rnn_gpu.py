@@ -141,3 +141,21 @@ def test_p2_single_window_operator(hip_ctx, gold):
         lgpu, hgpu = hip_ctx.forward_p2_window(x[:, i:i + 100], hgpu)
         np.testing.assert_allclose(lgpu, lg, atol=1e-4, rtol=0)
         np.testing.assert_allclose(hgpu, hid.transpose(1, 0, 2), atol=5e-5, rtol=0)
+
+
+# ---- PV_DTYPE_BF16_INPUT_GEMM (BASELINE configs[2]): 3-term bf16 split of the input projections -----------------
+@pytest.mark.parametrize("tag", ["p1", "p1sharp"])
+def test_p1_bf16_input_gemm_mode_meets_the_bar(gold, tag):
+    from pepper_thesis_amd import _ffi, runtime
+    ctx = runtime.Context(0)
+    w = synth.make_weights_p1(int(gold[tag + "/seed"][0]), float(gold[tag + "/gain"][0]))
+    ctx.load_p1(w, _ffi.PV_DTYPE_BF16_INPUT_GEMM)
+    probs = ctx.forward_p1(gold[tag + "/images"])
+    np.testing.assert_allclose(probs, gold[tag + "/probs"], atol=TOL_PROBS, rtol=0)
+    # ragged batch + decoder tap against the float64 oracle
+    x = synth.synth_windows(4, 200)
+    probs, _, dec = ctx.forward_p1(x, taps=True)
+    ref_p, _, ref_dec, _ = rnn_oracle.p1_forward(w, x[:48], np.float64, taps=True)
+    np.testing.assert_allclose(dec[:48], ref_dec, atol=1e-4, rtol=0)
+    np.testing.assert_allclose(probs[:48], ref_p, atol=TOL_PROBS, rtol=0)
+    ctx.close()

@@ -11,7 +11,7 @@ from pepper_thesis_amd import runtime, synth  # noqa: E402
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 iters = int(sys.argv[2]) if len(sys.argv) > 2 else 10
 ctx = runtime.Context(0)
-ctx.load_p1(synth.make_weights_p1(1234))
+ctx.load_p1(synth.make_weights_p1(1234), int(os.environ.get("PV_BENCH_DTYPE", "0")))
 x = torch.from_numpy(synth.synth_windows(1, B)).cuda()
 probs = torch.zeros((B, 3), dtype=torch.float32, device="cuda")
 for _ in range(3):
@@ -25,4 +25,4 @@ tot = 0.0
 for k, (ms, n) in prof.items():
     print("%-20s %8.3f ms" % (k, ms / n))
     tot += ms / n
-print("B=%d total %.3f ms -> %.0f windows/s (PV_LSTM_WAVES=%s)" % (B, tot, B / tot * 1e3, os.environ.get("PV_LSTM_WAVES", "8")))
+print("B=%d total %.3f ms -> %.0f windows/s (PV_LSTM_WAVES=%s)" % (B, tot, B / tot * 1e3, os.environ.get("PV_LSTM_WAVES", "8")) + " dtype=" + os.environ.get("PV_BENCH_DTYPE", "0"))
