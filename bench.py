@@ -105,6 +105,43 @@ def pmc_traffic():
     return out
 
 
+def bf16_secondary(device_id, weights, dbatch, P, dev, pad, groups=6):
+    """BASELINE configs[2] flavour: the same step (1 region + 512 windows, 8 fused per launch chain) with
+    PV_DTYPE_BF16_INPUT_GEMM: decoder input projection and linear_1 on the bf16 MFMA as a 3-term hi/lo split
+    (softmax still within 1e-4 of the reference), recurrence fp32. Not part of `value`."""
+    import torch
+    from pepper_thesis_amd import _ffi, runtime
+    from pepper_thesis_amd.device import DeviceOut
+    c2 = runtime.Context(device_id)
+    c2.load_p1(weights, _ffi.PV_DTYPE_BF16_INPUT_GEMM)
+    win = torch.from_numpy(pad).to(dev)
+    dout = DeviceOut(CALLERS * BATCH, CALLERS * BATCH * 16, dev, images=win)
+    probs = torch.zeros((CALLERS * BATCH, 3), dtype=torch.float32, device=dev)
+
+    def grp():
+        c2.summarize_dev(dbatch, P, dout)
+        c2.forward_p1_dev(win.data_ptr(), CALLERS * BATCH, probs.data_ptr())
+
+    grp()
+    c2.synchronize()
+    c2.profile_begin()
+    t0 = time.perf_counter()
+    for _ in range(groups):
+        grp()
+    c2.synchronize()
+    dt = time.perf_counter() - t0
+    prof = c2.profile_end()
+    c2.close()
+    gemm_ms = prof["k_gemm_bf16x3_dec"][0] / prof["k_gemm_bf16x3_dec"][1]
+    flop = 3 * 2.0 * (CALLERS * BATCH * 33) * 2048 * 512
+    return {"value": groups * CALLERS * BATCH / dt, "unit": "windows/s", "dtype": "bf16x3 input GEMMs + f32 recurrence",
+            "steps": groups * CALLERS, "ms_per_step": dt / (groups * CALLERS) * 1e3,
+            "input_gemm": {"kernel": "k_gemm_bf16x3 (decoder input projection, M=%d N=2048 K=512, 3 MFMA terms)" % (CALLERS * BATCH * 33),
+                           "launch_ms": gemm_ms, "achieved": flop / gemm_ms / 1e9, "peak": 2500.0, "unit": "TFLOP/s (bf16 MFMA)",
+                           "frac": flop / gemm_ms / 1e9 / 2500.0},
+            "kernel_ms": {k: v[0] / max(v[1], 1) for k, v in prof.items() if k.startswith("k_") and "summary" not in k}}
+
+
 def p2_secondary(ctx, dev):
     """secondary figures for the bi-GRU polisher plan (north_star's '1000 x 100 x feature' shape): the 19-window
     sliding loop over [B,1000,10] chunks at the SURVEY 8(d) batch (64 chunks), at 1000 chunks and at a
@@ -137,6 +174,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=8)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-p2", action="store_true", help="skip the secondary bi-GRU (P2) figures")
+    ap.add_argument("--no-bf16", action="store_true", help="skip the secondary configs[2] (bf16 input GEMM) figure")
     args = ap.parse_args()
 
     import torch
@@ -283,6 +321,11 @@ def main():
             "kernel_ms": {k: v[0] / max(v[1], 1) for k, v in prof.items()},
             "rnn_model_tflops": FLOP_PER_WINDOW * value / 1e12,
         }
+        if world == 1 and not args.no_bf16:
+            try:
+                out["config2_bf16_input_gemm"] = bf16_secondary(local_rank, weights, dbatch, P, dev, pad)
+            except Exception as e:
+                out["config2_bf16_input_gemm"] = {"error": repr(e)}
         if world == 1 and not args.no_p2:
             try:
                 out["p2_bigru"] = p2_secondary(ctx, dev)

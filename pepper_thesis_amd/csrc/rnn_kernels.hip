@@ -1056,6 +1056,12 @@ static int p1_forward_launch(pv_ctx* ctx, const int8_t* d_images, int64_t B, flo
     LstmArgs e;
     e.ablate = getenv("PV_ABLATE") ? atoi(getenv("PV_ABLATE")) : 0;
     e.stamps = nullptr;
+#ifdef PV_STAMPS
+    if (getenv("PV_STAMP_ENC")) {
+        unsigned long long* sp = nullptr;
+        if (pv_get(ctx, "p1.stamps", (size_t)lstm_grid * 8 * 4, &sp) == PV_OK) e.stamps = sp;
+    }
+#endif
     const bool stag = m->dec_stagger >= 0 && enc_packed != nullptr && m->dtype == PV_DTYPE_F32;
     e.x_i8 = d_images; e.x_f32 = nullptr; e.wp = m->enc_wp; e.bias = m->enc_bias; e.out = enc_out; e.B = B; e.n_tiles = n_tiles;
     e.out_packed = stag ? enc_packed : nullptr;
@@ -1112,12 +1118,13 @@ static int p1_forward_launch(pv_ctx* ctx, const int8_t* d_images, int64_t B, flo
         return PV_OK;
     }
     LstmArgs d = e;
+    d.stamps = nullptr;
     d.x_i8 = nullptr; d.x_f32 = enc_out; d.wp = m->dec_wp; d.bias = m->dec_bias; d.out = dec_out;
     d.out_packed = nullptr;
 #ifdef PV_STAMPS
     {
         unsigned long long* sp = nullptr;
-        if (pv_get(ctx, "p1.stamps", (size_t)lstm_grid * 8 * 4, &sp) == PV_OK) d.stamps = sp;
+        if (!getenv("PV_STAMP_ENC") && pv_get(ctx, "p1.stamps", (size_t)lstm_grid * 8 * 4, &sp) == PV_OK) d.stamps = sp;
     }
 #endif
     if (stag) {
