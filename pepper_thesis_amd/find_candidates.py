@@ -1,0 +1,289 @@
+"""`find_candidates`: prediction HDF files -> candidate selection -> VCF records.
+
+CPU-side consumer of the hot path, restated from the reference so that the pipeline BAM -> images ->
+predictions -> VCF runs end to end on this code base:
+  small_chunk_stitch        pepper_variant/modules/python/CandidateFinder.py:356-529
+  find_candidates (dedupe)  CandidateFinder.py:532-581
+  candidate_list_to_variant pepper_variant/modules/python/VcfWriter.py:48-138
+  write_vcf_records         VcfWriter.py:140-218   (header fields :220-289)
+The reference writes bgzipped + tabix-indexed VCFs through pysam; pysam/htslib are not available here, so
+the five files are written as plain-text `.vcf` with the same records, FILTER/FORMAT fields and file split
+(FULL, PEPPER, VARIANT_CALLING, *_SNPs, *_INDEL).
+Parity note: the reference module cannot be imported here (needs pysam/h5py/the pybind build) and ships no
+tests or fixtures for it: this restatement is pinned by nothing ("parity unpinned"); tests check its
+invariants and that GPU and oracle probabilities give identical records.
+"""
+import math
+import os
+from collections import defaultdict
+from dataclasses import dataclass
+from typing import Callable, Dict, Iterable, List, Tuple
+
+import numpy as np
+
+
+@dataclass
+class CandidateOptions:
+    """--ont_r9_guppy5_sup candidate-finding preset (SetParameters.py:39-66)"""
+    allowed_multiallelics: int = 4
+    snp_p_value: float = 0.1
+    insert_p_value: float = 0.1
+    delete_p_value: float = 0.1
+    snp_q_cutoff: int = 20
+    indel_q_cutoff: int = 15
+    report_snp_above_freq: float = 0
+    report_indel_above_freq: float = 0
+    snp_p_value_in_lc: float = 0.1
+    insert_p_value_in_lc: float = 0.15
+    delete_p_value_in_lc: float = 0.1
+    snp_q_cutoff_in_lc: int = 20
+    indel_q_cutoff_in_lc: int = 10
+
+
+def repeat_annotation(sequence: str, kmer_size: int) -> List[int]:
+    """CandidateFinder.py:277-297"""
+    max_observed_repeats = [1] * len(sequence)
+    for i in range(len(sequence) - (kmer_size - 1)):
+        kmer_count = 0
+        end_index = i + (kmer_size - 1)
+        for j in range(i, len(sequence), kmer_size):
+            if sequence[i:i + kmer_size] == sequence[j:j + kmer_size]:
+                kmer_count += 1
+            else:
+                break
+            end_index = j + kmer_size
+        for k in range(i, min(len(sequence), end_index)):
+            max_observed_repeats[k] = max(max_observed_repeats[k], kmer_count)
+    return max_observed_repeats
+
+
+def _valid(allele: str) -> bool:
+    return all(b in "ACGT" for b in allele)
+
+
+def select_candidates(records: Iterable[dict], get_ref: Callable[[str, int, int], str], opt: CandidateOptions):
+    """small_chunk_stitch for an iterable of prediction records
+    dict(contig, position, depth, candidates [str], candidate_frequency [int], prediction [3 floats]);
+    get_ref(contig, start, stop) = FASTA_handler.get_reference_sequence. -> list of DeepVariant-side tuples
+    (contig, start, end, ref_allele, alt_alleles, genotype, depth, supports, prediction_value, predictions,
+     non_alt_predictions, in_repeat)"""
+    selected = []
+    for c in records:
+        contig, pos = c["contig"], int(c["position"])
+        reference_base = get_ref(contig, pos, pos + 1).upper()
+        upstream = get_ref(contig, pos, pos + 10).upper()
+        downstream = get_ref(contig, max(0, pos - 10), pos).upper()
+        full = downstream + upstream
+        hp = repeat_annotation(full, 1)
+        pidx = len(downstream)
+        up_i, down_i = min(len(hp), pidx + 4), max(0, pidx - 5)
+        in_repeat = max(hp[down_i:up_i]) >= 5
+        if reference_base not in ("A", "C", "G", "T"):
+            continue
+        pred = np.asarray(c["prediction"], dtype=np.float64)
+        g = int(np.argmax(pred))
+        genotype = [0, 0] if g == 0 else ([0, 1] if g == 1 else [1, 1])
+        prediction_value = pred[g]
+        alt_alleles, supports, non_alt_predictions = [], [], []
+        reference_allele = reference_base
+        depth = int(c["depth"])
+        for alt_allele, freq in zip(c["candidates"], c["candidate_frequency"]):
+            alt_type, allele = alt_allele[0], alt_allele[1:]
+            if not _valid(allele):
+                continue
+            vaf = float(freq) / float(depth)
+            nap = max(pred[1], pred[2])
+            non_alt_predictions.append(nap)
+            if alt_type == "1":
+                if (not in_repeat and nap >= opt.snp_p_value) or (in_repeat and nap >= opt.snp_p_value_in_lc) or \
+                        (0 < opt.report_snp_above_freq <= vaf):
+                    alt_alleles.append(allele)
+                    supports.append(int(freq))
+            elif alt_type == "2":
+                if (not in_repeat and nap >= opt.insert_p_value) or (in_repeat and nap >= opt.insert_p_value_in_lc) or \
+                        (0 < opt.report_indel_above_freq <= vaf):
+                    alt_alleles.append(allele)
+                    supports.append(int(freq))
+            elif alt_type == "3":
+                if (not in_repeat and nap >= opt.delete_p_value) or (in_repeat and nap >= opt.delete_p_value_in_lc):
+                    alt_alleles.append(reference_allele)  # deletion: REF = anchor + deleted, ALT = previous REF
+                    reference_allele = allele
+                    supports.append(int(freq))
+                elif 0 < opt.report_indel_above_freq <= vaf:
+                    alt_alleles.append(allele)
+                    supports.append(int(freq))
+        if alt_alleles:
+            selected.append((contig, pos, pos + len(reference_allele), reference_allele, alt_alleles, genotype, depth,
+                             supports, prediction_value, pred, non_alt_predictions, in_repeat))
+    return selected
+
+
+def dedupe_by_position(selected) -> Dict[Tuple[str, int], list]:
+    """find_candidates tail (:548-574): sort by (contig, pos), keep the first record per (ref, alt)"""
+    out, seen = defaultdict(list), defaultdict(list)
+    for cand in sorted(selected, key=lambda x: (x[0], x[1])):
+        key, ra = (cand[0], cand[1]), (cand[3], cand[4][0])
+        if ra in seen[key]:
+            continue
+        seen[key].append(ra)
+        out[key].append(cand)
+    return out
+
+
+def candidate_list_to_variant(candidates, opt: CandidateOptions):
+    """VcfWriter.py:48-138"""
+    candidates = sorted(candidates, key=lambda x: (x[5], x[8]), reverse=True)[:opt.allowed_multiallelics]
+    max_ref = max((c[3] for c in candidates), key=len)
+    norm = []
+    for c in candidates:
+        contig, rs, re_, ref, alts, gt, depth, sup, gp, preds, naps, rep = c
+        if len(ref) < len(max_ref):
+            suffix = max_ref[-(len(max_ref) - len(ref)):]
+            ref, alts = ref + suffix, [a + suffix for a in alts]
+        norm.append((contig, rs, re_, ref, alts, gt, depth, sup, gp, preds, naps, rep))
+    gt_qual, hp1, hp2 = -1.0, [], []
+    site = None
+    site_alts, site_sup, site_naps, site_rep, site_depth = [], [], [], False, 0
+    for i, c in enumerate(norm):
+        contig, rs, re_, ref, alts, gt, depth, sup, gp, preds, naps, rep = c
+        site_rep = rep or site_rep
+        g = int(np.argmax(preds))
+        if g != 0:
+            gt_qual = preds[g] if gt_qual < 0 else min(gt_qual, preds[g])
+        elif gt_qual < 0:
+            gt_qual = max(preds[1], preds[2])
+        if site is None:
+            site = (contig, rs, rs + len(ref), ref)
+            site_depth = depth
+        site_depth = min(site_depth, depth)
+        site_alts.append(alts[0])
+        site_sup.append(sup[0])
+        site_naps.extend(naps)
+        if g == 1:
+            hp1.append(i + 1)
+        elif g == 2:
+            hp1.append(i + 1)
+            hp2.append(i + 1)
+    if 0 < len(hp1) + len(hp2) <= 2:
+        gt = hp1 + hp2
+        if len(gt) == 1:
+            gt = [0, gt[0]]
+    else:
+        gt = [0, 0]
+    return site[0], site[1], site[2], site[3], site_alts, gt, site_depth, site_sup, gt_qual, site_naps, site_rep
+
+
+def _fmt(v) -> str:
+    if isinstance(v, (float, np.floating)):
+        return ("%.6g" % float(v))
+    return str(v)
+
+
+VCF_HEADER = """##fileformat=VCFv4.2
+##FILTER=<ID=PASS,Description="All filters passed">
+##FILTER=<ID=refCall,Description="Call is homozygous">
+##FILTER=<ID=lowGQ,Description="Low genotype quality">
+##FILTER=<ID=lowQUAL,Description="Low variant call quality">
+##FILTER=<ID=conflictPos,Description="Overlapping record">
+##FORMAT=<ID=GT,Number=1,Type=String,Description="Genotype">
+##FORMAT=<ID=DP,Number=1,Type=Integer,Description="Depth">
+##FORMAT=<ID=AD,Number=A,Type=Integer,Description="Allele depth">
+##FORMAT=<ID=VAF,Number=A,Type=Float,Description="Variant allele fractions.">
+##FORMAT=<ID=AP,Number=A,Type=Float,Description="Maximum variant allele probability for each allele.">
+##FORMAT=<ID=GQ,Number=1,Type=Float,Description="Genotype Quality">
+##FORMAT=<ID=REP,Number=1,Type=String,Description="If set to 1 then variant site is considered to be ina LowCompexity repeat region">
+"""
+
+
+def variant_records(variants: Dict[Tuple[str, int], list], opt: CandidateOptions):
+    """write_vcf_records (:140-218) as data: yields (line, selected_for_variant_calling, is_snp)"""
+    last_position = -1
+    for contig, position in sorted(variants):
+        contig, rs, re_, ref, alleles, genotype, depth, sup, gp, naps, rep = candidate_list_to_variant(variants[(contig, position)], opt)
+        if len(alleles) <= 0 or rs == last_position:
+            continue
+        last_position = rs
+        max_alt_len = max(len(ref), max(len(x) for x in alleles))
+        qual = max(1, int(-10 * math.log10(max(0.000000001, 1.0 - gp))))
+        is_snp = max_alt_len == 1
+        if is_snp:
+            failed = qual <= (opt.snp_q_cutoff_in_lc if rep else opt.snp_q_cutoff)
+        else:
+            failed = qual <= (opt.indel_q_cutoff_in_lc if rep else opt.indel_q_cutoff)
+        selected = genotype == [0, 0] or failed
+        vafs = [round(ad / max(1, depth), 3) for ad in sup]
+        flt = "refCall" if genotype == [0, 0] else "PASS"
+        sample = ":".join(["/".join(str(x) for x in genotype), ",".join(_fmt(x) for x in naps), _fmt(qual), str(depth),
+                           ",".join(str(x) for x in sup), ",".join(_fmt(x) for x in vafs), "1" if rep else "0"])
+        line = "\t".join([str(contig), str(rs + 1), ".", ref, ",".join(alleles), str(qual), flt, ".", "GT:AP:GQ:DP:AD:VAF:REP", sample])
+        yield line, selected, is_snp
+
+
+def read_prediction_records(prediction_dir: str):
+    """every batch of every *.hdf file (FindCandidates.py:145-166)"""
+    from .hdf5io import PredictionStore
+    for fn in sorted(os.listdir(prediction_dir)):
+        if not fn.endswith("hdf"):
+            continue
+        with PredictionStore(os.path.join(prediction_dir, fn), "r") as st:
+            for _, b in st.batches():
+                for i in range(len(b["positions"])):
+                    yield dict(contig=b["contigs"][i].decode(), position=int(b["positions"][i]), depth=int(b["depths"][i]),
+                               candidates=[str(x) for x in b["candidates"][i]],
+                               candidate_frequency=[int(x) for x in b["candidate_frequency"][i]], prediction=b["base_prediction"][i])
+
+
+def process_candidates(prediction_dir: str, fasta_path: str, sample_name: str, output_dir: str,
+                       opt: CandidateOptions = CandidateOptions()) -> Dict[str, int]:
+    """candidate_finder (FindCandidates.py:131-190): prediction files -> five VCFs; returns the record counts"""
+    from .bamio import FastaHandler
+    fasta = FastaHandler(fasta_path)
+    selected = select_candidates(read_prediction_records(prediction_dir), fasta.get_reference_sequence, opt)
+    variants = dedupe_by_position(selected)
+    os.makedirs(output_dir, exist_ok=True)
+    contigs = []
+    for c in sorted(variants):
+        if c[0] not in contigs:
+            contigs.append(c[0])
+    header = VCF_HEADER + "".join("##contig=<ID=%s,length=%d>\n" % (n, fasta.get_chromosome_sequence_length(n))
+                                  for n in fasta.get_chromosome_names()) + \
+        "#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\t%s\n" % sample_name
+    names = {"full": "PEPPER_VARIANT_FULL.vcf", "pepper": "PEPPER_VARIANT_OUTPUT_PEPPER.vcf",
+             "vc": "PEPPER_VARIANT_OUTPUT_VARIANT_CALLING.vcf", "snp": "PEPPER_VARIANT_OUTPUT_VARIANT_CALLING_SNPs.vcf",
+             "indel": "PEPPER_VARIANT_OUTPUT_VARIANT_CALLING_INDEL.vcf"}
+    files = {k: open(os.path.join(output_dir, v), "w") for k, v in names.items()}
+    for f in files.values():
+        f.write(header)
+    counts = dict(total=0, pepper=0, variant_calling=0, snp=0, indel=0)
+    for line, selected_vc, is_snp in variant_records(variants, opt):
+        files["full"].write(line + "\n")
+        counts["total"] += 1
+        if selected_vc:
+            files["snp" if is_snp else "indel"].write(line + "\n")
+            counts["snp" if is_snp else "indel"] += 1
+            files["vc"].write(line + "\n")
+            counts["variant_calling"] += 1
+        else:
+            files["pepper"].write(line + "\n")
+            counts["pepper"] += 1
+    for f in files.values():
+        f.close()
+    return counts
+
+
+def main(argv=None):
+    import argparse
+    ap = argparse.ArgumentParser(prog="find_candidates")
+    ap.add_argument("-i", "--input_dir", required=True)
+    ap.add_argument("-f", "--fasta", required=True)
+    ap.add_argument("-o", "--output_dir", required=True)
+    ap.add_argument("-s", "--sample_name", default="SAMPLE")
+    args = ap.parse_args(argv)
+    c = process_candidates(args.input_dir, args.fasta, args.sample_name, args.output_dir)
+    import sys
+    sys.stderr.write("INFO: FINISHED PROCESSING, TOTAL CANDIDATES FOUND: %d (PEPPER %d, RE-GENOTYPING %d: SNP %d INDEL %d)\n" %
+                     (c["total"], c["pepper"], c["variant_calling"], c["snp"], c["indel"]))
+
+
+if __name__ == "__main__":
+    main()

@@ -112,3 +112,66 @@ def test_bam_to_predictions_end_to_end(hip_ctx, oracle_lib, tmp_path):
     with hdf5io.PredictionStore(str(tmp_path / "pred" / "pepper_prediction.hdf"), "r") as st:
         total = sum(bt["base_prediction"].shape[0] for _, bt in st.batches())
     assert total == n
+
+
+def test_call_variant_bam_to_vcf(hip_ctx, oracle_lib, tmp_path):
+    """the whole pipeline on this code base: BAM + FASTA -> images -> predictions -> VCFs; and the VCF records
+    computed from the GPU probabilities equal those computed from the float64 oracle probabilities
+    (north_star: identical candidate-variant calls)."""
+    import bam_writer as bw
+    from oracle import rnn_oracle
+    from pepper_thesis_amd import bamio, build, call_variant, find_candidates as fc
+    build.build_io()
+    rng = np.random.default_rng(17)
+    ref = "".join(rng.choice(list("ACGT"), size=40_000))
+    bw.write_fasta(str(tmp_path / "ref.fa"), [("chr20", ref)])
+    recs = bw.random_records(rng, 500, 40_000, tid=0, mean_len=2500, allow_skip=False)
+    for r in recs:
+        seq, qi, rp = list(r["seq"]), 0, r["pos"]
+        for op, ln in r["cigar"]:
+            if op in (0, 7, 8):
+                for i in range(ln):
+                    if rp + i < len(ref) and rng.random() > 0.04:
+                        seq[qi + i] = ref[rp + i]
+                qi += ln; rp += ln
+            elif op in (1, 4):
+                qi += ln
+            elif op in (2, 3):
+                rp += ln
+        r["seq"], r["mapq"] = "".join(seq), 60
+        r["flag"] &= 0x10
+    bw.write_bam(str(tmp_path / "reads.bam"), [("chr20", len(ref))], recs)
+    w = synth.make_weights_p1(3, 3.0)
+    np.savez(str(tmp_path / "model.npz"), **w)
+    out = tmp_path / "out"
+    counts = call_variant.main(["-b", str(tmp_path / "reads.bam"), "-f", str(tmp_path / "ref.fa"), "-m", str(tmp_path / "model.npz"),
+                                "-o", str(out), "-s", "HG003", "--ont_r9_guppy5_sup", "-r", "chr20:2000-38000", "--region_size", "12000"])
+    assert counts["total"] > 20 and counts["total"] == counts["pepper"] + counts["variant_calling"]
+    full = [l for l in open(out / "PEPPER_VARIANT_FULL.vcf") if not l.startswith("#")]
+    assert len(full) == counts["total"]
+    pos = [int(l.split("\t")[1]) for l in full]
+    assert pos == sorted(pos) and len(set(pos)) == len(pos)
+    assert open(out / "PEPPER_VARIANT_FULL.vcf").read().startswith("##fileformat=VCF")
+    # the same prediction records with oracle probabilities -> identical VCF lines
+    pred_dir = [p for p in os.listdir(out) if p.startswith("predictions_")][0]
+    records = list(fc.read_prediction_records(str(out / pred_dir)))
+    img_dir = [p for p in os.listdir(out) if p.startswith("images_")][0]
+    with hdf5io.ImageStore(str(out / img_dir / "pepper_variants_images_thread_0.hdf5"), "r") as st:
+        parts = [st.read_summary(n) for n in st.summaries()]
+    images = np.concatenate([p["images"] for p in parts])
+    keys = [(p["positions"][i], p["candidates"][i, 0]) for p in parts for i in range(len(p["positions"]))]
+    ref_probs = dict(zip(keys, rnn_oracle.p1_forward(w, images, np.float64)))
+    recs_oracle = [dict(r, prediction=ref_probs[(r["position"], r["candidates"][0])]) for r in records]
+    fasta = bamio.FastaHandler(str(tmp_path / "ref.fa"))
+    opt = fc.CandidateOptions()
+    v_gpu = fc.dedupe_by_position(fc.select_candidates(records, fasta.get_reference_sequence, opt))
+    v_ora = fc.dedupe_by_position(fc.select_candidates(recs_oracle, fasta.get_reference_sequence, opt))
+
+    def key_fields(v):  # everything except the float-valued AP field
+        out_ = []
+        for line, sel, snp in fc.variant_records(v, opt):
+            f = line.split("\t")
+            s = f[9].split(":")
+            out_.append((f[0], f[1], f[3], f[4], f[5], f[6], s[0], s[2], s[3], s[4], s[5], s[6], sel, snp))
+        return out_
+    assert key_fields(v_gpu) == key_fields(v_ora)
