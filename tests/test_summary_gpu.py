@@ -101,3 +101,70 @@ def test_full_size_region_properties(hip_ctx, oracle_lib):
     # run-to-run determinism (atomics only add integers)
     o3 = hip_ctx.summarize(b1, P, False)
     np.testing.assert_array_equal(o3.images, o1.images)
+
+
+def test_depth_5000_max_reads(hip_ctx, oracle_lib):
+    """MAX_READS_IN_REGION = 5000 (Options.py:98): several pair batches per tile, depth clipped to 125"""
+    reg = synth.synth_region(77, region_len=700, depth=5000, read_len=600, site_every=40)
+    assert len(reg.reads) > 4000
+    b = pack_regions([reg])
+    P = PRESETS["ont_r9_guppy5_sup"]
+    o = hip_ctx.summarize(b, P, True)
+    assert_summary_equal(o, summary_as_expected(oracle_lib.summarize(b, P, True)), "depth 5000")
+    assert int(o.depth.max()) == 125
+
+
+def test_every_column_a_site_triggers_workspace_retry(hip_ctx, oracle_lib):
+    """far more sites than the default workspace heuristic expects: the host entry point retries with exact bounds"""
+    from pepper_thesis_amd.batch import Read, Region
+    rng = np.random.default_rng(9)
+    R = 40_000
+    ref = rng.choice(np.frombuffer(b"ACGT", np.uint8), size=R).astype(np.uint8)
+    reads = []
+    for i in range(6):
+        seq = ref.copy()
+        flip = rng.random(R) < 0.5
+        seq[flip] = np.frombuffer(b"ACGT", np.uint8)[(np.searchsorted(np.frombuffer(b"ACGT", np.uint8), seq[flip]) + 1) % 4]
+        reads.append(Read.make(0, "%dM" % R, seq.tobytes(), 20, i % 2 == 0))
+    b = pack_regions([Region(0, R - 1, ref.tobytes(), reads)])
+    P = PRESETS["ont_r9_guppy5_sup"]
+    o = hip_ctx.summarize(b, P, False)
+    e = oracle_lib.summarize(b, P, False)
+    assert len(o) == len(e) > 30_000
+    np.testing.assert_array_equal(o.images, e.images)
+    assert o.candidates == e.candidates
+
+
+def test_more_than_1024_alleles_at_one_site_is_reported(hip_ctx):
+    """documented limit of the per-site LDS allele table: PV_ERR_LIMIT, not a crash or a wrong answer"""
+    from pepper_thesis_amd import _ffi
+    from pepper_thesis_amd.batch import Read, Region
+    ref = b"ACGTACGTACGTACGTACGTACGTACGTAC"
+    reads = []
+    for i in range(1100):
+        ins = "".join("ACGT"[(i >> (2 * k)) & 3] for k in range(6))  # 1100 distinct 6-mers
+        reads.append(Read.make(0, "15M6I15M", ref[:15] + ins.encode() + ref[15:], 30, i % 2 == 0))
+    with pytest.raises(_ffi.PepperHipError) as e:
+        hip_ctx.summarize(pack_regions([Region(0, 29, ref, reads)]), PRESETS["ont_r9_guppy5_sup"])
+    assert e.value.code == _ffi.PV_ERR_LIMIT
+
+
+def test_long_indels_and_padded_reference(hip_ctx, oracle_lib):
+    """a 3000-base insertion (quality sum over the whole insert, :448-450), a deletion longer than the region
+    remainder, and a reference buffer longer than the region (ref_len > R)"""
+    from pepper_thesis_amd.batch import Read, Region
+    rng = np.random.default_rng(4)
+    ref = bytes(rng.choice(np.frombuffer(b"ACGT", np.uint8), size=400).astype(np.uint8))
+    reads = []
+    for i in range(8):
+        ins = bytes(rng.choice(np.frombuffer(b"ACGT", np.uint8), size=3000).astype(np.uint8))
+        reads.append(Read.make(100, "50M3000I50M", ref[100:150] + ins + ref[150:200], 12 + i, i % 2 == 0))
+    for i in range(6):
+        reads.append(Read.make(100, "120M500D10M", ref[100:220] + b"ACGTACGTAC", 20, i % 2 == 0))
+    for i in range(6):
+        reads.append(Read.make(90, "200M", ref[90:290], 20, i % 2 == 1))
+    b = pack_regions([Region(100, 299, ref[100:], reads)])  # 300 reference bytes for a 200-column region
+    for preset in ("ont_r9_guppy5_sup", "hifi"):
+        P = PRESETS[preset]
+        o = hip_ctx.summarize(b, P, True)
+        assert_summary_equal(o, summary_as_expected(oracle_lib.summarize(b, P, True)), preset)
