@@ -181,15 +181,21 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    n_dev = torch.cuda.device_count()
+    dev_id = local_rank % max(n_dev, 1)  # one rank per GPU; (rehearsals with more ranks than GPUs share devices)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        torch.cuda.set_device(dev_id)
+        backend = os.environ.get("PV_BENCH_BACKEND", "nccl")  # nccl == RCCL on ROCm; gloo only for single-GPU rehearsals
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", dev_id))
+        else:
+            dist.init_process_group(backend)
     else:
         dist = None
-        torch.cuda.set_device(local_rank)
-    dev = "cuda:%d" % local_rank
+        torch.cuda.set_device(dev_id)
+    dev = "cuda:%d" % dev_id
 
     from pepper_thesis_amd import runtime, synth
     from pepper_thesis_amd.batch import PRESETS, pack_regions
@@ -216,7 +222,7 @@ def main():
         (rank, len(regions), batch.n_reads, batch.n_bases / 1e6, time.time() - t0))
     P = PRESETS["ont_r9_guppy5_sup"]
 
-    ctx = runtime.Context(local_rank)
+    ctx = runtime.Context(dev_id)
     ctx.load_p1(weights)
     dbatch = DeviceBatch(batch, dev)
     # Two window buffers: the image builder of group g+1 (stream s_build) overlaps the RNN of group g
@@ -282,7 +288,7 @@ def main():
     dt = time.perf_counter() - t0
     prof = ctx.profile_end()
     if dist is not None:
-        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+        tmax = torch.tensor([dt], dtype=torch.float64, device=dev if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
 
@@ -323,7 +329,7 @@ def main():
         }
         if world == 1 and not args.no_bf16:
             try:
-                out["config2_bf16_input_gemm"] = bf16_secondary(local_rank, weights, dbatch, P, dev, pad)
+                out["config2_bf16_input_gemm"] = bf16_secondary(dev_id, weights, dbatch, P, dev, pad)
             except Exception as e:
                 out["config2_bf16_input_gemm"] = {"error": repr(e)}
         if world == 1 and not args.no_p2:

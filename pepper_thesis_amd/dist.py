@@ -26,6 +26,9 @@ def gather_predictions(local: torch.Tensor, dst: int = 0, keys: Optional[torch.T
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
         return local, keys, [int(local.shape[0])]
     world, rank = dist.get_world_size(), dist.get_rank()
+    if dist.get_backend() != "nccl" and local.is_cuda:  # gloo rehearsal with device tensors: collective on the host
+        local = local.cpu()
+        keys = None if keys is None else keys.cpu()
     dev = local.device
     n = torch.tensor([local.shape[0]], dtype=torch.int64, device=dev)
     counts = torch.zeros(world, dtype=torch.int64, device=dev)
