@@ -154,6 +154,42 @@ int pv_summarize_regions_dev(pv_ctx* ctx, const pv_batch_in* in, const pv_params
                              int64_t n_reads, int64_t n_bases, int64_t n_cigar, int64_t n_ref_bytes,
                              int64_t max_region_len, pv_batch_out* out, int64_t* d_counts, void* stream);
 
+/* ---- P2 (polisher) summary images -------------------------------------------------------------
+ * Replaces SummaryGenerator::generate_summary + generate_image
+ * (pepper/modules/src/pileup_summary/summary_generator.cpp:47-121, 274-304, 371-392) and
+ * AlignmentSummarizer.chunk_images (pepper/modules/python/AlignmentSummarizer.py:19-56) for a batch of
+ * regions. Input is the same pv_batch_in struct; quals, cand_start and cand_end are not read, and the reference
+ * bytes are only needed for their length, as in the reference. Every reference position of a region
+ * gives one image row followed by `longest insert anchored there` insert rows; a row is 10 uint8:
+ *   0-3 A,C,G,T reverse  4-7 A,C,G,T forward  8 other/deleted reverse  9 other/deleted forward,
+ *   value = (uint8) (count / max(1, coverage[position]) * 254), the double->uint8 conversion taken as
+ *   truncation to int32 followed by the low byte (what the x86-64 build of the reference does; only
+ *   reachable where deletions cover a column no read base covers).
+ * The rows of a region are cut into chunks of seq_length rows that overlap by seq_overlap rows; the
+ * last chunk is padded with zero rows whose position/index are -1. */
+typedef struct pv_polish_out {
+    int64_t chunk_capacity; /* in: chunks the chunk arrays can hold */
+    int64_t row_capacity;   /* in: rows the flat arrays can hold (0 when the flat arrays are NULL) */
+    uint8_t* images;        /* [chunk_capacity][seq_length][10] */
+    int64_t* position;      /* [chunk_capacity][seq_length] genomic_pos.first */
+    int32_t* index;         /* [chunk_capacity][seq_length] genomic_pos.second (0 = base row, k = k-th insert row) */
+    int32_t* region;        /* [chunk_capacity] region of the batch */
+    int32_t* chunk_id;      /* [chunk_capacity] chunk number inside its region */
+    uint8_t* flat_images;   /* optional [row_capacity][10]: SummaryGenerator::image of all regions, concatenated */
+    int64_t* flat_position; /* optional [row_capacity] */
+    int32_t* flat_index;    /* optional [row_capacity] */
+    int64_t* region_row_off;/* optional [n_regions+1] first flat row of every region */
+    int64_t n_chunks;       /* out: chunks produced (or needed on PV_ERR_CAPACITY) */
+    int64_t n_rows;         /* out: flat rows produced (or needed) */
+} pv_polish_out;
+
+/* HOST buffers in and out. */
+int pv_polish_summarize_regions(pv_ctx* ctx, const pv_batch_in* in, int seq_length, int seq_overlap, pv_polish_out* out);
+/* Device-resident, asynchronous form (see pv_summarize_regions_dev): d_counts = {n_chunks, n_rows, status, insert rows}. */
+int pv_polish_summarize_regions_dev(pv_ctx* ctx, const pv_batch_in* in, int64_t n_reads, int64_t n_bases, int64_t n_cigar,
+                                    int64_t n_ref_bytes, int seq_length, int seq_overlap, pv_polish_out* out,
+                                    int64_t* d_counts, void* stream);
+
 /* ---- recurrent-network inference ------------------------------------------------------------ */
 
 #define PV_PLAN_P1_LSTM 1 /* pepper_variant: 2x bi-LSTM(256) + 5xLinear(512)/SELU + Linear(3) + softmax */

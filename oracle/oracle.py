@@ -17,10 +17,15 @@ _SIG = [C.POINTER(_ffi.pv_batch_in), C.POINTER(_ffi.pv_params), C.POINTER(_ffi.p
 _libs = {}
 
 
+_made = False
+
+
 def build(force=False):
-    """(re)build liboracle.so and, if /root/reference exists, oracle/_ref."""
-    if force or not os.path.exists(ORACLE_SO) or (os.path.exists("/root/reference") and not os.path.exists(REF_SO)):
-        subprocess.check_call(["make", "-s", "-C", _HERE])
+    """(re)build liboracle.so and, if /root/reference exists, oracle/_ref (make decides what is stale)."""
+    global _made
+    if force or not _made:
+        subprocess.check_call(["make", "-s", "-C", _HERE] + (["-B"] if force else []))
+        _made = True
 
 
 def _load(path, sym):
@@ -52,4 +57,21 @@ def reference_summarize(batch: RegionBatch, params: Params, want_i32=False):
     rc, out = run_flat_summarizer(_load(REF_SO, "ref_summarize_regions"), batch, params, want_i32)
     if rc:
         raise RuntimeError("ref_summarize_regions failed: %d" % rc)
+    return out
+
+
+def polish_summarize(batch: RegionBatch, seq_length=1000, seq_overlap=50, want_flat=True):
+    """CPU restatement of the polisher's SummaryGenerator.generate_summary + chunk_images (PARITY UNPINNED, see
+    polish_summary_oracle.c)."""
+    from pepper_thesis_amd.polish_summary import run_polish_summarizer
+    build()
+    key = (ORACLE_SO, "oracle_polish_summarize_regions")
+    if key not in _libs:
+        fn = getattr(C.CDLL(ORACLE_SO), key[1])
+        fn.restype = C.c_int
+        fn.argtypes = [C.POINTER(_ffi.pv_batch_in), C.c_int, C.c_int, C.POINTER(_ffi.pv_polish_out)]
+        _libs[key] = fn
+    rc, out = run_polish_summarizer(_libs[key], batch, seq_length, seq_overlap, want_flat)
+    if rc:
+        raise RuntimeError("oracle_polish_summarize_regions failed: %d" % rc)
     return out

@@ -95,6 +95,24 @@ class pv_batch_out(C.Structure):
     ]
 
 
+class pv_polish_out(C.Structure):
+    _fields_ = [
+        ("chunk_capacity", C.c_int64),
+        ("row_capacity", C.c_int64),
+        ("images", C.c_void_p),
+        ("position", C.c_void_p),
+        ("index", C.c_void_p),
+        ("region", C.c_void_p),
+        ("chunk_id", C.c_void_p),
+        ("flat_images", C.c_void_p),
+        ("flat_position", C.c_void_p),
+        ("flat_index", C.c_void_p),
+        ("region_row_off", C.c_void_p),
+        ("n_chunks", C.c_int64),
+        ("n_rows", C.c_int64),
+    ]
+
+
 class pv_rnn_dir(C.Structure):
     _fields_ = [("w_ih", C.c_void_p), ("w_hh", C.c_void_p), ("b_ih", C.c_void_p), ("b_hh", C.c_void_p)]
 
@@ -130,6 +148,10 @@ SYMBOLS = [
     ("pv_summarize_regions_dev", C.c_int,
      [C.c_void_p, C.POINTER(pv_batch_in), C.POINTER(pv_params), C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int64,
       C.POINTER(pv_batch_out), C.c_void_p, C.c_void_p]),
+    ("pv_polish_summarize_regions", C.c_int, [C.c_void_p, C.POINTER(pv_batch_in), C.c_int, C.c_int, C.POINTER(pv_polish_out)]),
+    ("pv_polish_summarize_regions_dev", C.c_int,
+     [C.c_void_p, C.POINTER(pv_batch_in), C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int, C.c_int,
+      C.POINTER(pv_polish_out), C.c_void_p, C.c_void_p]),
     ("pv_rnn_load_p1", C.c_int, [C.c_void_p, C.POINTER(pv_weights_p1), C.c_int]),
     ("pv_rnn_load_p2", C.c_int, [C.c_void_p, C.POINTER(pv_weights_p2), C.c_int]),
     ("pv_rnn_forward_p1", C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
@@ -162,6 +184,13 @@ def load():
         raise ImportError(
             "libpepper_hip.so is missing at %s - build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(hipcc --offload-arch=gfx950). There is no CPU fallback." % LIB_PATH)
+    try:
+        # PyTorch-ROCm wheels carry their own libamdhip64 / libhsa-runtime64. Load them FIRST so that this library's
+        # DT_NEEDED entries resolve to the copies already in the process: two HIP runtimes in one process cannot both
+        # open the device (torch then reports "No HIP GPUs are available" when it initialises second).
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     lib = C.CDLL(LIB_PATH)
     for name, res, args in SYMBOLS:
         fn = getattr(lib, name)  # AttributeError if the library does not export it

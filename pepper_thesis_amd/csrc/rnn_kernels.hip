@@ -38,6 +38,17 @@ constexpr int HEAD_N = 512;
 constexpr int HEAD_K = T_STEPS * 2 * H;  // 16896
 constexpr int HEAD_MAX_SPLITS = 33;      // split-K factor of linear_1 is chosen per launch from {1, 3, 11, 33}
 
+// Streaming accesses (x_t tiles, layer outputs, the head's A operand) carry the non-temporal hint: they are touched
+// once, and without the hint they push the packed weights (3.1 MB per direction in a 4 MB L2) out of the XCD's L2
+// every time step (rocprofv3 FETCH_SIZE showed the weights re-fetched on each of the 33 steps).
+#ifdef PV_NO_NT
+#define PV_LD_STREAM(p) (*(p))
+#define PV_ST_STREAM(v, p) (*(p) = (v))
+#else
+#define PV_LD_STREAM(p) __builtin_nontemporal_load(p)
+#define PV_ST_STREAM(v, p) __builtin_nontemporal_store((v), (p))
+#endif
+
 // v_exp_f32 / v_rcp_f32 (1 ulp) instead of the IEEE division sequence: ~3x fewer VALU instructions in the
 // cell update; absolute error of sigmoid/tanh stays ~1e-7 (tests pin 2e-5 on layer outputs).
 __device__ __forceinline__ float rcpf_(float x) { return __builtin_amdgcn_rcpf(x); }
@@ -270,7 +281,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void k_lstm_layer(LstmArgs a) {
                 const int row = i / V4, c4 = i - row * V4;
                 int64_t b = b0 + (row < ROWS ? row : ROWS - 1);
                 if (b >= a.B) b = a.B - 1;
-                xr[u] = *reinterpret_cast<const f32x4*>(a.x_f32 + (b * T_STEPS + t) * (int64_t)KP + c4 * 4);
+                xr[u] = PV_LD_STREAM(reinterpret_cast<const f32x4*>(a.x_f32 + (b * T_STEPS + t) * (int64_t)KP + c4 * 4));
             }
         }
     };
@@ -355,7 +366,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void k_lstm_layer(LstmArgs a) {
                 } else {
                     const size_t obase = ((size_t)b0 * T_STEPS + t) * (2 * H) + dir * H;
                     const unsigned ooff = (unsigned)row * (T_STEPS * 2 * H) + (unsigned)unit;
-                    (a.out + obase)[ooff] = h;
+                    PV_ST_STREAM(h, a.out + obase + ooff);
                     if (a.out_cm) {
                         const unsigned col = dir * H + unit;
                         a.out_cm[((size_t)(col >> 5) * a.cm_rows + (size_t)(b0 + row) * T_STEPS + t) * 32 + (col & 31)] = h;
@@ -554,6 +565,7 @@ struct HeadArgs {
     int n_tiles;
     int splits;           // divides 33
     int steps_per_split;
+    int per_xcd;          // > 0: XCD-aware order (see k_head_splitk); 0: tile-major order
 };
 
 __global__ __launch_bounds__(256, 1) void k_head_splitk(HeadArgs a) {
@@ -562,7 +574,18 @@ __global__ __launch_bounds__(256, 1) void k_head_splitk(HeadArgs a) {
     extern __shared__ float smem[];
     float* abuf = smem;  // [32][LDA]
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int tile = blockIdx.x / a.splits, split = blockIdx.x - tile * a.splits;
+    // XCD-aware order: workgroups are dealt round-robin to the 8 XCDs, so XCD x runs blocks x, x+8, ... Give it a
+    // CONTIGUOUS range of the split-major list (split, tile): its 32 CUs then stream the same 1/splits slice of the
+    // packed linear_1 weights at the same time and the slice passes through that XCD's L2 once, instead of every XCD
+    // pulling all 34.6 MB for every round of tiles.
+    int tile, split;
+    if (a.per_xcd > 0) {
+        const int l = (int)(blockIdx.x & 7) * a.per_xcd + (int)(blockIdx.x >> 3);
+        if ((int)(blockIdx.x >> 3) >= a.per_xcd || l >= a.n_tiles * a.splits) return;
+        split = l / a.n_tiles; tile = l - split * a.n_tiles;
+    } else {
+        tile = blockIdx.x / a.splits; split = blockIdx.x - tile * a.splits;
+    }
     const int64_t b0 = (int64_t)tile * ROWS;
     f32x16 acc[4];
 #pragma unroll
@@ -579,7 +602,7 @@ __global__ __launch_bounds__(256, 1) void k_head_splitk(HeadArgs a) {
             int64_t b = b0 + row;
             if (b >= a.B) b = a.B - 1;
             *reinterpret_cast<f32x4*>(abuf + row * LDA + c4 * 4) =
-                *reinterpret_cast<const f32x4*>(a.dec + (b * T_STEPS + t) * (int64_t)KC + c4 * 4);
+                PV_LD_STREAM(reinterpret_cast<const f32x4*>(a.dec + (b * T_STEPS + t) * (int64_t)KC + c4 * 4));
         }
         __syncthreads();
         const float* wp = a.w1p + ((size_t)wv * (HEAD_K / 8) + (size_t)t * (KC / 8)) * 4 * 256;
@@ -1150,7 +1173,11 @@ static int p1_forward_launch(pv_ctx* ctx, const int8_t* d_images, int64_t B, flo
     int splits = ((int64_t)n_tiles * 11 >= ctx->num_cu) ? 11 : 33;
     if (const char* e = getenv("PV_HEAD_SPLITS")) { const int v = atoi(e); if (v == 1 || v == 3 || v == 11 || v == 33) splits = v; }
     h.dec = dec_out; h.w1p = m->w1p; h.part = part; h.B = B; h.n_tiles = n_tiles; h.splits = splits; h.steps_per_split = T_STEPS / splits;
-    { pv_prof_scope ps(ctx, "k_head_splitk", st); k_head_splitk<<<(unsigned)(n_tiles * splits), 256, LDS_SPLITK, st>>>(h); }
+    static const int head_map = getenv("PV_HEAD_MAP") ? atoi(getenv("PV_HEAD_MAP")) : 1;
+    const int total_wg = n_tiles * splits;
+    h.per_xcd = head_map ? (total_wg + 7) / 8 : 0;
+    const unsigned head_grid = head_map ? (unsigned)(h.per_xcd * 8) : (unsigned)total_wg;
+    { pv_prof_scope ps(ctx, "k_head_splitk", st); k_head_splitk<<<head_grid, 256, LDS_SPLITK, st>>>(h); }
     TailArgs t;
     t.part = part; t.b1 = m->b1; t.splits = splits; t.part_rows = B;
     for (int i = 0; i < 4; i++) { t.wp[i] = m->wlp[i]; t.b[i] = m->bl[i]; }

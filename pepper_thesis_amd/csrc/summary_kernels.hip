@@ -37,7 +37,7 @@ constexpr int32_t OP_INACTIVE = 0x7fffffff;
 constexpr int UMAX = 1024;  // distinct alleles per site held in LDS
 constexpr int TILE_COLS = 512;  // columns per pileup tile (one workgroup accumulates a tile in LDS)
 
-enum { D_NSITES = 0, D_NEVENTS = 1, D_NOUT = 2, D_STRBYTES = 3, D_STATUS = 4, D_NPAIRS = 5, D_NDIAG = 8 };
+enum { D_NSITES = 0, D_NEVENTS = 1, D_NOUT = 2, D_STRBYTES = 3, D_STATUS = 4, D_NPAIRS = 5, D_NINS = 6, D_NROWS = 7, D_NCHUNKS = 8, D_NDIAG = 10 };
 
 struct Event {  // 16 B
     int64_t src;  // index into bases (kind 1) or ref (kind 2)
@@ -106,6 +106,22 @@ struct SumArgs {
     int64_t max_events;
     pv_batch_out out;
     int64_t* d_counts;
+    // ---- P2 (polisher) summary only ----
+    int32_t polish;       // 1: CIGAR semantics of SummaryGenerator::iterate_over_read (N and P consume the reference only)
+    int32_t seq_len, seq_step;  // chunk length, chunk length - overlap
+    int32_t* pcnt;        // [PC_N][n_cols] plane-major: 10 features, coverage, longest insert
+    int32_t* ins_blk;     // [n_blk] insert rows per 1024-column block
+    int32_t* ins_blkoff;  // [n_blk] exclusive scan
+    int32_t* ins_off;     // [n_cols + 1] insert rows before every column
+    int32_t* ins_cnt;     // [max_ins_rows][10]
+    int64_t max_ins_rows;
+    int64_t* reg_rows;    // [n_regions + 1] first flat row of every region
+    int64_t* reg_chunks;  // [n_regions + 1] first chunk of every region
+    uint8_t* flat_img;    // [flat_cap][10]
+    int64_t* flat_pos;
+    int32_t* flat_idx;
+    int64_t flat_cap;
+    pv_polish_out pout;
 };
 
 __device__ __forceinline__ int up(int c) { return (c >= 'a' && c <= 'z') ? c - 32 : c; }
@@ -162,7 +178,7 @@ __global__ __launch_bounds__(256) void k_cigar_scan(SumArgs a) {
     const int64_t c0 = a.in.cigar_off[r], c1 = a.in.cigar_off[r + 1];
     const bool skip = a.in.read_mapq[r] == 0;  // :619
     const int64_t R = a.in.ref_end[g] - a.in.ref_start[g] + 1;
-    if (!skip && a.in.base_off[r + 1] - a.in.base_off[r] <= 0 && lane == 0) set_status(a.diag, PV_ERR_INVALID);
+    if (!skip && !a.polish && a.in.base_off[r + 1] - a.in.base_off[r] <= 0 && lane == 0) set_status(a.diag, PV_ERR_INVALID);
     int64_t ref_rel = a.in.read_pos[r] - a.in.ref_start[g];
     int64_t rd = 0;
     for (int64_t cb = c0; cb < c1; cb += 64) {
@@ -171,7 +187,8 @@ __global__ __launch_bounds__(256) void k_cigar_scan(SumArgs a) {
         const int op = w & 0xF;
         const int64_t len = c < c1 ? (int64_t)(w >> 4) : 0;
         const bool cr = (op == 0 || op == 7 || op == 8 || op == 2 || op == 3 || op == 6);
-        const bool cq = (op == 0 || op == 7 || op == 8 || op == 1 || op == 4 || op == 3 || op == 6);
+        // P2: REF_SKIP and PAD share the DEL case (summary_generator.cpp:100-114) and consume the reference only
+        const bool cq = (op == 0 || op == 7 || op == 8 || op == 1 || op == 4 || (!a.polish && (op == 3 || op == 6)));
         const int64_t dr = cr ? len : 0, dq = cq ? len : 0;
         const int64_t ir = wave_incl_scan(dr, lane), iq = wave_incl_scan(dq, lane);
         const int64_t my_ref = ref_rel + ir - dr, my_rd = rd + iq - dq;
@@ -970,6 +987,294 @@ __global__ __launch_bounds__(64) void k_write_windows(SumArgs a) {
     }
 }
 
+// ==== P2 (polisher) summary images ====================================================================
+// SummaryGenerator::iterate_over_read / generate_image (pepper/modules/src/pileup_summary/summary_generator.cpp:47-121,
+// 274-304). Same tile-owner scheme as k_pileup_tiles (pairs -> ops -> bases, counters of a 512-column tile in LDS), with
+// the polisher's much simpler per-base rule: one ds_add into one of ten (symbol, strand) planes, no qualities.
+constexpr int PC_COV = 10, PC_LONG = 11, PC_N = 12;  // global planes: 0-9 features, coverage, longest insert
+enum { Q_F = 0, Q_STAR = 10 /* [rev, fwd] deleted columns */, Q_DCOV = 12, Q_LONG = 13, Q_N = 14 };
+
+// get_feature_index (summary_generator.cpp:16-33): toupper, then reverse A0 C1 G2 T3 else 8, forward A4 C5 G6 T7 else 9
+__device__ __forceinline__ int polish_sym(int c) { c = up(c); return c == 'A' ? 0 : c == 'C' ? 1 : c == 'G' ? 2 : c == 'T' ? 3 : 4; }
+__device__ __forceinline__ int polish_feature(int sym, bool rev) { return sym < 4 ? (rev ? sym : 4 + sym) : (rev ? 8 : 9); }
+
+__global__ __launch_bounds__(PT_THREADS) void k_polish_tiles(SumArgs a) {
+    __shared__ int32_t s_cnt[Q_N][TILE_COLS];
+    __shared__ uint8_t s_lut[256];           // polish_sym of every byte
+    __shared__ uint16_t s_blk[PT_THREADS * TILE_COLS / 64 + 1];
+    __shared__ int32_t s_pref[PT_THREADS];
+    __shared__ int32_t s_col0[PT_THREADS];
+    __shared__ int64_t s_base[PT_THREADS];
+    __shared__ int32_t s_i0[PT_THREADS];
+    __shared__ uint8_t s_opfl[PT_THREADS];   // bit0 rev
+    __shared__ uint8_t s_opair[PT_THREADS];
+    __shared__ int32_t p_off[PT_PB + 1];
+    __shared__ int32_t p_oplo[PT_PB], p_colbase[PT_PB], p_R[PT_PB], p_rev[PT_PB];
+    __shared__ int64_t p_base0[PT_PB], p_seqend[PT_PB];
+    __shared__ int32_t s_wsum[PT_THREADS / 64];
+    const int tid = threadIdx.x;
+    const int64_t tile = blockIdx.x;
+    const int64_t tlo = tile * TILE_COLS, thi = tlo + TILE_COLS - 1;
+    for (int i = tid; i < Q_N * TILE_COLS; i += PT_THREADS) (&s_cnt[0][0])[i] = 0;
+    if (tid < 256) s_lut[tid] = (uint8_t)polish_sym(tid);
+    const int32_t p0 = a.tile_off[tile];
+    const int32_t np = a.tile_cnt[tile];
+    __syncthreads();
+    for (int32_t pb = 0; pb < np; pb += PT_PB) {
+        const int npb = (np - pb) < PT_PB ? (np - pb) : PT_PB;
+        int nops = 0;
+        if (tid < npb) {
+            const PairRec pr = a.pairs[p0 + pb + tid];
+            nops = pr.op_hi - pr.op_lo;
+            p_oplo[tid] = pr.op_lo; p_colbase[tid] = pr.col_base; p_R[tid] = pr.R;
+            p_rev[tid] = pr.rev; p_base0[tid] = pr.base0; p_seqend[tid] = pr.seq_end;
+        }
+        const int incl_ops = block_incl_scan512(nops, s_wsum, tid);
+        if (tid < npb) p_off[tid + 1] = incl_ops;
+        if (tid == 0) p_off[0] = 0;
+        __syncthreads();
+        const int total_ops = p_off[npb];
+        for (int ob = 0; ob < total_ops; ob += PT_THREADS) {
+            const int k = ob + tid;
+            int32_t ref_rel = 0, rd = 0, len = 0, op = 15, col_base = 0, R = 0;
+            bool active = false, rev = false;
+            int pslot = 0;
+            int32_t c = 0;
+            int64_t clo = 0, chi = -1;
+            if (k < total_ops) {
+                int lo = 0, hi = npb;
+                while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (p_off[mid] <= k) lo = mid; else hi = mid; }
+                pslot = lo;
+                c = p_oplo[pslot] + (k - p_off[pslot]);
+                const int32_t rr = a.op_ref[c];
+                const uint32_t w = a.in.cigar[c];
+                const int32_t rdv = a.op_rd[c];
+                col_base = p_colbase[pslot];
+                rev = p_rev[pslot] != 0;
+                R = p_R[pslot];
+                active = rr != OP_INACTIVE;
+                if (active) { ref_rel = rr; rd = rdv; op = w & 0xF; len = (int32_t)(w >> 4); }
+                clo = tlo - col_base; chi = thi - col_base;
+                if (clo < 0) clo = 0;
+                if (chi > R - 1) chi = R - 1;
+            }
+            if (active && op == PV_CIGAR_IN) {  // :82-98; the tile that owns the anchor column takes the op
+                const int64_t anchor = (int64_t)ref_rel - 1;
+                if (anchor >= clo && anchor <= chi) {
+                    const int lc = (int)(col_base + anchor - tlo);
+                    if (p_base0[pslot] + rd + (int64_t)len > p_seqend[pslot]) {
+                        set_status(a.diag, PV_ERR_INVALID);  // alt[i] past the end of the read
+                    } else {
+                        atomicMax(&s_cnt[Q_LONG][lc], len);
+                        a.op_flag[c] = 1;  // counted per insert row by k_polish_insert once the row layout is known
+                    }
+                }
+            } else if (active && (op == PV_CIGAR_DEL || op == PV_CIGAR_REF_SKIP || op == PV_CIGAR_PAD)) {  // :100-114
+                int64_t i0 = clo - ref_rel; if (i0 < 0) i0 = 0;
+                int64_t i1 = chi + 1 - ref_rel; if (i1 > len) i1 = len;
+                for (int64_t i = i0; i < i1; i++)
+                    atomicAdd(&s_cnt[Q_STAR + (rev ? 0 : 1)][(int)((int64_t)col_base + ref_rel + i - tlo)], 1);
+                // "coverage[ref_position] += 1.0" sits INSIDE the loop over the deleted columns but is keyed by the
+                // START of the deletion (:110): that column gains one per in-region deleted column, the others nothing.
+                if ((int64_t)ref_rel >= clo && (int64_t)ref_rel <= chi) {
+                    int64_t n = (int64_t)R - ref_rel; if (n > len) n = len;
+                    if (n > 0) atomicAdd(&s_cnt[Q_DCOV][(int)(col_base + ref_rel - tlo)], (int)n);
+                }
+            }
+            const bool is_m = active && (op == PV_CIGAR_MATCH || op == PV_CIGAR_EQUAL || op == PV_CIGAR_DIFF);
+            int32_t i0 = 0, eff = 0;
+            if (is_m) {
+                int64_t lo = clo - ref_rel; if (lo < 0) lo = 0;
+                int64_t hi = chi + 1 - ref_rel; if (hi > len) hi = len;
+                if (hi > lo) { i0 = (int32_t)lo; eff = (int32_t)(hi - lo); }
+            }
+            const int32_t incl = block_incl_scan512(eff, s_wsum, tid);
+            s_pref[tid] = incl;
+            s_col0[tid] = col_base + ref_rel;
+            s_base[tid] = (k < total_ops ? p_base0[pslot] : 0) + rd;
+            s_i0[tid] = i0 - (incl - eff);
+            s_opfl[tid] = (uint8_t)(rev ? 1 : 0);
+            s_opair[tid] = (uint8_t)pslot;
+            for (int32_t bb = (incl - eff + 63) >> 6; (bb << 6) < incl; bb++) s_blk[bb] = (uint16_t)tid;
+            __syncthreads();
+            const int32_t total = s_pref[PT_THREADS - 1];
+            for (int32_t jb = 0; jb < total; jb += PT_THREADS * PT_BPL) {
+                int lcv[PT_BPL], basev[PT_BPL], rv[PT_BPL];
+                bool ok[PT_BPL];
+#pragma unroll
+                for (int u = 0; u < PT_BPL; u++) {
+                    const int32_t j = jb + u * PT_THREADS + tid;
+                    ok[u] = j < total;
+                    int owc = ok[u] ? s_blk[j >> 6] : 0;
+                    while (ok[u] && s_pref[owc] <= j) owc++;
+                    const int32_t i = j + s_i0[owc];
+                    lcv[u] = (int)((int64_t)s_col0[owc] + i - tlo);
+                    const int64_t bi = s_base[owc] + i;
+                    rv[u] = s_opfl[owc] & 1;
+                    if (ok[u] && bi >= p_seqend[s_opair[owc]]) { set_status(a.diag, PV_ERR_INVALID); ok[u] = false; }
+                    basev[u] = ok[u] ? a.in.bases[bi] : 0;
+                }
+#pragma unroll
+                for (int u = 0; u < PT_BPL; u++) {
+                    if (!ok[u]) continue;
+                    atomicAdd(&s_cnt[Q_F + polish_feature(s_lut[basev[u]], rv[u] != 0)][lcv[u]], 1);  // :70-74
+                }
+            }
+            __syncthreads();
+        }
+        __syncthreads();
+    }
+    __syncthreads();
+    const int64_t NC = a.n_cols;
+    int64_t ncol = NC - tlo;
+    if (ncol > TILE_COLS) ncol = TILE_COLS;
+    for (int lc = tid; lc < ncol; lc += PT_THREADS) {
+        const int64_t g = tlo + lc;
+        int cov = s_cnt[Q_DCOV][lc];
+#pragma unroll
+        for (int f = 0; f < 10; f++) {
+            const int v = s_cnt[Q_F + f][lc];
+            cov += v;  // every aligned base bumps coverage once (:72-73)
+            a.pcnt[(int64_t)f * NC + g] = v + (f == 8 ? s_cnt[Q_STAR][lc] : f == 9 ? s_cnt[Q_STAR + 1][lc] : 0);
+        }
+        a.pcnt[(int64_t)PC_COV * NC + g] = cov;
+        a.pcnt[(int64_t)PC_LONG * NC + g] = s_cnt[Q_LONG][lc];
+    }
+}
+
+// insert rows per 1024-column block (columns of the reference buffer beyond R never get an insert: the tile kernel clips)
+__global__ __launch_bounds__(1024) void k_polish_blk(SumArgs a) {
+    __shared__ int32_t s_w[16];
+    const int64_t col = (int64_t)blockIdx.x * 1024 + threadIdx.x;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int32_t v = col < a.n_cols ? a.pcnt[(int64_t)PC_LONG * a.n_cols + col] : 0;
+    const int32_t inc = wave_incl_scan32(v, lane);
+    if (lane == 63) s_w[wv] = inc;
+    __syncthreads();
+    if (threadIdx.x == 0) { int32_t t = 0; for (int k = 0; k < 16; k++) t += s_w[k]; a.ins_blk[blockIdx.x] = t; }
+}
+
+__global__ __launch_bounds__(1024) void k_polish_insoff(SumArgs a) {
+    __shared__ int32_t s_w[16];
+    const int64_t col = (int64_t)blockIdx.x * 1024 + threadIdx.x;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int32_t v = col < a.n_cols ? a.pcnt[(int64_t)PC_LONG * a.n_cols + col] : 0;
+    const int32_t inc = wave_incl_scan32(v, lane);
+    if (lane == 63) s_w[wv] = inc;
+    __syncthreads();
+    int32_t woff = 0;
+    for (int k = 0; k < wv; k++) woff += s_w[k];
+    const int32_t excl = a.ins_blkoff[blockIdx.x] + woff + inc - v;
+    if (col < a.n_cols) a.ins_off[col] = excl;
+    if (col == a.n_cols - 1) a.ins_off[a.n_cols] = excl + v;
+}
+
+// row / chunk layout of the regions (sequential over the few regions of a batch), limits, counters
+__global__ void k_polish_regions(SumArgs a) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    int64_t rows = 0, chunks = 0;
+    for (int g = 0; g < a.in.n_regions; g++) {
+        a.reg_rows[g] = rows;
+        a.reg_chunks[g] = chunks;
+        const int64_t R = a.in.ref_end[g] - a.in.ref_start[g] + 1;
+        const int64_t c0 = a.in.ref_off[g];
+        const int64_t n = R + (a.ins_off[c0 + R] - a.ins_off[c0]);
+        rows += n;
+        // AlignmentSummarizer.chunk_images (AlignmentSummarizer.py:19-56): starts 0, L-O, 2(L-O), ... until a chunk ends at n
+        chunks += n <= a.seq_len ? 1 : 1 + (n - a.seq_len + a.seq_step - 1) / a.seq_step;
+    }
+    a.reg_rows[a.in.n_regions] = rows;
+    a.reg_chunks[a.in.n_regions] = chunks;
+    a.diag[D_NROWS] = rows;
+    a.diag[D_NCHUNKS] = chunks;
+    if (a.diag[D_NINS] > a.max_ins_rows) set_status(a.diag, PV_ERR_LIMIT);
+    a.d_counts[0] = chunks;
+    a.d_counts[1] = rows;
+    a.d_counts[2] = a.diag[D_STATUS];
+    a.d_counts[3] = a.diag[D_NINS];
+}
+
+// thread per CIGAR op: the bases of every in-region insert, counted on its insert rows (:88-93)
+__global__ __launch_bounds__(256) void k_polish_insert(SumArgs a) {
+    const int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (c >= a.n_cigar || a.diag[D_STATUS] != 0 || a.op_flag[c] != 1) return;
+    const uint32_t w = a.in.cigar[c];
+    const int32_t len = (int32_t)(w >> 4);
+    const int32_t r = a.op_read[c];
+    const int g = a.read_region[r];
+    const int64_t col = a.in.ref_off[g] + a.op_ref[c] - 1;
+    const int64_t row = a.ins_off[col];
+    const int64_t b0 = a.in.base_off[r] + a.op_rd[c];
+    const bool rev = (a.in.read_flags[r] & 1) != 0;
+    for (int32_t i = 0; i < len; i++)
+        atomicAdd(&a.ins_cnt[(row + i) * 10 + polish_feature(polish_sym(a.in.bases[b0 + i]), rev)], 1);
+}
+
+__device__ __forceinline__ uint8_t polish_pixel(int32_t cnt, int32_t cov) {  // generate_image, :281 / :293-294
+    const double v = ((double)cnt / ((double)cov > 1.0 ? (double)cov : 1.0)) * 254.0;
+    return (uint8_t)(uint32_t)(int32_t)v;
+}
+
+// thread per column: its base row and its insert rows
+__global__ __launch_bounds__(256) void k_polish_image(SumArgs a) {
+    const int64_t col = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (col >= a.n_cols || a.diag[D_STATUS] != 0) return;
+    const int g = upper_bound_i64(a.in.ref_off, a.in.n_regions + 1, col) - 1;
+    if (g < 0 || g >= a.in.n_regions) return;
+    const int64_t c0 = a.in.ref_off[g];
+    const int64_t i = col - c0;
+    if (i >= a.in.ref_end[g] - a.in.ref_start[g] + 1) return;
+    const int64_t NC = a.n_cols;
+    const int64_t ins0 = a.ins_off[col];
+    int64_t row = a.reg_rows[g] + i + (ins0 - a.ins_off[c0]);
+    const int32_t cov = a.pcnt[(int64_t)PC_COV * NC + col];
+    const int32_t nl = a.pcnt[(int64_t)PC_LONG * NC + col];
+    const int64_t pos = a.in.ref_start[g] + i;
+    if (row < a.flat_cap) {
+#pragma unroll
+        for (int f = 0; f < 10; f++) a.flat_img[row * 10 + f] = polish_pixel(a.pcnt[(int64_t)f * NC + col], cov);
+        a.flat_pos[row] = pos;
+        a.flat_idx[row] = 0;
+    }
+    for (int32_t ii = 0; ii < nl; ii++) {
+        row++;
+        if (row >= a.flat_cap) break;
+#pragma unroll
+        for (int f = 0; f < 10; f++) a.flat_img[row * 10 + f] = polish_pixel(a.ins_cnt[(ins0 + ii) * 10 + f], cov);
+        a.flat_pos[row] = pos;
+        a.flat_idx[row] = ii + 1;
+    }
+}
+
+// thread per (chunk, row): gather from the flat rows, or pad
+__global__ __launch_bounds__(256) void k_polish_chunks(SumArgs a) {
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (a.diag[D_STATUS] != 0) return;
+    int64_t nck = a.diag[D_NCHUNKS];
+    if (nck > a.pout.chunk_capacity) nck = a.pout.chunk_capacity;
+    const int64_t k = t / a.seq_len;
+    if (k >= nck) return;
+    const int j = (int)(t - k * a.seq_len);
+    const int g = upper_bound_i64(a.reg_chunks, a.in.n_regions + 1, k) - 1;
+    const int64_t kk = k - a.reg_chunks[g];
+    const int64_t rows = a.reg_rows[g + 1] - a.reg_rows[g];
+    const int64_t r = kk * a.seq_step + j;
+    if (j == 0) { a.pout.region[k] = g; a.pout.chunk_id[k] = (int32_t)kk; }
+    uint8_t* dst = a.pout.images + t * 10;
+    if (r < rows && a.reg_rows[g] + r < a.flat_cap) {
+        const int64_t src = a.reg_rows[g] + r;
+#pragma unroll
+        for (int f = 0; f < 10; f++) dst[f] = a.flat_img[src * 10 + f];
+        a.pout.position[t] = a.flat_pos[src];
+        a.pout.index[t] = a.flat_idx[src];
+    } else {
+#pragma unroll
+        for (int f = 0; f < 10; f++) dst[f] = 0;
+        a.pout.position[t] = -1;
+        a.pout.index[t] = -1;
+    }
+}
+
 __global__ void k_zero_diag(int64_t* diag) {
     if (threadIdx.x < D_NDIAG) diag[threadIdx.x] = 0;
 }
@@ -1193,5 +1498,206 @@ extern "C" int pv_summarize_regions(pv_ctx* ctx, const pv_batch_in* in, const pv
         PV_HIP(hipMemcpyAsync(out->cand_off, dout.cand_off, (n + 1) * sizeof(int64_t), hipMemcpyDeviceToHost, st));
         PV_HIP(hipStreamSynchronize(st));
     }
+    return PV_OK;
+}
+
+// ==== P2 (polisher) summary images: launch sequence and C-ABI ===========================================
+static int polish_launch(pv_ctx* ctx, const pv_batch_in* in, int64_t n_reads, int64_t n_bases, int64_t n_cigar,
+                         int64_t n_cols, int64_t max_pairs, int64_t max_ins_rows, int seq_length, int seq_overlap,
+                         const pv_polish_out* out, int64_t* d_counts, hipStream_t st) {
+    PV_CHECK(seq_length >= 1 && seq_overlap >= 0 && seq_overlap < seq_length, PV_ERR_INVALID,
+             "need 0 <= seq_overlap < seq_length (got %d, %d)", seq_overlap, seq_length);
+    PV_CHECK(n_cols < (1ll << 31) - 2048 && n_cigar < (1ll << 31) && n_reads < (1ll << 31), PV_ERR_LIMIT,
+             "batch too large for 32-bit column/op indices (cols %lld, ops %lld)", (long long)n_cols, (long long)n_cigar);
+    SumArgs a;
+    memset(&a, 0, sizeof(a));
+    a.in = *in;
+    a.polish = 1;
+    a.seq_len = seq_length;
+    a.seq_step = seq_length - seq_overlap;
+    a.n_reads = n_reads; a.n_bases = n_bases; a.n_cigar = n_cigar; a.n_cols = n_cols;
+    a.max_pairs = max_pairs;
+    a.max_ins_rows = max_ins_rows;
+    a.pout = *out;
+    a.d_counts = d_counts;
+    a.n_tiles = (n_cols + TILE_COLS - 1) / TILE_COLS;
+    const int64_t n_blk = (n_cols + 1023) / 1024;
+    const int64_t nc1 = n_cigar > 0 ? n_cigar : 1, nr1 = n_reads > 0 ? n_reads : 1, G = in->n_regions;
+    int rc;
+    if ((rc = pv_get(ctx, "sum.op_ref", nc1, &a.op_ref))) return rc;
+    if ((rc = pv_get(ctx, "sum.op_rd", nc1, &a.op_rd))) return rc;
+    if ((rc = pv_get(ctx, "sum.op_read", nc1, &a.op_read))) return rc;
+    if ((rc = pv_get(ctx, "sum.op_flag", nc1, &a.op_flag))) return rc;
+    if ((rc = pv_get(ctx, "sum.read_region", nr1, &a.read_region))) return rc;
+    if ((rc = pv_get(ctx, "sum.read_t0", nr1, &a.read_t0))) return rc;
+    if ((rc = pv_get(ctx, "sum.read_t1", nr1, &a.read_t1))) return rc;
+    if ((rc = pv_get(ctx, "sum.tile_cnt", a.n_tiles, &a.tile_cnt))) return rc;
+    if ((rc = pv_get(ctx, "sum.tile_off", a.n_tiles, &a.tile_off))) return rc;
+    if ((rc = pv_get(ctx, "sum.tile_fill", a.n_tiles, &a.tile_fill))) return rc;
+    if ((rc = pv_get(ctx, "sum.pairs", max_pairs, &a.pairs))) return rc;
+    if ((rc = pv_get(ctx, "pol.pcnt", (size_t)PC_N * n_cols, &a.pcnt))) return rc;
+    if ((rc = pv_get(ctx, "pol.ins_blk", n_blk, &a.ins_blk))) return rc;
+    if ((rc = pv_get(ctx, "pol.ins_blkoff", n_blk, &a.ins_blkoff))) return rc;
+    if ((rc = pv_get(ctx, "pol.ins_off", n_cols + 1, &a.ins_off))) return rc;
+    if ((rc = pv_get(ctx, "pol.ins_cnt", (size_t)(max_ins_rows > 0 ? max_ins_rows : 1) * 10, &a.ins_cnt))) return rc;
+    if ((rc = pv_get(ctx, "pol.reg_rows", (size_t)G + 1, &a.reg_rows))) return rc;
+    if ((rc = pv_get(ctx, "pol.reg_chunks", (size_t)G + 1, &a.reg_chunks))) return rc;
+    if ((rc = pv_get(ctx, "sum.diag", (size_t)D_NDIAG, &a.diag))) return rc;
+    if (out->flat_images) {
+        PV_CHECK(out->flat_position && out->flat_index, PV_ERR_INVALID, "flat_position / flat_index missing");
+        a.flat_img = out->flat_images; a.flat_pos = out->flat_position; a.flat_idx = out->flat_index;
+        a.flat_cap = out->row_capacity;
+    } else {
+        a.flat_cap = n_cols + max_ins_rows;
+        if ((rc = pv_get(ctx, "pol.flat_img", (size_t)a.flat_cap * 10, &a.flat_img))) return rc;
+        if ((rc = pv_get(ctx, "pol.flat_pos", (size_t)a.flat_cap, &a.flat_pos))) return rc;
+        if ((rc = pv_get(ctx, "pol.flat_idx", (size_t)a.flat_cap, &a.flat_idx))) return rc;
+    }
+
+    pv_prof_scope ps_all(ctx, "polish_pipeline", st);
+    k_zero_diag<<<1, 64, 0, st>>>(a.diag);
+    PV_HIP(hipMemsetAsync(a.tile_cnt, 0, (size_t)a.n_tiles * sizeof(int32_t), st));
+    PV_HIP(hipMemsetAsync(a.tile_fill, 0, (size_t)a.n_tiles * sizeof(int32_t), st));
+    PV_HIP(hipMemsetAsync(a.ins_cnt, 0, (size_t)(max_ins_rows > 0 ? max_ins_rows : 1) * 10 * sizeof(int32_t), st));
+    if (n_reads > 0) { pv_prof_scope ps(ctx, "k_cigar_scan", st); k_cigar_scan<<<grid_for(n_reads, 4), 256, 0, st>>>(a); }
+    k_scan_i32<<<1, 1024, 0, st>>>(a.tile_cnt, a.tile_off, a.n_tiles, nullptr, a.n_tiles, &a.diag[D_NPAIRS]);
+    k_check_pairs<<<1, 1, 0, st>>>(a);
+    if (n_reads > 0) { pv_prof_scope ps(ctx, "k_tile_fill", st); k_tile_fill<<<grid_for(n_reads, 4), 256, 0, st>>>(a); }
+    { pv_prof_scope ps(ctx, "k_polish_tiles", st); k_polish_tiles<<<(unsigned)a.n_tiles, PT_THREADS, 0, st>>>(a); }
+    k_polish_blk<<<(unsigned)n_blk, 1024, 0, st>>>(a);
+    k_scan_i32<<<1, 1024, 0, st>>>(a.ins_blk, a.ins_blkoff, n_blk, nullptr, n_blk, &a.diag[D_NINS]);
+    k_polish_insoff<<<(unsigned)n_blk, 1024, 0, st>>>(a);
+    k_polish_regions<<<1, 1, 0, st>>>(a);
+    if (n_cigar > 0) { pv_prof_scope ps(ctx, "k_polish_insert", st); k_polish_insert<<<grid_for(n_cigar, 256), 256, 0, st>>>(a); }
+    { pv_prof_scope ps(ctx, "k_polish_image", st); k_polish_image<<<grid_for(n_cols, 256), 256, 0, st>>>(a); }
+    if (out->chunk_capacity > 0 && out->images) {
+        PV_CHECK(out->position && out->index && out->region && out->chunk_id, PV_ERR_INVALID, "chunk output arrays missing");
+        pv_prof_scope ps(ctx, "k_polish_chunks", st);
+        k_polish_chunks<<<grid_for(out->chunk_capacity * seq_length, 256), 256, 0, st>>>(a);
+    }
+    if (out->region_row_off)
+        PV_HIP(hipMemcpyAsync(out->region_row_off, a.reg_rows, (size_t)(G + 1) * sizeof(int64_t), hipMemcpyDeviceToDevice, st));
+    PV_HIP(hipGetLastError());
+    return PV_OK;
+}
+
+static void polish_limits(int64_t n_cols, int64_t n_bases, int64_t n_reads, int64_t* max_pairs, int64_t* max_ins_rows) {
+    *max_pairs = 2 * (n_bases / TILE_COLS) + 3 * n_reads + 64;
+    *max_ins_rows = 2 * n_cols + 4096;  // 60x ONT (2 % inserts of 1-3 bases) adds ~1.5 insert rows per column; the device reports overflow
+}
+
+extern "C" int pv_polish_summarize_regions_dev(pv_ctx* ctx, const pv_batch_in* in, int64_t n_reads, int64_t n_bases,
+                                               int64_t n_cigar, int64_t n_ref_bytes, int seq_length, int seq_overlap,
+                                               pv_polish_out* out, int64_t* d_counts, void* stream) {
+    PV_CHECK(ctx && in && out && d_counts, PV_ERR_INVALID, "null argument");
+    PV_CHECK(in->n_regions >= 0 && n_ref_bytes >= 0, PV_ERR_INVALID, "negative sizes");
+    PV_HIP(hipSetDevice(ctx->device));
+    int64_t mp, mi;
+    polish_limits(n_ref_bytes, n_bases, n_reads, &mp, &mi);
+    if (out->flat_images && out->row_capacity > n_ref_bytes && out->row_capacity - n_ref_bytes > mi) mi = out->row_capacity - n_ref_bytes;
+    return polish_launch(ctx, in, n_reads, n_bases, n_cigar, n_ref_bytes > 0 ? n_ref_bytes : 1, mp, mi, seq_length, seq_overlap,
+                         out, d_counts, pv_pick_stream(ctx, stream));
+}
+
+extern "C" int pv_polish_summarize_regions(pv_ctx* ctx, const pv_batch_in* in, int seq_length, int seq_overlap,
+                                           pv_polish_out* out) {
+    PV_CHECK(ctx && in && out, PV_ERR_INVALID, "null argument");
+    PV_HIP(hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    const int G = in->n_regions;
+    out->n_chunks = 0;
+    out->n_rows = 0;
+    if (G <= 0) return PV_OK;
+    const int64_t n_reads = in->read_off[G], n_cols = in->ref_off[G];
+    PV_CHECK(in->read_off[0] == 0 && in->ref_off[0] == 0 && n_reads >= 0, PV_ERR_INVALID, "offset arrays must start at 0");
+    for (int g = 0; g < G; g++) {
+        const int64_t R = in->ref_end[g] - in->ref_start[g] + 1;
+        PV_CHECK(R >= 1 && in->ref_off[g + 1] - in->ref_off[g] >= R, PV_ERR_INVALID,
+                 "region %d: reference shorter than ref_end-ref_start+1", g);
+        PV_CHECK(in->read_off[g + 1] >= in->read_off[g], PV_ERR_INVALID, "read_off not monotone");
+    }
+    const int64_t n_bases = n_reads ? in->base_off[n_reads] : 0, n_cigar = n_reads ? in->cigar_off[n_reads] : 0;
+    for (int64_t r = 0; r < n_reads; r++)
+        PV_CHECK(in->base_off[r + 1] >= in->base_off[r] && in->cigar_off[r + 1] >= in->cigar_off[r], PV_ERR_INVALID,
+                 "read %lld: offsets not monotone", (long long)r);
+
+    pv_batch_in d = *in;
+    int rc;
+    if ((rc = upload(ctx, "in.ref_start", in->ref_start, G, &d.ref_start, st))) return rc;
+    if ((rc = upload(ctx, "in.ref_end", in->ref_end, G, &d.ref_end, st))) return rc;
+    if ((rc = upload(ctx, "in.ref_off", in->ref_off, G + 1, &d.ref_off, st))) return rc;
+    d.cand_start = d.ref_start; d.cand_end = d.ref_end; d.ref = nullptr; d.quals = nullptr;  // not read by the polisher kernels
+    if ((rc = upload(ctx, "in.read_off", in->read_off, G + 1, &d.read_off, st))) return rc;
+    if ((rc = upload(ctx, "in.read_pos", in->read_pos, n_reads, &d.read_pos, st))) return rc;
+    if ((rc = upload(ctx, "in.read_flags", in->read_flags, n_reads, &d.read_flags, st))) return rc;
+    if ((rc = upload(ctx, "in.read_mapq", in->read_mapq, n_reads, &d.read_mapq, st))) return rc;
+    if ((rc = upload(ctx, "in.base_off", in->base_off, n_reads + 1, &d.base_off, st))) return rc;
+    if ((rc = upload(ctx, "in.bases", in->bases, n_bases, &d.bases, st))) return rc;
+    if ((rc = upload(ctx, "in.cigar_off", in->cigar_off, n_reads + 1, &d.cigar_off, st))) return rc;
+    if ((rc = upload(ctx, "in.cigar", in->cigar, n_cigar, &d.cigar, st))) return rc;
+
+    const int64_t ccap = out->chunk_capacity > 0 ? out->chunk_capacity : 0, rcap = out->flat_images ? out->row_capacity : 0;
+    pv_polish_out dout = *out;
+    dout.chunk_capacity = ccap;
+    dout.row_capacity = rcap;
+    const size_t L = (size_t)seq_length;
+    if ((rc = pv_get(ctx, "pout.images", (ccap + 1) * L * 10, &dout.images))) return rc;
+    if ((rc = pv_get(ctx, "pout.position", (ccap + 1) * L, &dout.position))) return rc;
+    if ((rc = pv_get(ctx, "pout.index", (ccap + 1) * L, &dout.index))) return rc;
+    if ((rc = pv_get(ctx, "pout.region", (size_t)ccap + 1, &dout.region))) return rc;
+    if ((rc = pv_get(ctx, "pout.chunk_id", (size_t)ccap + 1, &dout.chunk_id))) return rc;
+    dout.flat_images = nullptr; dout.flat_position = nullptr; dout.flat_index = nullptr; dout.region_row_off = nullptr;
+    if (out->flat_images) {
+        PV_CHECK(out->flat_position && out->flat_index, PV_ERR_INVALID, "flat_position / flat_index missing");
+        if ((rc = pv_get(ctx, "pout.flat_images", (size_t)(rcap + 1) * 10, &dout.flat_images))) return rc;
+        if ((rc = pv_get(ctx, "pout.flat_position", (size_t)rcap + 1, &dout.flat_position))) return rc;
+        if ((rc = pv_get(ctx, "pout.flat_index", (size_t)rcap + 1, &dout.flat_index))) return rc;
+    }
+    if (out->region_row_off)
+        if ((rc = pv_get(ctx, "pout.region_row_off", (size_t)G + 1, &dout.region_row_off))) return rc;
+    int64_t* d_counts = nullptr;
+    if ((rc = pv_get(ctx, "out.counts", (size_t)4, &d_counts))) return rc;
+
+    int64_t mp, mi;
+    polish_limits(n_cols, n_bases, n_reads, &mp, &mi);
+    if (rcap > n_cols && rcap - n_cols > mi) mi = rcap - n_cols;
+    for (int attempt = 0; attempt < 3; attempt++) {
+        rc = polish_launch(ctx, &d, n_reads, n_bases, n_cigar, n_cols, mp, mi, seq_length, seq_overlap, &dout, d_counts, st);
+        if (rc) return rc;
+        PV_HIP(hipMemcpyAsync(ctx->h_counts, d_counts, 4 * sizeof(int64_t), hipMemcpyDeviceToHost, st));
+        PV_HIP(hipStreamSynchronize(st));
+        if (ctx->h_counts[2] == PV_ERR_LIMIT && attempt < 2) {  // workspace heuristics too small: take what the device measured
+            mp = n_reads * ((n_cols + TILE_COLS - 1) / TILE_COLS + 2);
+            if (ctx->h_counts[3] > mi) mi = ctx->h_counts[3];
+            continue;
+        }
+        break;
+    }
+    const int64_t status = ctx->h_counts[2];
+    PV_CHECK(status != PV_ERR_INVALID, PV_ERR_INVALID, "malformed read: CIGAR walks past the end of its bases");
+    PV_CHECK(status == 0, (int)status, "device status %lld", (long long)status);
+    out->n_chunks = ctx->h_counts[0];
+    out->n_rows = ctx->h_counts[1];
+    if (out->n_chunks > ccap || (out->flat_images && out->n_rows > rcap)) {
+        pv_set_error("output capacity too small: need %lld chunks, %lld rows", (long long)out->n_chunks, (long long)out->n_rows);
+        return PV_ERR_CAPACITY;
+    }
+    const size_t n = (size_t)out->n_chunks;
+    if (n > 0 && out->images) {
+        PV_HIP(hipMemcpyAsync(out->images, dout.images, n * L * 10, hipMemcpyDeviceToHost, st));
+        PV_HIP(hipMemcpyAsync(out->position, dout.position, n * L * sizeof(int64_t), hipMemcpyDeviceToHost, st));
+        PV_HIP(hipMemcpyAsync(out->index, dout.index, n * L * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+        PV_HIP(hipMemcpyAsync(out->region, dout.region, n * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+        PV_HIP(hipMemcpyAsync(out->chunk_id, dout.chunk_id, n * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    }
+    if (out->flat_images && out->n_rows > 0) {
+        const size_t nr = (size_t)out->n_rows;
+        PV_HIP(hipMemcpyAsync(out->flat_images, dout.flat_images, nr * 10, hipMemcpyDeviceToHost, st));
+        PV_HIP(hipMemcpyAsync(out->flat_position, dout.flat_position, nr * sizeof(int64_t), hipMemcpyDeviceToHost, st));
+        PV_HIP(hipMemcpyAsync(out->flat_index, dout.flat_index, nr * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    }
+    if (out->region_row_off)
+        PV_HIP(hipMemcpyAsync(out->region_row_off, dout.region_row_off, (size_t)(G + 1) * sizeof(int64_t), hipMemcpyDeviceToHost, st));
+    PV_HIP(hipStreamSynchronize(st));
     return PV_OK;
 }

@@ -61,3 +61,28 @@ class DeviceOut:
 
     def status(self) -> int:
         return int(self.counts[2].item())
+
+
+class DevicePolishOut:
+    """Caller-owned chunk arrays of pv_polish_out in HBM (the polisher's image batches, input of forward_p2_dev)."""
+
+    def __init__(self, chunk_capacity: int, seq_length: int = 1000, seq_overlap: int = 50, device="cuda:0"):
+        self.capacity, self.seq_length, self.seq_overlap = int(chunk_capacity), int(seq_length), int(seq_overlap)
+        self.images = torch.zeros((chunk_capacity, seq_length, 10), dtype=torch.uint8, device=device)
+        self.position = torch.zeros((chunk_capacity, seq_length), dtype=torch.int64, device=device)
+        self.index = torch.zeros((chunk_capacity, seq_length), dtype=torch.int32, device=device)
+        self.region = torch.zeros(chunk_capacity, dtype=torch.int32, device=device)
+        self.chunk_id = torch.zeros(chunk_capacity, dtype=torch.int32, device=device)
+        self.counts = torch.zeros(4, dtype=torch.int64, device=device)
+        c = _ffi.pv_polish_out()
+        c.chunk_capacity, c.row_capacity = self.capacity, 0
+        c.images, c.position, c.index = self.images.data_ptr(), self.position.data_ptr(), self.index.data_ptr()
+        c.region, c.chunk_id = self.region.data_ptr(), self.chunk_id.data_ptr()
+        c.flat_images = c.flat_position = c.flat_index = c.region_row_off = None
+        self.c = c
+
+    def n_chunks(self) -> int:
+        return int(self.counts[0].item())
+
+    def status(self) -> int:
+        return int(self.counts[2].item())

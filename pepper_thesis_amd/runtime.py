@@ -131,6 +131,10 @@ class Context:
                                               None if acc is None else acc.ctypes.data))
         return (labels, acc) if want_acc else labels
 
+    def forward_p2_dev(self, d_images: int, B: int, d_labels: int, d_acc: int = 0, stream: int = 0):
+        """asynchronous; device pointers: images uint8 [B,1000,10] -> labels uint8 [B,1000] (+ acc float [B,1000,5])."""
+        _ffi.check(self.lib.pv_rnn_forward_p2_dev(self.handle, d_images, int(B), d_labels, d_acc or None, stream or None))
+
     def forward_p2_window(self, images: np.ndarray, hidden: Optional[np.ndarray] = None):
         """TransducerGRU.forward(x, hidden): images uint8 [B,100,10], hidden [B,2,128] or None -> (logits [B,100,5], hidden [B,2,128])"""
         x = np.ascontiguousarray(images, dtype=np.uint8)
@@ -151,6 +155,18 @@ class Context:
         _ffi.check(self.lib.pv_summarize_regions_dev(
             self.handle, C.byref(dbatch.c), C.byref(cp), dbatch.n_reads, dbatch.n_bases, dbatch.n_cigar,
             dbatch.n_ref_bytes, dbatch.max_region_len, C.byref(dout.c), dout.counts.data_ptr(), stream or None))
+
+    def polish_summarize(self, batch: RegionBatch, seq_length: int = 1000, seq_overlap: int = 50, want_flat: bool = False):
+        """Polisher (P2) SummaryGenerator.generate_summary + chunk_images for a batch (host buffers), see polish_summary.py."""
+        from .polish_summary import polish_summarize
+        return polish_summarize(self, batch, seq_length, seq_overlap, want_flat)
+
+    def polish_summarize_dev(self, dbatch: "DeviceBatch", dout: "DevicePolishOut", stream: int = 0):
+        """asynchronous, device-resident: chunks land in dout.images ([capacity, seq_length, 10] uint8 in HBM), ready
+        for forward_p2_dev; counters {n_chunks, n_rows, status, insert rows} in dout.counts."""
+        _ffi.check(self.lib.pv_polish_summarize_regions_dev(
+            self.handle, C.byref(dbatch.c), dbatch.n_reads, dbatch.n_bases, dbatch.n_cigar, dbatch.n_ref_bytes,
+            dout.seq_length, dout.seq_overlap, C.byref(dout.c), dout.counts.data_ptr(), stream or None))
 
     def profile_begin(self):
         _ffi.check(self.lib.pv_profile_begin(self.handle))
