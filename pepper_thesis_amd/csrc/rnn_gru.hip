@@ -29,10 +29,25 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 constexpr int SEQ = 1000, WIN = 100, JUMP = 50, NWIN = 19, FEAT = 10, NCLS = 5;
 constexpr int HG = 128;          // GRU hidden
 constexpr int ROWS = 32;         // chunks per workgroup
-constexpr int KPE = 16;          // encoder input padded to a multiple of 8
+constexpr int KPE = 32;          // encoder input (10 features) padded to four k-blocks of 8 (mma3_ring works in groups of 4)
 constexpr int KPD = 2 * HG;      // decoder input
 constexpr int LDH = HG + 4;      // LDS row strides (floats): % 64 == 4 keeps ds_read_b128 conflict-free
 constexpr int LDXD = KPD + 4;
+
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+// Raw buffer accesses: a 128-bit resource in SGPRs + one 32-bit lane offset + a scalar offset. Unlike global_load with
+// per-lane 64-bit addresses they need no address VGPRs at all, which is what keeps this kernel (64 accumulator + 48 ring
+// + 32 staging registers per lane) inside the register file.
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, 0x7fffffff, 0x00020000);
+}
+__device__ __forceinline__ f32x4 buf_load4(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
+}
+__device__ __forceinline__ void buf_store1(float v, __amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, voff, soff, 0);
+}
 
 __device__ __forceinline__ float rcpf_(float x) { return __builtin_amdgcn_rcpf(x); }
 __device__ __forceinline__ float sigmoidf_(float x) { return rcpf_(1.0f + __expf(-x)); }
@@ -87,6 +102,70 @@ __device__ __forceinline__ void mma3(f32x16& c0, f32x16& c1, f32x16& c2, const f
     }
 }
 
+// One K loop over [x_t | h_{t-1}] for the three gate tiles of a wave: r and z accumulate both products, n keeps its x- and
+// h-parts apart (anx / anh, PyTorch's GRU: n = tanh(W_in x + b_in + r * (W_hn h + b_hn))). The packed weight stream is
+// contiguous over both operands. B fragments come from L2 (~1 us away) while a k-block is only 12 MFMAs (0.33 us), so they
+// run in a ring of four register sets requested THREE k-blocks ahead; with the one-block-ahead scheme of mma3 every k-block
+// waited out an L2 round trip (measured 30 us per GRU step against 11 us of MFMA work). A fragments (LDS) are fetched one
+// block ahead. The ring wraps around: the last group of a step already requests k-blocks 0..2 of the next step (same weights
+// every step), which arrive during the cell update and the barriers, so a step does not start with a cold L2 round trip.
+// `bq` lives in the caller (slots 0..2 must hold k-blocks 0..2 on entry). nkbx and nkbh are multiples of 4.
+__device__ __forceinline__ void mma3_ring(f32x16& ar, f32x16& az, f32x16& anx, f32x16& anh, const float* __restrict__ X,
+                                          int ldx, int nkbx, const float* __restrict__ Hh, int ldh, int nkbh,
+                                          __amdgpu_buffer_rsrc_t wr, f32x4 (&bq)[4][3], int lane) {
+    const float* apx = X + (lane & 31) * ldx + 4 * (lane >> 5);
+    const float* aph = Hh + (lane & 31) * ldh + 4 * (lane >> 5) - 8 * nkbx;
+    const int nkb = nkbx + nkbh;
+    const unsigned lane16 = (unsigned)lane * 16u;
+    f32x4 aq[2];
+#define G_B(slot, kbv) { _Pragma("unroll") for (int nt = 0; nt < 3; nt++) bq[slot][nt] = buf_load4(wr, lane16, (unsigned)(((kbv) * 3 + nt) * 1024)); }
+#define G_A(slot, kbv) { aq[slot] = *reinterpret_cast<const f32x4*>(((kbv) < nkbx ? apx : aph) + 8 * (kbv)); }
+#define G_M(bs, as, CN)                                                                              \
+    {                                                                                                \
+        _Pragma("unroll") for (int j = 0; j < 4; j++) {                                              \
+            ar = __builtin_amdgcn_mfma_f32_32x32x2f32(aq[as][j], bq[bs][0][j], ar, 0, 0, 0);         \
+            az = __builtin_amdgcn_mfma_f32_32x32x2f32(aq[as][j], bq[bs][1][j], az, 0, 0, 0);         \
+            CN = __builtin_amdgcn_mfma_f32_32x32x2f32(aq[as][j], bq[bs][2][j], CN, 0, 0, 0);         \
+        }                                                                                            \
+    }
+#define G_FENCE __builtin_amdgcn_sched_barrier(0); /* keep hipcc from sinking the prefetches next to their uses */
+#define G_GROUP(CN)                          \
+    {                                        \
+        G_B(3, kb + 3)                       \
+        G_A(1, kb + 1)                       \
+        G_FENCE                              \
+        G_M(0, 0, CN)                        \
+        G_FENCE                              \
+        const int kw = kb + 4 < nkb ? kb + 4 : 0; /* wrap: next step's first blocks */ \
+        G_B(0, kw)                           \
+        G_A(0, kb + 2)                       \
+        G_FENCE                              \
+        G_M(1, 1, CN)                        \
+        G_FENCE                              \
+        G_B(1, kw + 1)                       \
+        G_A(1, kb + 3)                       \
+        G_FENCE                              \
+        G_M(2, 0, CN)                        \
+        G_FENCE                              \
+        G_B(2, kw + 2)                       \
+        if (kb + 4 < nkb) G_A(0, kb + 4)     \
+        G_FENCE                              \
+        G_M(3, 1, CN)                        \
+        G_FENCE                              \
+    }
+    G_A(0, 0)
+    int kb = 0;
+#pragma nounroll
+    for (; kb < nkbx; kb += 4) G_GROUP(anx)
+#pragma nounroll
+    for (; kb < nkb; kb += 4) G_GROUP(anh)
+#undef G_B
+#undef G_A
+#undef G_M
+#undef G_GROUP
+#undef G_FENCE
+}
+
 struct GruArgs {
     const uint8_t* images;  // [B,1000,10]
     const float* enc_wp;    // packed [2 dirs][4 waves][(KPE+HG)/8 kb][3][64][4]
@@ -107,7 +186,10 @@ struct GruArgs {
     float* logits;          // [B,100,5] raw dense1 output of the LAST window, or NULL
 };
 
-// one GRU layer over one 100-column window for this wave's direction
+// one GRU layer over one 100-column window for this wave's direction.
+// Addressing: every global / LDS access is written as (wave-uniform base) + (32-bit lane offset computed once) so that
+// hipcc keeps the bases in SGPRs; with per-lane 64-bit addresses for the 8 x-loads, 16 h-stores and 12 weight loads of a
+// step the kernel spilled 150 VGPRs around the MFMA loop.
 template <int KP, bool ENC>
 __device__ __forceinline__ void gru_window(const GruArgs& a, int win_start, int dir, int wq, int lane, int tid_dir,
                                            int64_t b0, int tile, float* xbuf, float* hbuf, int& cur, f32x16& hst,
@@ -118,45 +200,51 @@ __device__ __forceinline__ void gru_window(const GruArgs& a, int win_start, int 
     const float b_r = bias[0 * HG + unit], b_z = bias[1 * HG + unit], b_in = bias[2 * HG + unit], b_hn = bias[3 * HG + unit];
     // register staging of x_t for this direction (256 threads per direction)
     constexpr int V4 = KP / 4;
-    constexpr int XR = ENC ? 1 : (ROWS * V4 + 255) / 256;
+    constexpr int XR = ENC ? 1 : (ROWS * V4) / 256;       // decoder: 8 float4 per thread, rows tid_dir/64 + 4u
+    constexpr int XE = ROWS * KPE / 256;                   // encoder: 4 floats per thread, rows tid_dir/32 + 8u
     f32x4 xr[XR];
-    float xe[ENC ? 2 : 1];  // encoder: 32 rows x 16 padded features = 512 floats / 256 threads
+    float xe[ENC ? XE : 1];
+    unsigned xoff[ENC ? XE : 1];                           // encoder: byte offset of (row's chunk, feature k) from the tile's first chunk
+    const unsigned xd_g = (unsigned)((tid_dir >> 6) * KPD + (tid_dir & 63) * 4);   // decoder: float offset in x_src[t]
+    const unsigned xd_l = (unsigned)((tid_dir >> 6) * LDX + (tid_dir & 63) * 4);   // ... and in xbuf
+    const unsigned xe_l = (unsigned)((tid_dir >> 5) * LDX + (tid_dir & 31));
+    const bool xe_valid = (tid_dir & 31) < FEAT;
+    if constexpr (ENC) {
+#pragma unroll
+        for (int u = 0; u < XE; u++) {
+            int64_t r = (tid_dir >> 5) + 8 * u;
+            if (b0 + r >= a.B) r = a.B - 1 - b0;
+            xoff[u] = (unsigned)(r * a.seq * FEAT) + (unsigned)(tid_dir & 31);
+        }
+    }
+    const uint8_t* img0 = a.images + ((size_t)b0 * a.seq + win_start) * FEAT;  // uniform
+    const __amdgpu_buffer_rsrc_t wr = make_rsrc(wp), xsr = make_rsrc(ENC ? (const void*)wp : (const void*)x_src), osr = make_rsrc(out_dst);
     auto x_load = [&](int t) {
         if constexpr (ENC) {
+            const uint8_t* src = img0 + t * FEAT;
 #pragma unroll
-            for (int u = 0; u < 2; u++) {
-                const int i = tid_dir + u * 256;
-                const int row = i / KPE, k = i - row * KPE;
-                int64_t b = b0 + row;
-                if (b >= a.B) b = a.B - 1;
-                xe[u] = k < FEAT ? (float)a.images[(b * a.seq + win_start + t) * FEAT + k] : 0.0f;
-            }
+            for (int u = 0; u < XE; u++) xe[u] = xe_valid ? (float)src[xoff[u]] : 0.0f;
         } else {
 #pragma unroll
-            for (int u = 0; u < XR; u++) {
-                const int i = tid_dir + u * 256;
-                const int row = i / V4, c4 = i - row * V4;
-                xr[u] = *reinterpret_cast<const f32x4*>(x_src + ((size_t)t * ROWS + row) * KPD + c4 * 4);
-            }
+            for (int u = 0; u < XR; u++) xr[u] = buf_load4(xsr, xd_g * 4u, (unsigned)((t * ROWS + u * 4) * KPD * 4));
         }
     };
     auto x_store = [&]() {
         if constexpr (ENC) {
 #pragma unroll
-            for (int u = 0; u < 2; u++) {
-                const int i = tid_dir + u * 256;
-                const int row = i / KPE, k = i - row * KPE;
-                xbuf[row * LDX + k] = xe[u];
-            }
+            for (int u = 0; u < XE; u++) (xbuf + u * 8 * LDX)[xe_l] = xe[u];
         } else {
 #pragma unroll
-            for (int u = 0; u < XR; u++) {
-                const int i = tid_dir + u * 256;
-                const int row = i / V4, c4 = i - row * V4;
-                *reinterpret_cast<f32x4*>(xbuf + row * LDX + c4 * 4) = xr[u];
-            }
+            for (int u = 0; u < XR; u++) *reinterpret_cast<f32x4*>(xbuf + u * 4 * LDX + xd_l) = xr[u];
         }
     };
+    f32x4 bq[4][3];  // weight-fragment ring of mma3_ring; slots 0..2 start with k-blocks 0..2
+#pragma unroll
+    for (int q = 0; q < 3; q++)
+#pragma unroll
+        for (int nt = 0; nt < 3; nt++) bq[q][nt] = buf_load4(wr, (unsigned)lane * 16u, (unsigned)((q * 3 + nt) * 1024));
+    const unsigned h_l = (unsigned)(4 * (lane >> 5) * LDH + unit);   // lane part of the h tile offset (row = 4*(lane>>5) + f(r))
+    const unsigned o_l = (unsigned)(4 * (lane >> 5) * KPD + unit);   // lane part of the output offset
     x_load(dir ? WIN - 1 : 0);
     x_store();
     __syncthreads();
@@ -167,9 +255,10 @@ __device__ __forceinline__ void gru_window(const GruArgs& a, int win_start, int 
         f32x16 ar, az, anx, anh;  // r and z accumulate both products; n keeps its x and h parts apart
 #pragma unroll
         for (int r = 0; r < 16; r++) { ar[r] = b_r; az[r] = b_z; anx[r] = b_in; anh[r] = b_hn; }
-        mma3(ar, az, anx, xbuf, LDX, wp, NKB_X, lane);
-        mma3(ar, az, anh, hbuf + cur * ROWS * LDH, LDH, wp + (size_t)NKB_X * 3 * 256, NKB_H, lane);
+        static_assert(NKB_X % 4 == 0 && NKB_H % 4 == 0, "mma3_ring works in groups of four k-blocks");
+        mma3_ring(ar, az, anx, anh, xbuf, LDX, NKB_X, hbuf + cur * ROWS * LDH, LDH, NKB_H, wr, bq, lane);
         float* hn = hbuf + nxt * ROWS * LDH;
+        const unsigned ob = (unsigned)((t * ROWS * KPD + dir * HG) * 4);  // uniform byte offset of (t, direction) in the scratch
 #pragma unroll
         for (int r = 0; r < 16; r++) {
             const float rg = sigmoidf_(ar[r]);
@@ -177,9 +266,9 @@ __device__ __forceinline__ void gru_window(const GruArgs& a, int win_start, int 
             const float ng = tanhf_(anx[r] + rg * anh[r]);
             const float h = (1.0f - zg) * ng + zg * hst[r];
             hst[r] = h;
-            const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-            hn[row * LDH + unit] = h;
-            out_dst[((size_t)t * ROWS + row) * KPD + dir * HG + unit] = h;
+            const int rr = (r & 3) + 8 * (r >> 2);  // compile-time part of the row
+            (hn + rr * LDH)[h_l] = h;
+            buf_store1(h, osr, o_l * 4u, ob + (unsigned)(rr * KPD * 4));
         }
         cur = nxt;
         __syncthreads();
@@ -194,7 +283,7 @@ __device__ __forceinline__ void gru_window(const GruArgs& a, int win_start, int 
 __global__ __launch_bounds__(512, 2) void k_gru_p2(GruArgs a) {
     extern __shared__ float smem[];
     // per direction: hbuf [2][32][LDH], xbuf [32][LDXD]
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);  // SGPR: bases derived from it stay scalar
     const int dir = wv >> 2, wq = wv & 3, tid_dir = tid & 255;
     float* hbuf = smem + dir * (2 * ROWS * LDH + ROWS * LDXD);
     float* xbuf = hbuf + 2 * ROWS * LDH;
