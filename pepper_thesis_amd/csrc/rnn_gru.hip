@@ -25,10 +25,10 @@ namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 constexpr int SEQ = 1000, WIN = 100, JUMP = 50, NWIN = 19, FEAT = 10, NCLS = 5;
 constexpr int HG = 128;          // GRU hidden
-constexpr int ROWS = 32;         // chunks per workgroup
 constexpr int KPE = 32;          // encoder input (10 features) padded to four k-blocks of 8 (mma3_ring works in groups of 4)
 constexpr int KPD = 2 * HG;      // decoder input
 constexpr int LDH = HG + 4;      // LDS row strides (floats): % 64 == 4 keeps ds_read_b128 conflict-free
@@ -56,77 +56,73 @@ __device__ __forceinline__ float tanhf_(float x) {
     return 1.0f - 2.0f * rcpf_(e + 1.0f);
 }
 
-// acc[nt] += A[32 x 8*nkb] . B for 3 gate tiles; see rnn_kernels.hip mma_panel for the fragment layout.
-__device__ __forceinline__ void mma3(f32x16& c0, f32x16& c1, f32x16& c2, const float* __restrict__ A, int lda,
-                                     const float* __restrict__ Bp, int nkb, int lane) {
-    const float* ap = A + (lane & 31) * lda + 4 * (lane >> 5);
-    const f32x4* bp = reinterpret_cast<const f32x4*>(Bp) + lane;
-    f32x4 b0[3], b1[3], a0, a1;
+// ---- batch-tile geometry ---------------------------------------------------------------------------------------------
+// TR = chunks (batch rows) per workgroup. 32 rows use v_mfma_f32_32x32x2_f32, 16 rows v_mfma_f32_16x16x4_f32: the same
+// FLOP per cycle, half the cycles per GRU step and twice the workgroups, which is what small batches need (a launch of
+// B chunks is a chain of 3800 dependent steps, so its duration is set by the per-step MFMA time of one workgroup, not by
+// B, until the workgroups fill the chip); the price is that every weight fragment feeds half as many rows, so the
+// 32-row form stays the choice once 32-row tiles fill all CUs.
+// Per wave: hidden units [32w, 32w+32) of the gates r, z, n. One "gate accumulator" holds those 32 units for TR rows.
+template <int TR> struct Gate;
+template <> struct Gate<32> { f32x16 v; };      // one 32x32 tile: lane -> unit lane&31, rows (e&3) + 8*(e>>2) + 4*(lane>>5)
+template <> struct Gate<16> { f32x4 v[2]; };    // two 16x16 tiles: lane -> unit 16*t + (lane&15), rows 4*(lane>>4) + i
+template <int TR> struct AFrag;
+template <> struct AFrag<32> { typedef f32x4 type; };  // A[row = lane&31][8kb + 4*(lane>>5) + j], j = 0..3
+template <> struct AFrag<16> { typedef f32x2 type; };  // A[row = lane&15][8kb + 2*(lane>>4) + j], j = 0..1
+
+template <int TR> __device__ __forceinline__ void gate_fill(Gate<TR>& g, float x) {
+    if constexpr (TR == 32) {
 #pragma unroll
-    for (int nt = 0; nt < 3; nt++) b0[nt] = bp[nt * 64];
-    a0 = *reinterpret_cast<const f32x4*>(ap);
-    int kb = 0;
-#pragma nounroll
-    for (; kb + 1 < nkb; kb += 2) {
+        for (int e = 0; e < 16; e++) g.v[e] = x;
+    } else {
 #pragma unroll
-        for (int nt = 0; nt < 3; nt++) b1[nt] = bp[((kb + 1) * 3 + nt) * 64];
-        a1 = *reinterpret_cast<const f32x4*>(ap + 8 * (kb + 1));
-#pragma unroll
-        for (int j = 0; j < 4; j++)
-        {
-            c0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[j], b0[0][j], c0, 0, 0, 0);
-            c1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[j], b0[1][j], c1, 0, 0, 0);
-            c2 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[j], b0[2][j], c2, 0, 0, 0);
-        }
-        if (kb + 2 < nkb) {
-#pragma unroll
-            for (int nt = 0; nt < 3; nt++) b0[nt] = bp[((kb + 2) * 3 + nt) * 64];
-            a0 = *reinterpret_cast<const f32x4*>(ap + 8 * (kb + 2));
-        }
-#pragma unroll
-        for (int j = 0; j < 4; j++)
-        {
-            c0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[j], b1[0][j], c0, 0, 0, 0);
-            c1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[j], b1[1][j], c1, 0, 0, 0);
-            c2 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[j], b1[2][j], c2, 0, 0, 0);
-        }
+        for (int e = 0; e < 4; e++) { g.v[0][e] = x; g.v[1][e] = x; }
     }
-    if (kb < nkb) {
-#pragma unroll
-        for (int j = 0; j < 4; j++)
-        {
-            c0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[j], b0[0][j], c0, 0, 0, 0);
-            c1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[j], b0[1][j], c1, 0, 0, 0);
-            c2 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[j], b0[2][j], c2, 0, 0, 0);
-        }
+}
+template <int TR> __device__ __forceinline__ float gate_get(const Gate<TR>& g, int e) {
+    if constexpr (TR == 32) return g.v[e];
+    else return g.v[e >> 2][e & 3];
+}
+// one k-step (j) of one gate: B fragment layout TR=32: b[j]; TR=16: {tile0 j0, tile0 j1, tile1 j0, tile1 j1}
+template <int TR> __device__ __forceinline__ void gate_mma(Gate<TR>& g, const typename AFrag<TR>::type& a, const f32x4& b, int j) {
+    if constexpr (TR == 32) {
+        g.v = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j], b[j], g.v, 0, 0, 0);
+    } else {
+        g.v[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j], b[j], g.v[0], 0, 0, 0);
+        g.v[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j], b[2 + j], g.v[1], 0, 0, 0);
     }
 }
 
-// One K loop over [x_t | h_{t-1}] for the three gate tiles of a wave: r and z accumulate both products, n keeps its x- and
+// One K loop over [x_t | h_{t-1}] for the three gates of a wave: r and z accumulate both products, n keeps its x- and
 // h-parts apart (anx / anh, PyTorch's GRU: n = tanh(W_in x + b_in + r * (W_hn h + b_hn))). The packed weight stream is
-// contiguous over both operands. B fragments come from L2 (~1 us away) while a k-block is only 12 MFMAs (0.33 us), so they
-// run in a ring of four register sets requested THREE k-blocks ahead; with the one-block-ahead scheme of mma3 every k-block
-// waited out an L2 round trip (measured 30 us per GRU step against 11 us of MFMA work). A fragments (LDS) are fetched one
-// block ahead. The ring wraps around: the last group of a step already requests k-blocks 0..2 of the next step (same weights
-// every step), which arrive during the cell update and the barriers, so a step does not start with a cold L2 round trip.
-// `bq` lives in the caller (slots 0..2 must hold k-blocks 0..2 on entry). nkbx and nkbh are multiples of 4.
-__device__ __forceinline__ void mma3_ring(f32x16& ar, f32x16& az, f32x16& anx, f32x16& anh, const float* __restrict__ X,
-                                          int ldx, int nkbx, const float* __restrict__ Hh, int ldh, int nkbh,
-                                          __amdgpu_buffer_rsrc_t wr, f32x4 (&bq)[4][3], int lane) {
-    const float* apx = X + (lane & 31) * ldx + 4 * (lane >> 5);
-    const float* aph = Hh + (lane & 31) * ldh + 4 * (lane >> 5) - 8 * nkbx;
+// contiguous over both operands, one f32x4 per lane per gate per k-block of 8. B fragments come from L2 (~1 us away)
+// while a k-block is only 12 MFMAs (0.33 us), so they run in a ring of four register sets requested THREE k-blocks
+// ahead. A fragments (LDS) are fetched one block ahead. The ring wraps around: the last group of a step already requests
+// k-blocks 0..2 of the next step (same weights every step), which arrive during the cell update and the barriers, so a
+// step does not start with a cold L2 round trip. `bq` lives in the caller (slots 0..2 must hold k-blocks 0..2 on
+// entry). nkbx and nkbh are multiples of 4.
+template <int TR>
+__device__ __forceinline__ void mma3_ring(Gate<TR>& ar, Gate<TR>& az, Gate<TR>& anx, Gate<TR>& anh,
+                                          const float* __restrict__ X, int ldx, int nkbx, const float* __restrict__ Hh,
+                                          int ldh, int nkbh, __amdgpu_buffer_rsrc_t wr, f32x4 (&bq)[4][3], int lane) {
+    typedef typename AFrag<TR>::type afrag;
+    constexpr int NJ = TR == 32 ? 4 : 2;
+    const int arow = TR == 32 ? (lane & 31) : (lane & 15);
+    const int acol = TR == 32 ? 4 * (lane >> 5) : 2 * (lane >> 4);
+    const float* apx = X + arow * ldx + acol;
+    const float* aph = Hh + arow * ldh + acol - 8 * nkbx;
     const int nkb = nkbx + nkbh;
     const unsigned lane16 = (unsigned)lane * 16u;
-    f32x4 aq[2];
+    afrag aq[2];
 #define G_B(slot, kbv) { _Pragma("unroll") for (int nt = 0; nt < 3; nt++) bq[slot][nt] = buf_load4(wr, lane16, (unsigned)(((kbv) * 3 + nt) * 1024)); }
-#define G_A(slot, kbv) { aq[slot] = *reinterpret_cast<const f32x4*>(((kbv) < nkbx ? apx : aph) + 8 * (kbv)); }
-#define G_M(bs, as, CN)                                                                              \
-    {                                                                                                \
-        _Pragma("unroll") for (int j = 0; j < 4; j++) {                                              \
-            ar = __builtin_amdgcn_mfma_f32_32x32x2f32(aq[as][j], bq[bs][0][j], ar, 0, 0, 0);         \
-            az = __builtin_amdgcn_mfma_f32_32x32x2f32(aq[as][j], bq[bs][1][j], az, 0, 0, 0);         \
-            CN = __builtin_amdgcn_mfma_f32_32x32x2f32(aq[as][j], bq[bs][2][j], CN, 0, 0, 0);         \
-        }                                                                                            \
+#define G_A(slot, kbv) { aq[slot] = *reinterpret_cast<const afrag*>(((kbv) < nkbx ? apx : aph) + 8 * (kbv)); }
+#define G_M(bs, as, CN)                                         \
+    {                                                           \
+        _Pragma("unroll") for (int j = 0; j < NJ; j++) {        \
+            gate_mma<TR>(ar, aq[as], bq[bs][0], j);             \
+            gate_mma<TR>(az, aq[as], bq[bs][1], j);             \
+            gate_mma<TR>(CN, aq[as], bq[bs][2], j);             \
+        }                                                       \
     }
 #define G_FENCE __builtin_amdgcn_sched_barrier(0); /* keep hipcc from sinking the prefetches next to their uses */
 #define G_GROUP(CN)                          \
@@ -168,14 +164,14 @@ __device__ __forceinline__ void mma3_ring(f32x16& ar, f32x16& az, f32x16& anx, f
 
 struct GruArgs {
     const uint8_t* images;  // [B,1000,10]
-    const float* enc_wp;    // packed [2 dirs][4 waves][(KPE+HG)/8 kb][3][64][4]
+    const float* enc_wp;    // packed [2 dirs][4 waves][(KPE+HG)/8 kb][3 gates][64 lanes][4] in the tile form of the launch
     const float* dec_wp;    // packed [2 dirs][4 waves][(KPD+HG)/8 kb][3][64][4]
     const float* enc_bias;  // [2 dirs][4][128]: b_ir+b_hr, b_iz+b_hz, b_in, b_hn
     const float* dec_bias;
     const float* dense_w;   // [5,256]
     const float* dense_b;   // [5]
-    float* enc_out;         // scratch [n_tiles][100][32][256]
-    float* dec_out;         // scratch [n_tiles][100][32][256]
+    float* enc_out;         // scratch [n_tiles][100][TR][256]
+    float* dec_out;         // scratch [n_tiles][100][TR][256]
     float* acc;             // [B,seq,5] (zero-initialised by the caller)
     uint8_t* labels;        // [B,seq] or NULL
     int64_t B;
@@ -186,25 +182,36 @@ struct GruArgs {
     float* logits;          // [B,100,5] raw dense1 output of the LAST window, or NULL
 };
 
+// element e of a gate accumulator -> (row, unit) = (lane part) + (compile-time part)
+template <int TR> __device__ __forceinline__ int lane_row(int lane) { return TR == 32 ? 4 * (lane >> 5) : 4 * (lane >> 4); }
+template <int TR> __device__ __forceinline__ int lane_unit(int lane) { return TR == 32 ? (lane & 31) : (lane & 15); }
+template <int TR> __device__ __forceinline__ constexpr int elem_row(int e) { return TR == 32 ? (e & 3) + 8 * (e >> 2) : (e & 3); }
+template <int TR> __device__ __forceinline__ constexpr int elem_unit(int e) { return TR == 32 ? 0 : 16 * (e >> 2); }
+
 // one GRU layer over one 100-column window for this wave's direction.
-// Addressing: every global / LDS access is written as (wave-uniform base) + (32-bit lane offset computed once) so that
-// hipcc keeps the bases in SGPRs; with per-lane 64-bit addresses for the 8 x-loads, 16 h-stores and 12 weight loads of a
-// step the kernel spilled 150 VGPRs around the MFMA loop.
-template <int KP, bool ENC>
+// Addressing: every global access is a raw buffer access (wave-uniform resource + 32-bit lane offset computed once +
+// scalar offset) and every LDS access a uniform base plus a lane offset; with per-lane 64-bit addresses for the x-loads,
+// h-stores and weight loads of a step the kernel spilled 150 VGPRs around the MFMA loop.
+template <int TR, int KP, bool ENC>
 __device__ __forceinline__ void gru_window(const GruArgs& a, int win_start, int dir, int wq, int lane, int tid_dir,
-                                           int64_t b0, int tile, float* xbuf, float* hbuf, int& cur, f32x16& hst,
+                                           int64_t b0, float* xbuf, float* hbuf, int& cur, float (&hst)[TR / 2],
                                            const float* wp, const float* bias, const float* x_src, float* out_dst) {
     constexpr int LDX = KP + 4;
     constexpr int NKB_X = KP / 8, NKB_H = HG / 8;
-    const int unit = 32 * wq + (lane & 31);
-    const float b_r = bias[0 * HG + unit], b_z = bias[1 * HG + unit], b_in = bias[2 * HG + unit], b_hn = bias[3 * HG + unit];
+    constexpr int NE = TR / 2;  // accumulator elements per lane per gate
+    const int unit = 32 * wq + lane_unit<TR>(lane);
+    float b_r[TR == 32 ? 1 : 2], b_z[TR == 32 ? 1 : 2], b_in[TR == 32 ? 1 : 2], b_hn[TR == 32 ? 1 : 2];
+#pragma unroll
+    for (int t = 0; t < (TR == 32 ? 1 : 2); t++) {
+        b_r[t] = bias[0 * HG + unit + 16 * t]; b_z[t] = bias[1 * HG + unit + 16 * t];
+        b_in[t] = bias[2 * HG + unit + 16 * t]; b_hn[t] = bias[3 * HG + unit + 16 * t];
+    }
     // register staging of x_t for this direction (256 threads per direction)
-    constexpr int V4 = KP / 4;
-    constexpr int XR = ENC ? 1 : (ROWS * V4) / 256;       // decoder: 8 float4 per thread, rows tid_dir/64 + 4u
-    constexpr int XE = ROWS * KPE / 256;                   // encoder: 4 floats per thread, rows tid_dir/32 + 8u
+    constexpr int XR = ENC ? 1 : TR / 4;   // decoder: float4 per thread, rows tid_dir/64 + 4u
+    constexpr int XE = TR / 8;             // encoder: floats per thread, rows tid_dir/32 + 8u (KPE = 32 padded features)
     f32x4 xr[XR];
     float xe[ENC ? XE : 1];
-    unsigned xoff[ENC ? XE : 1];                           // encoder: byte offset of (row's chunk, feature k) from the tile's first chunk
+    unsigned xoff[ENC ? XE : 1];           // encoder: byte offset of (row's chunk, feature k) from the tile's first chunk
     const unsigned xd_g = (unsigned)((tid_dir >> 6) * KPD + (tid_dir & 63) * 4);   // decoder: float offset in x_src[t]
     const unsigned xd_l = (unsigned)((tid_dir >> 6) * LDX + (tid_dir & 63) * 4);   // ... and in xbuf
     const unsigned xe_l = (unsigned)((tid_dir >> 5) * LDX + (tid_dir & 31));
@@ -226,7 +233,7 @@ __device__ __forceinline__ void gru_window(const GruArgs& a, int win_start, int 
             for (int u = 0; u < XE; u++) xe[u] = xe_valid ? (float)src[xoff[u]] : 0.0f;
         } else {
 #pragma unroll
-            for (int u = 0; u < XR; u++) xr[u] = buf_load4(xsr, xd_g * 4u, (unsigned)((t * ROWS + u * 4) * KPD * 4));
+            for (int u = 0; u < XR; u++) xr[u] = buf_load4(xsr, xd_g * 4u, (unsigned)((t * TR + u * 4) * KPD * 4));
         }
     };
     auto x_store = [&]() {
@@ -243,8 +250,8 @@ __device__ __forceinline__ void gru_window(const GruArgs& a, int win_start, int 
     for (int q = 0; q < 3; q++)
 #pragma unroll
         for (int nt = 0; nt < 3; nt++) bq[q][nt] = buf_load4(wr, (unsigned)lane * 16u, (unsigned)((q * 3 + nt) * 1024));
-    const unsigned h_l = (unsigned)(4 * (lane >> 5) * LDH + unit);   // lane part of the h tile offset (row = 4*(lane>>5) + f(r))
-    const unsigned o_l = (unsigned)(4 * (lane >> 5) * KPD + unit);   // lane part of the output offset
+    const unsigned h_l = (unsigned)(lane_row<TR>(lane) * LDH + unit);   // lane part of the h tile offset
+    const unsigned o_l = (unsigned)(lane_row<TR>(lane) * KPD + unit);   // lane part of the output offset
     x_load(dir ? WIN - 1 : 0);
     x_store();
     __syncthreads();
@@ -252,23 +259,31 @@ __device__ __forceinline__ void gru_window(const GruArgs& a, int win_start, int 
         const int t = dir ? (WIN - 1 - s) : s;
         const int nxt = cur ^ 1;
         if (s + 1 < WIN) x_load(dir ? (WIN - 2 - s) : (s + 1));
-        f32x16 ar, az, anx, anh;  // r and z accumulate both products; n keeps its x and h parts apart
+        Gate<TR> ar, az, anx, anh;  // r and z accumulate both products; n keeps its x and h parts apart
+        if constexpr (TR == 32) {
+            gate_fill<TR>(ar, b_r[0]); gate_fill<TR>(az, b_z[0]); gate_fill<TR>(anx, b_in[0]); gate_fill<TR>(anh, b_hn[0]);
+        } else {
 #pragma unroll
-        for (int r = 0; r < 16; r++) { ar[r] = b_r; az[r] = b_z; anx[r] = b_in; anh[r] = b_hn; }
+            for (int e = 0; e < 4; e++) {
+#pragma unroll
+                for (int t2 = 0; t2 < 2; t2++) {
+                    ar.v[t2][e] = b_r[t2]; az.v[t2][e] = b_z[t2]; anx.v[t2][e] = b_in[t2]; anh.v[t2][e] = b_hn[t2];
+                }
+            }
+        }
         static_assert(NKB_X % 4 == 0 && NKB_H % 4 == 0, "mma3_ring works in groups of four k-blocks");
-        mma3_ring(ar, az, anx, anh, xbuf, LDX, NKB_X, hbuf + cur * ROWS * LDH, LDH, NKB_H, wr, bq, lane);
-        float* hn = hbuf + nxt * ROWS * LDH;
-        const unsigned ob = (unsigned)((t * ROWS * KPD + dir * HG) * 4);  // uniform byte offset of (t, direction) in the scratch
+        mma3_ring<TR>(ar, az, anx, anh, xbuf, LDX, NKB_X, hbuf + cur * TR * LDH, LDH, NKB_H, wr, bq, lane);
+        float* hn = hbuf + nxt * TR * LDH;
+        const unsigned ob = (unsigned)((t * TR * KPD + dir * HG) * 4);  // uniform byte offset of (t, direction) in the scratch
 #pragma unroll
-        for (int r = 0; r < 16; r++) {
-            const float rg = sigmoidf_(ar[r]);
-            const float zg = sigmoidf_(az[r]);
-            const float ng = tanhf_(anx[r] + rg * anh[r]);
-            const float h = (1.0f - zg) * ng + zg * hst[r];
-            hst[r] = h;
-            const int rr = (r & 3) + 8 * (r >> 2);  // compile-time part of the row
-            (hn + rr * LDH)[h_l] = h;
-            buf_store1(h, osr, o_l * 4u, ob + (unsigned)(rr * KPD * 4));
+        for (int e = 0; e < NE; e++) {
+            const float rg = sigmoidf_(gate_get<TR>(ar, e));
+            const float zg = sigmoidf_(gate_get<TR>(az, e));
+            const float ng = tanhf_(gate_get<TR>(anx, e) + rg * gate_get<TR>(anh, e));
+            const float h = (1.0f - zg) * ng + zg * hst[e];
+            hst[e] = h;
+            (hn + elem_row<TR>(e) * LDH + elem_unit<TR>(e))[h_l] = h;
+            buf_store1(h, osr, o_l * 4u, ob + (unsigned)((elem_row<TR>(e) * KPD + elem_unit<TR>(e)) * 4));
         }
         cur = nxt;
         __syncthreads();
@@ -277,40 +292,41 @@ __device__ __forceinline__ void gru_window(const GruArgs& a, int win_start, int 
             __syncthreads();
         }
     }
-    (void)tile;
 }
 
+template <int TR>
 __global__ __launch_bounds__(512, 2) void k_gru_p2(GruArgs a) {
     extern __shared__ float smem[];
-    // per direction: hbuf [2][32][LDH], xbuf [32][LDXD]
+    // per direction: hbuf [2][TR][LDH], xbuf [TR][LDXD]
     const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);  // SGPR: bases derived from it stay scalar
     const int dir = wv >> 2, wq = wv & 3, tid_dir = tid & 255;
-    float* hbuf = smem + dir * (2 * ROWS * LDH + ROWS * LDXD);
-    float* xbuf = hbuf + 2 * ROWS * LDH;
+    constexpr int NE = TR / 2;
+    float* hbuf = smem + dir * (2 * TR * LDH + TR * LDXD);
+    float* xbuf = hbuf + 2 * TR * LDH;
     const int tile = blockIdx.x;
-    const int64_t b0 = (int64_t)tile * ROWS;
-    float* enc_out = a.enc_out + (size_t)tile * WIN * ROWS * KPD;
-    float* dec_out = a.dec_out + (size_t)tile * WIN * ROWS * KPD;
+    const int64_t b0 = (int64_t)tile * TR;
+    float* enc_out = a.enc_out + (size_t)tile * WIN * TR * KPD;
+    float* dec_out = a.dec_out + (size_t)tile * WIN * TR * KPD;
     const float* enc_wp = a.enc_wp + ((size_t)(dir * 4 + wq) * ((KPE + HG) / 8)) * 3 * 256;
     const float* dec_wp = a.dec_wp + ((size_t)(dir * 4 + wq) * ((KPD + HG) / 8)) * 3 * 256;
     const float* enc_bias = a.enc_bias + dir * 4 * HG;
     const float* dec_bias = a.dec_bias + dir * 4 * HG;
 
-    for (int i = tid_dir; i < 2 * ROWS * LDH; i += 256) hbuf[i] = 0.0f;  // hidden = zeros (predict.py:55)
-    f32x16 hst;
+    for (int i = tid_dir; i < 2 * TR * LDH; i += 256) hbuf[i] = 0.0f;  // hidden = zeros (predict.py:55)
+    float hst[NE];
 #pragma unroll
-    for (int r = 0; r < 16; r++) hst[r] = 0.0f;
+    for (int e = 0; e < NE; e++) hst[e] = 0.0f;
     int cur = 0;
     __syncthreads();
+    const int unit0 = 32 * wq + lane_unit<TR>(lane);
     if (a.hidden_in) {  // TransducerGRU.forward(x, hidden): hidden [B,2,H], index 0 = forward (simple_model.py:28)
-        const int unit = 32 * wq + (lane & 31);
 #pragma unroll
-        for (int r = 0; r < 16; r++) {
-            const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        for (int e = 0; e < NE; e++) {
+            const int row = lane_row<TR>(lane) + elem_row<TR>(e), unit = unit0 + elem_unit<TR>(e);
             int64_t b = b0 + row;
             if (b >= a.B) b = a.B - 1;
             const float h = a.hidden_in[(b * 2 + dir) * HG + unit];
-            hst[r] = h;
+            hst[e] = h;
             hbuf[row * LDH + unit] = h;
         }
         __syncthreads();
@@ -318,15 +334,15 @@ __global__ __launch_bounds__(512, 2) void k_gru_p2(GruArgs a) {
 
     for (int w = 0; w < a.nwin; w++) {
         const int ws = w * JUMP;
-        gru_window<KPE, true>(a, ws, dir, wq, lane, tid_dir, b0, tile, xbuf, hbuf, cur, hst, enc_wp, enc_bias, nullptr, enc_out);
+        gru_window<TR, KPE, true>(a, ws, dir, wq, lane, tid_dir, b0, xbuf, hbuf, cur, hst, enc_wp, enc_bias, nullptr, enc_out);
         // decoder h0 = encoder final state of the same direction: hst / hbuf[cur] simply carry over
-        gru_window<KPD, false>(a, ws, dir, wq, lane, tid_dir, b0, tile, xbuf, hbuf, cur, hst, dec_wp, dec_bias, enc_out, dec_out);
-        // dense1 + softmax + accumulate over the window (predict.py:70-89); 3200 (row, t) pairs
-        for (int p = tid; p < ROWS * WIN; p += 512) {
-            const int t = p / ROWS, row = p - t * ROWS;
+        gru_window<TR, KPD, false>(a, ws, dir, wq, lane, tid_dir, b0, xbuf, hbuf, cur, hst, dec_wp, dec_bias, enc_out, dec_out);
+        // dense1 + softmax + accumulate over the window (predict.py:70-89); TR*100 (row, t) pairs
+        for (int p = tid; p < TR * WIN; p += 512) {
+            const int t = p / TR, row = p - t * TR;
             const int64_t b = b0 + row;
             if (b >= a.B) continue;
-            const float* d = dec_out + ((size_t)t * ROWS + row) * KPD;
+            const float* d = dec_out + ((size_t)t * TR + row) * KPD;
             float lg[NCLS];
 #pragma unroll
             for (int c = 0; c < NCLS; c++) lg[c] = a.dense_b[c];
@@ -355,16 +371,15 @@ __global__ __launch_bounds__(512, 2) void k_gru_p2(GruArgs a) {
         }
         __syncthreads();
     }
-    // labels = argmax over the 5 classes, first maximum wins (torch.max, predict.py:91)
     if (a.hidden_out) {  // final decoder state (the next window's encoder h0, simple_model.py:41)
-        const int unit = 32 * wq + (lane & 31);
 #pragma unroll
-        for (int r = 0; r < 16; r++) {
-            const int64_t b = b0 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-            if (b < a.B) a.hidden_out[(b * 2 + dir) * HG + unit] = hst[r];
+        for (int e = 0; e < NE; e++) {
+            const int64_t b = b0 + lane_row<TR>(lane) + elem_row<TR>(e);
+            if (b < a.B) a.hidden_out[(b * 2 + dir) * HG + unit0 + elem_unit<TR>(e)] = hst[e];
         }
     }
-    for (int p = tid; a.labels && p < ROWS * a.seq; p += 512) {
+    // labels = argmax over the 5 classes, first maximum wins (torch.max, predict.py:91)
+    for (int p = tid; a.labels && p < TR * a.seq; p += 512) {
         const int row = p / a.seq, pos = p - row * a.seq;
         const int64_t b = b0 + row;
         if (b >= a.B) continue;
@@ -377,8 +392,11 @@ __global__ __launch_bounds__(512, 2) void k_gru_p2(GruArgs a) {
     }
 }
 
-// gate column of (wave w, tile nt in {r,z,n}, lane) = nt*HG + 32w + (lane&31); K = [x (padded to KP) | h]
-void pack_gru(const pv_rnn_dir* dirs, int K, int KP, std::vector<float>& wp, std::vector<float>& bias) {
+// Packed weight stream of one wave: [k-block of 8][gate r,z,n][lane][4]; K = [x (padded to KP) | h].
+//  32-row form: lane -> gate column 32w + (lane&31), the four values are k = 8kb + 4*(lane>>5) + j, j = 0..3
+//  16-row form: lane -> gate columns 32w + (lane&15) (tile 0) and 32w + 16 + (lane&15) (tile 1),
+//               the four values are {tile0 j0, tile0 j1, tile1 j0, tile1 j1} with k = 8kb + 2*(lane>>4) + j
+void pack_gru(const pv_rnn_dir* dirs, int K, int KP, int TR, std::vector<float>& wp, std::vector<float>& bias) {
     const int nkb = (KP + HG) / 8;
     wp.assign((size_t)2 * 4 * nkb * 3 * 256, 0.0f);
     bias.assign((size_t)2 * 4 * HG, 0.0f);
@@ -389,30 +407,35 @@ void pack_gru(const pv_rnn_dir* dirs, int K, int KP, std::vector<float>& wp, std
             bias[(size_t)d * 4 * HG + 2 * HG + u] = dirs[d].b_ih[2 * HG + u];
             bias[(size_t)d * 4 * HG + 3 * HG + u] = dirs[d].b_hh[2 * HG + u];
         }
+        auto wval = [&](int n, int k) -> float {
+            if (k < KP) return k < K ? dirs[d].w_ih[(size_t)n * K + k] : 0.0f;
+            return dirs[d].w_hh[(size_t)n * HG + (k - KP)];
+        };
         for (int w = 0; w < 4; w++)
             for (int kb = 0; kb < nkb; kb++)
                 for (int nt = 0; nt < 3; nt++)
                     for (int lane = 0; lane < 64; lane++) {
-                        const int n = nt * HG + 32 * w + (lane & 31);
                         float* dst = &wp[((((size_t)(d * 4 + w) * nkb + kb) * 3 + nt) * 64 + lane) * 4];
-                        for (int j = 0; j < 4; j++) {
-                            const int k = kb * 8 + 4 * (lane >> 5) + j;
-                            float v = 0.0f;
-                            if (k < KP) { if (k < K) v = dirs[d].w_ih[(size_t)n * K + k]; }
-                            else v = dirs[d].w_hh[(size_t)n * HG + (k - KP)];
-                            dst[j] = v;
+                        if (TR == 32) {
+                            const int n = nt * HG + 32 * w + (lane & 31);
+                            for (int j = 0; j < 4; j++) dst[j] = wval(n, kb * 8 + 4 * (lane >> 5) + j);
+                        } else {
+                            for (int t = 0; t < 2; t++)
+                                for (int j = 0; j < 2; j++)
+                                    dst[2 * t + j] = wval(nt * HG + 32 * w + 16 * t + (lane & 15), kb * 8 + 2 * (lane >> 4) + j);
                         }
                     }
     }
 }
 
-constexpr size_t LDS_P2 = (size_t)2 * (2 * ROWS * LDH + ROWS * LDXD) * sizeof(float);
+template <int TR> constexpr size_t lds_p2() { return (size_t)2 * (2 * TR * LDH + TR * LDXD) * sizeof(float); }
 
 }  // namespace
 
 struct pv_rnn_p2 {
-    float* enc_wp = nullptr; float* enc_bias = nullptr;
-    float* dec_wp = nullptr; float* dec_bias = nullptr;
+    float* enc_wp[2] = {nullptr, nullptr};  // [0] 32-row tile form, [1] 16-row tile form
+    float* dec_wp[2] = {nullptr, nullptr};
+    float* enc_bias = nullptr; float* dec_bias = nullptr;
     float* dense_w = nullptr; float* dense_b = nullptr;
     std::vector<void*> owned;
 };
@@ -449,12 +472,17 @@ extern "C" int pv_rnn_load_p2(pv_ctx* ctx, const pv_weights_p2* w, int dtype) {
     ctx->p2 = m;
     std::vector<float> wp, bias;
     int rc;
-    pack_gru(w->encoder, FEAT, KPE, wp, bias);
-    if ((rc = up2(wp.data(), wp.size(), &m->enc_wp, m->owned)) || (rc = up2(bias.data(), bias.size(), &m->enc_bias, m->owned))) return rc;
-    pack_gru(w->decoder, KPD, KPD, wp, bias);
-    if ((rc = up2(wp.data(), wp.size(), &m->dec_wp, m->owned)) || (rc = up2(bias.data(), bias.size(), &m->dec_bias, m->owned))) return rc;
+    for (int f = 0; f < 2; f++) {
+        pack_gru(w->encoder, FEAT, KPE, f ? 16 : 32, wp, bias);
+        if ((rc = up2(wp.data(), wp.size(), &m->enc_wp[f], m->owned))) return rc;
+        if (!f && (rc = up2(bias.data(), bias.size(), &m->enc_bias, m->owned))) return rc;
+        pack_gru(w->decoder, KPD, KPD, f ? 16 : 32, wp, bias);
+        if ((rc = up2(wp.data(), wp.size(), &m->dec_wp[f], m->owned))) return rc;
+        if (!f && (rc = up2(bias.data(), bias.size(), &m->dec_bias, m->owned))) return rc;
+    }
     if ((rc = up2(w->dense_w, (size_t)NCLS * KPD, &m->dense_w, m->owned)) || (rc = up2(w->dense_b, NCLS, &m->dense_b, m->owned))) return rc;
-    PV_HIP(hipFuncSetAttribute((const void*)k_gru_p2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_P2));
+    PV_HIP(hipFuncSetAttribute((const void*)k_gru_p2<32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_p2<32>()));
+    PV_HIP(hipFuncSetAttribute((const void*)k_gru_p2<16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_p2<16>()));
     return PV_OK;
 }
 
@@ -462,14 +490,18 @@ static int p2_launch(pv_ctx* ctx, const uint8_t* d_images, int64_t B, uint8_t* d
                      int seq = SEQ, int nwin = NWIN, const float* d_hidden_in = nullptr, float* d_hidden_out = nullptr,
                      float* d_logits = nullptr) {
     pv_rnn_p2* m = ctx->p2;
-    const int64_t n_tiles = (B + ROWS - 1) / ROWS;
+    // tile form: 32-row tiles once they fill the chip, else 16-row tiles (twice the workgroups, half the time per step)
+    int tr = ((B + 31) / 32 >= ctx->num_cu) ? 32 : 16;
+    if (const char* e = getenv("PV_GRU_ROWS")) { const int v = atoi(e); if (v == 16 || v == 32) tr = v; }
+    const int f = tr == 16 ? 1 : 0;
+    const int64_t n_tiles = (B + tr - 1) / tr;
     GruArgs g;
     g.images = d_images;
-    g.enc_wp = m->enc_wp; g.dec_wp = m->dec_wp; g.enc_bias = m->enc_bias; g.dec_bias = m->dec_bias;
+    g.enc_wp = m->enc_wp[f]; g.dec_wp = m->dec_wp[f]; g.enc_bias = m->enc_bias; g.dec_bias = m->dec_bias;
     g.dense_w = m->dense_w; g.dense_b = m->dense_b;
     int rc;
-    if ((rc = pv_get(ctx, "p2.enc_out", (size_t)n_tiles * WIN * ROWS * KPD, &g.enc_out))) return rc;
-    if ((rc = pv_get(ctx, "p2.dec_out", (size_t)n_tiles * WIN * ROWS * KPD, &g.dec_out))) return rc;
+    if ((rc = pv_get(ctx, "p2.enc_out", (size_t)n_tiles * WIN * tr * KPD, &g.enc_out))) return rc;
+    if ((rc = pv_get(ctx, "p2.dec_out", (size_t)n_tiles * WIN * tr * KPD, &g.dec_out))) return rc;
     g.acc = d_acc;
     if (!g.acc)
         if ((rc = pv_get(ctx, "p2.acc", (size_t)B * seq * NCLS, &g.acc))) return rc;
@@ -479,7 +511,8 @@ static int p2_launch(pv_ctx* ctx, const uint8_t* d_images, int64_t B, uint8_t* d
     PV_HIP(hipMemsetAsync(g.acc, 0, (size_t)B * seq * NCLS * sizeof(float), st));
     {
         pv_prof_scope ps(ctx, "k_gru_p2", st);
-        k_gru_p2<<<(unsigned)n_tiles, 512, LDS_P2, st>>>(g);
+        if (tr == 32) k_gru_p2<32><<<(unsigned)n_tiles, 512, lds_p2<32>(), st>>>(g);
+        else k_gru_p2<16><<<(unsigned)n_tiles, 512, lds_p2<16>(), st>>>(g);
     }
     PV_HIP(hipGetLastError());
     return PV_OK;

@@ -88,8 +88,10 @@ def _check_labels(labels, acc_ref, labels_ref):
     assert diff.mean() < 2e-3
 
 
+@pytest.mark.parametrize("rows", ["16", "32"])
 @pytest.mark.parametrize("tag", ["p2", "p2sharp"])
-def test_p2_matches_reference_golden(hip_ctx, gold, tag):
+def test_p2_matches_reference_golden(hip_ctx, gold, tag, rows, monkeypatch):
+    monkeypatch.setenv("PV_GRU_ROWS", rows)  # both tile forms of k_gru_p2 (16x16x4 and 32x32x2 MFMA)
     w = synth.make_weights_p2(int(gold[tag + "/seed"][0]), float(gold[tag + "/gain"][0]))
     hip_ctx.load_p2(w)
     labels, acc = hip_ctx.forward_p2(gold[tag + "/images"], want_acc=True)
@@ -97,8 +99,10 @@ def test_p2_matches_reference_golden(hip_ctx, gold, tag):
     _check_labels(labels, gold[tag + "/acc"], gold[tag + "/labels"])
 
 
+@pytest.mark.parametrize("rows", ["16", "32"])
 @pytest.mark.parametrize("B", [1, 33, 70])
-def test_p2_ragged_batches_vs_oracle(hip_ctx, B):
+def test_p2_ragged_batches_vs_oracle(hip_ctx, B, rows, monkeypatch):
+    monkeypatch.setenv("PV_GRU_ROWS", rows)
     w = synth.make_weights_p2(31, 3.0)
     hip_ctx.load_p2(w)
     x = synth.synth_p2_images(500 + B, B)
