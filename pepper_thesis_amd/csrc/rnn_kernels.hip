@@ -173,49 +173,100 @@ __device__ __forceinline__ void mma_dual(f32x16 (&acc)[NT], const float* __restr
     }
 }
 
-// Same contract as mma_dual, but the B fragments run in a ring of FOUR register sets and are requested
-// TWO k-blocks ahead of their use (A fragments, from LDS, one block ahead). Requires (nkb1 + nkb2) % 4 == 0.
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, 0x7fffffff, 0x00020000);
+}
+__device__ __forceinline__ f32x4 buf_load4(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
+}
+
+__device__ __forceinline__ void buf_store1(float v, __amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, voff, soff, 0);
+}
+
+// Same contract as mma_dual, but the B fragments are raw buffer loads (SGPR resource + lane offset + scalar offset: no
+// address VGPRs) into a ring of FOUR register sets requested THREE k-blocks ahead, fenced so that hipcc keeps the
+// distance; the ring wraps into the next time step (same weights every step), so `bq` slots 0..2 must hold k-blocks 0..2
+// on entry and do so again on exit. Requires (nkb1 + nkb2) % 4 == 0.
 template <int NT>
-__device__ __forceinline__ void mma_dual_ring4(f32x16 (&acc)[NT], const float* __restrict__ A1, int lda1, int nkb1,
+__device__ __forceinline__ void mma_dual_ringb(f32x16 (&acc)[NT], const float* __restrict__ A1, int lda1, int nkb1,
                                                const float* __restrict__ A2, int lda2, int nkb2,
-                                               const float* __restrict__ Bp, const f32x4 (&bres)[NT], int lane) {
+                                               __amdgpu_buffer_rsrc_t wr, f32x4 (&bq)[4][NT], int lane) {
     const float* ap1 = A1 + (lane & 31) * lda1 + 4 * (lane >> 5);
     const float* ap2 = A2 + (lane & 31) * lda2 + 4 * (lane >> 5) - 8 * nkb1;
-    const f32x4* bp = reinterpret_cast<const f32x4*>(Bp) + lane;
     const int nkb = nkb1 + nkb2;
-    f32x4 bq[4][NT], aq[2];
-#define R4_B(slot, kbv) { _Pragma("unroll") for (int nt = 0; nt < NT; nt++) bq[slot][nt] = bp[((kbv) * NT + nt) * 64]; }
-#define R4_A(slot, kbv) { aq[slot] = *reinterpret_cast<const f32x4*>(((kbv) < nkb1 ? ap1 : ap2) + 8 * (kbv)); }
-#define R4_M(bs, as)                                                                    \
+    const unsigned lane16 = (unsigned)lane * 16u;
+    f32x4 aq[2];
+#define RB_B(slot, kbv) { _Pragma("unroll") for (int nt = 0; nt < NT; nt++) bq[slot][nt] = buf_load4(wr, lane16, (unsigned)(((kbv) * NT + nt) * 1024)); }
+#define RB_A(slot, kbv) { aq[slot] = *reinterpret_cast<const f32x4*>(((kbv) < nkb1 ? ap1 : ap2) + 8 * (kbv)); }
+#define RB_M(bs, as)                                                                    \
     {                                                                                   \
         _Pragma("unroll") for (int j = 0; j < 4; j++)                                   \
             _Pragma("unroll") for (int nt = 0; nt < NT; nt++)                           \
                 acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(aq[as][j], bq[bs][nt][j], acc[nt], 0, 0, 0); \
     }
-#pragma unroll
-    for (int nt = 0; nt < NT; nt++) bq[0][nt] = bres[nt];
-    R4_B(1, 1)
-    R4_A(0, 0)
+#define RB_F __builtin_amdgcn_sched_barrier(0);
+    RB_A(0, 0)
 #pragma nounroll
     for (int kb = 0; kb < nkb; kb += 4) {
-        R4_B(2, kb + 2)
-        R4_A(1, kb + 1)
-        R4_M(0, 0)
-        R4_B(3, kb + 3)
-        R4_A(0, kb + 2)
-        R4_M(1, 1)
-        if (kb + 4 < nkb) R4_B(0, kb + 4)
-        R4_A(1, kb + 3)
-        R4_M(2, 0)
-        if (kb + 4 < nkb) {
-            R4_B(1, kb + 5)
-            R4_A(0, kb + 4)
-        }
-        R4_M(3, 1)
+        const int kw = kb + 4 < nkb ? kb + 4 : 0;
+        RB_B(3, kb + 3) RB_A(1, kb + 1) RB_F RB_M(0, 0) RB_F
+        RB_B(0, kw) RB_A(0, kb + 2) RB_F RB_M(1, 1) RB_F
+        RB_B(1, kw + 1) RB_A(1, kb + 3) RB_F RB_M(2, 0) RB_F
+        RB_B(2, kw + 2)
+        if (kb + 4 < nkb) RB_A(0, kb + 4)
+        RB_F RB_M(3, 1) RB_F
     }
-#undef R4_B
-#undef R4_A
-#undef R4_M
+#undef RB_B
+#undef RB_A
+#undef RB_M
+#undef RB_F
+}
+
+// Single-operand form over a CONTINUING weight stream: multiplies k-blocks [kpos, kpos + nkb) of the stream behind `wr`
+// with A[32 x 8*nkb] in LDS. On entry bq slots 0..2 hold k-blocks kpos..kpos+2; on exit they hold kpos+nkb..kpos+nkb+2,
+// i.e. the next call's first blocks, so consecutive calls (time steps of linear_1, layers of the head) never start with a
+// cold L2/HBM round trip. Requests beyond the resource's size return zeros (raw buffer bounds check). nkb % 4 == 0.
+template <int NT>
+__device__ __forceinline__ void mma_stream_ringb(f32x16 (&acc)[NT], const float* __restrict__ A, int lda, int nkb,
+                                                 __amdgpu_buffer_rsrc_t wr, int kpos, f32x4 (&bq)[4][NT], int lane) {
+    const float* ap = A + (lane & 31) * lda + 4 * (lane >> 5);
+    const unsigned lane16 = (unsigned)lane * 16u;
+    f32x4 aq[2];
+#define RB_B(slot, kbv) { _Pragma("unroll") for (int nt = 0; nt < NT; nt++) bq[slot][nt] = buf_load4(wr, lane16, (unsigned)(((kpos + (kbv)) * NT + nt) * 1024)); }
+#define RB_A(slot, kbv) { aq[slot] = *reinterpret_cast<const f32x4*>(ap + 8 * (kbv)); }
+#define RB_M(bs, as)                                                                    \
+    {                                                                                   \
+        _Pragma("unroll") for (int j = 0; j < 4; j++)                                   \
+            _Pragma("unroll") for (int nt = 0; nt < NT; nt++)                           \
+                acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(aq[as][j], bq[bs][nt][j], acc[nt], 0, 0, 0); \
+    }
+#define RB_F __builtin_amdgcn_sched_barrier(0);
+    RB_A(0, 0)
+#pragma nounroll
+    for (int kb = 0; kb < nkb; kb += 4) {
+        RB_B(3, kb + 3) RB_A(1, kb + 1) RB_F RB_M(0, 0) RB_F
+        RB_B(0, kb + 4) RB_A(0, kb + 2) RB_F RB_M(1, 1) RB_F
+        RB_B(1, kb + 5) RB_A(1, kb + 3) RB_F RB_M(2, 0) RB_F
+        RB_B(2, kb + 6)
+        if (kb + 4 < nkb) RB_A(0, kb + 4)
+        RB_F RB_M(3, 1) RB_F
+    }
+#undef RB_B
+#undef RB_A
+#undef RB_M
+#undef RB_F
+}
+template <int NT>
+__device__ __forceinline__ void ring_prime(f32x4 (&bq)[4][NT], __amdgpu_buffer_rsrc_t wr, int kpos, int lane) {
+#pragma unroll
+    for (int q = 0; q < 3; q++)
+#pragma unroll
+        for (int nt = 0; nt < NT; nt++) bq[q][nt] = buf_load4(wr, (unsigned)lane * 16u, (unsigned)(((kpos + q) * NT + nt) * 1024));
+}
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc_sized(const void* p, unsigned bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)bytes, 0x00020000);
 }
 
 // KP = padded input width (multiple of 8): 32 for the encoder (26 real), 512 for the decoder.
@@ -232,7 +283,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void k_lstm_layer(LstmArgs a) {
     extern __shared__ float smem[];
     float* xbuf = smem;                 // [32][LDX]
     float* hbuf = smem + ROWS * LDX;    // [2][32][LDH]
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);  // SGPR: bases/offsets derived from it stay scalar
     // XCD-aware mapping: blocks b and b+8 share an XCD (round-robin dispatch); give every XCD one
     // direction only so that its L2 holds a single direction's packed weights.
     const int xcd = blockIdx.x & 7;
@@ -264,6 +315,10 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void k_lstm_layer(LstmArgs a) {
     constexpr int XI = (ROWS * KP + NTHR - 1) / NTHR;           // int8 elements per thread (encoder)
     f32x4 xr[XR];
     float xi[INT8 ? XI : 1];
+    const __amdgpu_buffer_rsrc_t xsr = make_rsrc(INT8 ? (const void*)a.wp : (const void*)(a.x_f32 + (size_t)b0 * T_STEPS * KP));
+    const __amdgpu_buffer_rsrc_t osr = make_rsrc(a.out + (size_t)b0 * T_STEPS * 2 * H);
+    const unsigned xg_l = (unsigned)(((tid / V4) * T_STEPS * KP + (tid % V4) * 4) * 4);  // byte offset of this thread's float4 in row group 0, step 0
+    const unsigned og_l = (unsigned)((4 * (lane >> 5) * T_STEPS * 2 * H + (lane & 31)) * 4);
     auto x_load = [&](int t) {
         if constexpr (INT8) {
 #pragma unroll
@@ -275,14 +330,12 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void k_lstm_layer(LstmArgs a) {
                 xi[u] = (i < ROWS * KP && k < F_IN) ? (float)a.x_i8[(b * T_STEPS + t) * F_IN + k] : 0.0f;
             }
         } else {
+            // the layer input is padded to whole 32-row tiles (rows beyond B replicate row B-1): no clamp, and the
+            // address is (tile resource) + (lane offset, computed once) + (scalar offset of row group u and step t)
+            static_assert((ROWS * V4) % NTHR == 0, "x staging assumes whole row groups per pass");
 #pragma unroll
-            for (int u = 0; u < XR; u++) {
-                const int i = tid + u * NTHR;
-                const int row = i / V4, c4 = i - row * V4;
-                int64_t b = b0 + (row < ROWS ? row : ROWS - 1);
-                if (b >= a.B) b = a.B - 1;
-                xr[u] = PV_LD_STREAM(reinterpret_cast<const f32x4*>(a.x_f32 + (b * T_STEPS + t) * (int64_t)KP + c4 * 4));
-            }
+            for (int u = 0; u < XR; u++)
+                xr[u] = buf_load4(xsr, xg_l, (unsigned)(((u * (NTHR / V4)) * T_STEPS + t) * KP * 4));
         }
     };
     auto x_store = [&]() {
@@ -302,6 +355,10 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void k_lstm_layer(LstmArgs a) {
             }
         }
     };
+    // NW == 8: weight fragments run in a 4-deep register ring fed by raw buffer loads three k-blocks ahead (mma_dual_ringb)
+    const __amdgpu_buffer_rsrc_t wr = make_rsrc(wp);
+    f32x4 bq[NW == 8 ? 4 : 1][NT];
+    if constexpr (NW == 8) ring_prime<NT>(bq, wr, 0, lane);
     x_load(dir ? T_STEPS - 1 : 0);
     x_store();
     __syncthreads();
@@ -324,11 +381,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void k_lstm_layer(LstmArgs a) {
 #pragma unroll
             for (int r = 0; r < 16; r++) acc[nt][r] = bs[nt];
         if constexpr (NW == 8) {
-#ifdef PV_RING4
-            mma_dual_ring4<NT>(acc, xbuf, LDX, NKB_X, hbuf + cur * ROWS * LDH, LDH, NKB_H, wp, bres, lane);
-#else
-            mma_dual<NT>(acc, xbuf, LDX, NKB_X, hbuf + cur * ROWS * LDH, LDH, NKB_H, wp, bres, lane);
-#endif
+            mma_dual_ringb<NT>(acc, xbuf, LDX, NKB_X, hbuf + cur * ROWS * LDH, LDH, NKB_H, wr, bq, lane);
         } else {
             mma_dual<NT>(acc, xbuf, LDX, NKB_X, hbuf + cur * ROWS * LDH, LDH, NKB_H, wp, bres, lane);
         }
@@ -364,9 +417,8 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void k_lstm_layer(LstmArgs a) {
                     float* pk = a.out_packed + ((size_t)tile * T_STEPS + t) * 64 * 256;
                     pk[(col >> 3) * 256 + ((((col >> 2) & 1) * 32 + row) << 2) + (col & 3)] = h;
                 } else {
-                    const size_t obase = ((size_t)b0 * T_STEPS + t) * (2 * H) + dir * H;
-                    const unsigned ooff = (unsigned)row * (T_STEPS * 2 * H) + (unsigned)unit;
-                    PV_ST_STREAM(h, a.out + obase + ooff);
+                    const int rr = (r & 3) + 8 * (r >> 2);  // compile-time part of the row
+                    buf_store1(h, osr, og_l, (unsigned)((t * 2 * H + dir * H + UW * wv + 32 * s2 + rr * T_STEPS * 2 * H) * 4));
                     if (a.out_cm) {
                         const unsigned col = dir * H + unit;
                         a.out_cm[((size_t)(col >> 5) * a.cm_rows + (size_t)(b0 + row) * T_STEPS + t) * 32 + (col & 31)] = h;
@@ -573,7 +625,7 @@ __global__ __launch_bounds__(256, 1) void k_head_splitk(HeadArgs a) {
     constexpr int LDA = KC + 4;
     extern __shared__ float smem[];
     float* abuf = smem;  // [32][LDA]
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     // XCD-aware order: workgroups are dealt round-robin to the 8 XCDs, so XCD x runs blocks x, x+8, ... Give it a
     // CONTIGUOUS range of the split-major list (split, tile): its 32 CUs then stream the same 1/splits slice of the
     // packed linear_1 weights at the same time and the slice passes through that XCD's L2 once, instead of every XCD
@@ -592,6 +644,10 @@ __global__ __launch_bounds__(256, 1) void k_head_splitk(HeadArgs a) {
     for (int nt = 0; nt < 4; nt++)
 #pragma unroll
         for (int r = 0; r < 16; r++) acc[nt][r] = 0.0f;
+    // this wave's slice of the packed linear_1 weights is one contiguous stream over all 33 time steps
+    const __amdgpu_buffer_rsrc_t wr = make_rsrc_sized(a.w1p + (size_t)wv * (HEAD_K / 8) * 4 * 256, (unsigned)((HEAD_K / 8) * 4 * 256 * sizeof(float)));
+    f32x4 bq[4][4];
+    ring_prime<4>(bq, wr, split * a.steps_per_split * (KC / 8), lane);
     for (int st = 0; st < a.steps_per_split; st++) {
         const int t = split * a.steps_per_split + st;
         constexpr int V4 = KC / 4;
@@ -605,8 +661,7 @@ __global__ __launch_bounds__(256, 1) void k_head_splitk(HeadArgs a) {
                 PV_LD_STREAM(reinterpret_cast<const f32x4*>(a.dec + (b * T_STEPS + t) * (int64_t)KC + c4 * 4));
         }
         __syncthreads();
-        const float* wp = a.w1p + ((size_t)wv * (HEAD_K / 8) + (size_t)t * (KC / 8)) * 4 * 256;
-        mma_panel<4>(acc, abuf, LDA, wp, KC / 8, lane);
+        mma_stream_ringb<4>(acc, abuf, LDA, KC / 8, wr, t * (KC / 8), bq, lane);
     }
     float* dst = a.part + (size_t)split * a.B * HEAD_N;
 #pragma unroll
@@ -639,7 +694,7 @@ __global__ __launch_bounds__(256, 1) void k_head_tail(TailArgs a) {
     float* y0 = smem;               // [32][LDY]
     float* y1 = smem + ROWS * LDY;  // [32][LDY]
     __shared__ float logits[ROWS][4];
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int64_t b0 = (int64_t)blockIdx.x * ROWS;
     // y0 = selu(sum of slabs + b1)   (simple_model.py:57-59)
     for (int i = tid; i < ROWS * HEAD_N; i += 256) {
@@ -662,7 +717,13 @@ __global__ __launch_bounds__(256, 1) void k_head_tail(TailArgs a) {
 #pragma unroll
             for (int r = 0; r < 16; r++) acc[nt][r] = bv;
         }
-        mma_panel<4>(acc, src, LDY, a.wp[layer] + (size_t)wv * (HEAD_N / 8) * 4 * 256, HEAD_N / 8, lane);
+        {
+            const __amdgpu_buffer_rsrc_t wr = make_rsrc_sized(a.wp[layer] + (size_t)wv * (HEAD_N / 8) * 4 * 256,
+                                                              (unsigned)((HEAD_N / 8) * 4 * 256 * sizeof(float)));
+            f32x4 bq[4][4];
+            ring_prime<4>(bq, wr, 0, lane);
+            mma_stream_ringb<4>(acc, src, LDY, HEAD_N / 8, wr, 0, bq, lane);
+        }
 #pragma unroll
         for (int nt = 0; nt < 4; nt++) {
             const int n = 128 * wv + 32 * nt + (lane & 31);
@@ -835,7 +896,7 @@ __global__ __launch_bounds__(512, 2) void k_lstm_rec_g(RecArgs a) {
     constexpr int LDH = H + 4, NKB_X = 64, NKB_H = H / 8, NT = 4, UW = 32;
     extern __shared__ float smem[];
     float* hbuf = smem;  // [2][32][LDH]
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int xcd = blockIdx.x & 7;
     const int dir = xcd & 1;
     const int tile = (blockIdx.x >> 3) * 4 + (xcd >> 1);
@@ -846,31 +907,38 @@ __global__ __launch_bounds__(512, 2) void k_lstm_rec_g(RecArgs a) {
     f32x16 cst;
 #pragma unroll
     for (int r = 0; r < 16; r++) cst[r] = 0.0f;
-    f32x4 bres[NT];
-#pragma unroll
-    for (int nt = 0; nt < NT; nt++) bres[nt] = reinterpret_cast<const f32x4*>(wph)[nt * 64 + lane];
+    const __amdgpu_buffer_rsrc_t wr = make_rsrc(wph);
+    f32x4 bq[4][NT];
+    ring_prime<NT>(bq, wr, 0, lane);
     const int unit = UW * wv + (lane & 31);
+    // raw buffer accesses (tile resource + lane offset + scalar offset): no per-lane 64-bit addresses next to the 64 gx values
+    const __amdgpu_buffer_rsrc_t gsr = make_rsrc(a.G + (size_t)b0 * T_STEPS * 2048);
+    const __amdgpu_buffer_rsrc_t osr = make_rsrc(a.out + (size_t)b0 * T_STEPS * 2 * H);
+    const unsigned gl_l = (unsigned)((4 * (lane >> 5) * T_STEPS * 2048 + (lane & 31)) * 4);
+    const unsigned og_l = (unsigned)((4 * (lane >> 5) * T_STEPS * 2 * H + (lane & 31)) * 4);
+    const unsigned cm_l = (unsigned)((4 * (lane >> 5) * 32 + (lane & 31)) * 4);
     __syncthreads();
     for (int s = 0; s < T_STEPS; s++) {
         const int t = dir ? (T_STEPS - 1 - s) : s;
         const int cur = s & 1, nxt = cur ^ 1;
         // input projections of this step: 64 values per lane, in flight during the h-part MFMAs
-        const float* gb = a.G + ((size_t)b0 * T_STEPS + t) * 2048 + dir * 1024 + unit;
         float gx[NT][16];
 #pragma unroll
         for (int nt = 0; nt < NT; nt++)
 #pragma unroll
             for (int r = 0; r < 16; r++) {
-                const unsigned row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                gx[nt][r] = gb[row * (unsigned)(T_STEPS * 2048) + nt * H];
+                const int rr = (r & 3) + 8 * (r >> 2);  // compile-time part of the row; the lane part is in gl_l
+                gx[nt][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                    gsr, gl_l, (unsigned)((t * 2048 + dir * 1024 + UW * wv + rr * T_STEPS * 2048 + nt * H) * 4), 0));
             }
         f32x16 acc[NT];
 #pragma unroll
         for (int nt = 0; nt < NT; nt++)
 #pragma unroll
             for (int r = 0; r < 16; r++) acc[nt][r] = 0.0f;
-        mma_dual<NT>(acc, hbuf + cur * ROWS * LDH, LDH, NKB_H, hbuf, LDH, 0, wph, bres, lane);
+        mma_dual_ringb<NT>(acc, hbuf + cur * ROWS * LDH, LDH, NKB_H, hbuf, LDH, 0, wr, bq, lane);
         float* hn = hbuf + nxt * ROWS * LDH;
+        const __amdgpu_buffer_rsrc_t cmr = make_rsrc(a.out_cm + ((size_t)(t * 16 + dir * 8 + wv) * a.cm_rows + (size_t)b0) * 32);
 #pragma unroll
         for (int r = 0; r < 16; r++) {
             const float ig = sigmoidf_(acc[0][r] + gx[0][r]);
@@ -880,13 +948,12 @@ __global__ __launch_bounds__(512, 2) void k_lstm_rec_g(RecArgs a) {
             const float c = fg * cst[r] + ig * gg;
             cst[r] = c;
             const float h = og * tanhf_(c);
-            const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            const int rr = (r & 3) + 8 * (r >> 2);
+            const int row = rr + 4 * (lane >> 5);
             hn[row * LDH + unit] = h;
-            const size_t obase = ((size_t)b0 * T_STEPS + t) * (2 * H) + dir * H;
-            const unsigned ooff = (unsigned)row * (T_STEPS * 2 * H) + (unsigned)unit;
-            (a.out + obase)[ooff] = h;
-            const unsigned col = t * (2 * H) + dir * H + unit;  // flattened [t][512] index = K index of linear_1
-            a.out_cm[((size_t)(col >> 5) * a.cm_rows + (size_t)(b0 + row)) * 32 + (col & 31)] = h;
+            buf_store1(h, osr, og_l, (unsigned)((t * 2 * H + dir * H + UW * wv + rr * T_STEPS * 2 * H) * 4));
+            // chunk-major copy: flattened [t][512] column = K index of linear_1; this wave's 32 units are one 32-wide chunk
+            buf_store1(h, cmr, cm_l, (unsigned)(rr * 32 * 4));
         }
         __syncthreads();
     }
