@@ -301,7 +301,11 @@ __device__ __forceinline__ OpCtx load_op(const SumArgs& a, int64_t c) {
 //                 so lanes stay busy whatever the CIGAR run lengths are and bytes are read coalesced.
 constexpr int PT_THREADS = 512;
 constexpr int PT_PB = 128;  // pairs per batch
-constexpr int PT_BPL = 4;   // bases per thread per trip (strided by the block size)
+constexpr int PT_GPL = 2;   // groups of 4 consecutive bases per thread per trip (groups strided by the block size)
+// counters of a tile live in LDS with the column index swizzled so that the 64 lanes of a wave, which hold columns
+// c, c+4, c+8, ... for the same group element, hit 64 consecutive banks
+#define SW(lc) ((((lc) & 3) << 7) | ((lc) >> 2))
+static_assert(TILE_COLS == 512, "SW() assumes 512-column tiles");
 
 __device__ __forceinline__ int block_incl_scan512(int v, int* s_wsum, int tid) {
     const int lane = tid & 63, wv = tid >> 6;
@@ -330,11 +334,12 @@ enum {
 
 __global__ __launch_bounds__(PT_THREADS) void k_pileup_tiles(SumArgs a) {
     __shared__ int32_t s_cnt[L_N][TILE_COLS];
-    __shared__ uint8_t s_ref[TILE_COLS];     // the tile's reference bytes
+    __shared__ uint8_t s_ref[TILE_COLS + 4];  // the tile's reference bytes (+4: a padded group may look past the tile)
     __shared__ uint8_t s_lut[256];           // byte class: bits0-2 plane symbol 1..7, 8 = upper ACGT, 16 = lower acgt, 32 = valid reference
-    __shared__ uint16_t s_blk[PT_THREADS * TILE_COLS / 64 + 1];  // op that owns the first base of every 64-base block
+    __shared__ uint16_t s_blk[PT_THREADS * (TILE_COLS + 4) / 64 + 2];  // op that owns the first slot of every 64-slot block
     // per-op staging (one op batch)
-    __shared__ int32_t s_pref[PT_THREADS];   // inclusive prefix of in-tile aligned bases
+    __shared__ int32_t s_pref[PT_THREADS];   // inclusive prefix of the in-tile aligned bases, every op padded to whole groups of 4
+    __shared__ int32_t s_iend[PT_THREADS];   // one past the op's last in-tile base offset
     __shared__ int32_t s_col0[PT_THREADS];   // global column of op offset 0
     __shared__ int64_t s_base[PT_THREADS];   // global base index of op offset 0
     __shared__ int32_t s_i0[PT_THREADS];     // i = j + s_i0
@@ -350,7 +355,7 @@ __global__ __launch_bounds__(PT_THREADS) void k_pileup_tiles(SumArgs a) {
     const int64_t tile = blockIdx.x;
     const int64_t tlo = tile * TILE_COLS, thi = tlo + TILE_COLS - 1;  // global columns of this tile
     for (int i = tid; i < L_N * TILE_COLS; i += PT_THREADS) (&s_cnt[0][0])[i] = 0;
-    for (int i = tid; i < TILE_COLS; i += PT_THREADS) s_ref[i] = (tlo + i < a.n_cols) ? a.in.ref[tlo + i] : (uint8_t)'N';
+    for (int i = tid; i < TILE_COLS + 4; i += PT_THREADS) s_ref[i] = (i < TILE_COLS && tlo + i < a.n_cols) ? a.in.ref[tlo + i] : (uint8_t)'N';
     if (tid < 256) s_lut[tid] = (uint8_t)(sym_of(tid) | (is_acgt(tid) ? 8 : 0) | ((tid != up(tid) && is_acgt(up(tid))) ? 16 : 0) | (is_acgt(up(tid)) ? 32 : 0));
     const int32_t p0 = a.tile_off[tile];
     const int32_t np = a.tile_cnt[tile];
@@ -414,10 +419,10 @@ __global__ __launch_bounds__(PT_THREADS) void k_pileup_tiles(SumArgs a) {
                         int64_t qs = 0;
                         for (int64_t i = 0; i < L; i++) qs += a.in.quals[start + i];
                         const bool qok = (double)qs >= a.p.min_indel_baseq * (double)L;
-                        if (qok && (double)a.in.quals[start] < a.p.min_snp_baseq) atomicAdd(&s_cnt[L_COVI][lc], 1);  // :453
+                        if (qok && (double)a.in.quals[start] < a.p.min_snp_baseq) atomicAdd(&s_cnt[L_COVI][SW(lc)], 1);  // :453
                         if (1 + L <= PV_MAX_ALLELE_KEY && qok) {
-                            if (is_acgt(up(s_ref[lc]))) atomicAdd(&s_cnt[so + 0][lc], 1);
-                            atomicAdd(&s_cnt[L_INS][lc], 1);
+                            if (is_acgt(up(s_ref[lc]))) atomicAdd(&s_cnt[so + 0][SW(lc)], 1);
+                            atomicAdd(&s_cnt[L_INS][SW(lc)], 1);
                             a.op_flag[c] = 1;
                         }
                     }
@@ -426,11 +431,11 @@ __global__ __launch_bounds__(PT_THREADS) void k_pileup_tiles(SumArgs a) {
                 const int64_t anchor = (int64_t)ref_rel - 1;
                 if (anchor >= clo && anchor <= chi) {
                     const int lc = (int)(col_base + anchor - tlo);
-                    if (is_acgt(up(s_ref[lc]))) atomicAdd(&s_cnt[so + 1][lc], 1);  // unconditional, :496
+                    if (is_acgt(up(s_ref[lc]))) atomicAdd(&s_cnt[so + 1][SW(lc)], 1);  // unconditional, :496
                     int64_t L = (int64_t)len + 1;
                     if (anchor + L > p_reflen[pslot]) L = p_reflen[pslot] - anchor;  // substr truncation, :500
                     if (1 + L <= PV_MAX_ALLELE_KEY) {
-                        atomicAdd(&s_cnt[L_DEL][lc], 1);
+                        atomicAdd(&s_cnt[L_DEL][SW(lc)], 1);
                         a.op_flag[c] = 1;
                     }
                 }
@@ -438,7 +443,7 @@ __global__ __launch_bounds__(PT_THREADS) void k_pileup_tiles(SumArgs a) {
                 int64_t i1 = chi + 1 - ref_rel; if (i1 > len) i1 = len;
                 for (int64_t i = i0; i < i1; i++) {  // :542-552
                     const int lc2 = (int)((int64_t)col_base + ref_rel + i - tlo);
-                    if (is_acgt(up(s_ref[lc2]))) atomicAdd(&s_cnt[so + 2][lc2], 1);
+                    if (is_acgt(up(s_ref[lc2]))) atomicAdd(&s_cnt[so + 2][SW(lc2)], 1);
                 }
             }
             // (2) aligned bases of the batch's M/=/X ops, clipped to tile and region
@@ -449,73 +454,85 @@ __global__ __launch_bounds__(PT_THREADS) void k_pileup_tiles(SumArgs a) {
                 int64_t hi = chi + 1 - ref_rel; if (hi > len) hi = len;
                 if (hi > lo) { i0 = (int32_t)lo; eff = (int32_t)(hi - lo); }
             }
-            const int32_t incl = block_incl_scan512(eff, s_wsum, tid);
+            // Slots: every op's in-tile bases are padded to whole groups of 4 slots, so that a GROUP never straddles two ops:
+            // one owner lookup, one dword load of bases and one of qualities serve 4 consecutive bases / columns.
+            const int32_t effp = (eff + 3) & ~3;
+            const int32_t incl = block_incl_scan512(effp, s_wsum, tid);
             s_pref[tid] = incl;
             s_col0[tid] = col_base + ref_rel;
             s_base[tid] = (k < total_ops ? p_base0[pslot] : 0) + rd;
-            s_i0[tid] = i0 - (incl - eff);
+            s_i0[tid] = i0 - (incl - effp);
+            s_iend[tid] = i0 + eff;
             s_meta[tid] = len - 1;
             s_opfl[tid] = (uint8_t)((rev ? 1 : 0) | (anchor_next ? 2 : 0));
             s_opair[tid] = (uint8_t)pslot;
-            for (int32_t bb = (incl - eff + 63) >> 6; (bb << 6) < incl; bb++) s_blk[bb] = (uint16_t)tid;  // blocks starting inside this op
+            for (int32_t bb = (incl - effp + 63) >> 6; (bb << 6) < incl; bb++) s_blk[bb] = (uint16_t)tid;  // blocks starting inside this op
             __syncthreads();
-#ifdef ABL_NOEXP
-            const int32_t total = 0;
-#else
             const int32_t total = s_pref[PT_THREADS - 1];
-#endif
-            // ---- expansion: PT_BPL consecutive bases per thread per trip -----------------------------------
-            for (int32_t jb = 0; jb < total; jb += PT_THREADS * PT_BPL) {
-                int64_t colv[PT_BPL];
-                int basev[PT_BPL], qv[PT_BPL], refv[PT_BPL], fl[PT_BPL];
-                bool ok[PT_BPL];
+            // ---- expansion: PT_GPL groups of 4 consecutive bases per thread per trip -----------------------------
+            for (int32_t jb = 0; jb < total; jb += PT_THREADS * PT_GPL * 4) {
+                int lcv[PT_GPL], nvv[PT_GPL], fl[PT_GPL], lastv[PT_GPL];
+                uint32_t bw[PT_GPL], qw[PT_GPL], rw[PT_GPL];
 #pragma unroll
-                for (int u = 0; u < PT_BPL; u++) {
-                    // consecutive lanes take consecutive bases: conflict-free ds_add, coalesced byte loads
-                    const int32_t j = jb + u * PT_THREADS + tid;
-                    ok[u] = j < total;
-                    int owc = ok[u] ? s_blk[j >> 6] : 0;  // owner of the block's first base, then a short probe
-                    while (ok[u] && s_pref[owc] <= j) owc++;
+                for (int u = 0; u < PT_GPL; u++) {
+                    // consecutive lanes take consecutive groups: the dword loads of a wave cover 256 consecutive bytes of a run
+                    const int32_t j = jb + (u * PT_THREADS + tid) * 4;
+                    const bool ok = j < total;
+                    int owc = ok ? s_blk[j >> 6] : 0;  // owner of the block's first slot, then a short probe
+                    while (ok && s_pref[owc] <= j) owc++;
                     const int32_t i = j + s_i0[owc];
-                    colv[u] = (int64_t)s_col0[owc] + i;
+                    int nv = s_iend[owc] - i;          // valid bases of the group (the rest is padding)
+                    nv = ok ? (nv > 4 ? 4 : nv) : 0;
                     const int64_t bi = s_base[owc] + i;
+                    const int64_t left = p_seqend[s_opair[owc]] - bi;
+                    if (nv > 0 && nv > left) { set_status(a.diag, PV_ERR_INVALID); nv = left > 0 ? (int)left : 0; }
+                    const int lc = (int)((int64_t)s_col0[owc] + i - tlo);
+                    lcv[u] = lc;
+                    nvv[u] = nv;
                     const int f = s_opfl[owc];
-                    fl[u] = (f & 1) | (((f & 2) && i == s_meta[owc]) ? 2 : 0);  // bit0 rev, bit1 "is the anchor base"
-                    if (ok[u] && bi >= p_seqend[s_opair[owc]]) { set_status(a.diag, PV_ERR_INVALID); ok[u] = false; }
-#ifdef ABL_NOLOAD
-                    basev[u] = 65 + (int)(bi & 3); qv[u] = 20; refv[u] = 65 + (int)(colv[u] & 3);
-#else
-                    basev[u] = ok[u] ? a.in.bases[bi] : 0;
-                    qv[u] = ok[u] ? a.in.quals[bi] : 0;
-                    refv[u] = ok[u] ? s_ref[(int)(colv[u] - tlo)] : 0;
-#endif
+                    fl[u] = f & 1;
+                    lastv[u] = (f & 2) ? s_meta[owc] - i : -1;  // group position of the op's last base, if that base anchors an indel
+                    uint32_t b4 = 0, q4 = 0;
+                    if (nv > 0) {
+                        if (bi + 4 <= a.n_bases) {  // unaligned dword loads
+                            b4 = *reinterpret_cast<const uint32_t*>(a.in.bases + bi);
+                            q4 = *reinterpret_cast<const uint32_t*>(a.in.quals + bi);
+                        } else {
+                            for (int e = 0; e < nv; e++) {
+                                b4 |= (uint32_t)a.in.bases[bi + e] << (8 * e);
+                                q4 |= (uint32_t)a.in.quals[bi + e] << (8 * e);
+                            }
+                        }
+                    }
+                    bw[u] = b4; qw[u] = q4;
+                    const int lcr = nv > 0 ? lc : 0;
+                    rw[u] = (uint32_t)s_ref[lcr] | ((uint32_t)s_ref[lcr + 1] << 8) | ((uint32_t)s_ref[lcr + 2] << 16) | ((uint32_t)s_ref[lcr + 3] << 24);
                 }
 #pragma unroll
-                for (int u = 0; u < PT_BPL; u++) {
-                    const int base = basev[u], refb = refv[u];
-                    const bool qok = ok[u] && (qv[u] >= a.qmin_snp);
-                    if (!qok) continue;
-                    const int lc = (int)(colv[u] - tlo);
-#ifdef ABL_NOATOM
-                    if (base == 1234567) atomicAdd(&s_cnt[C_COV][lc], refb);
-                    continue;
-#endif
-                    const int st = fl[u] & 1;
-                    const int cb = s_lut[base];
-                    const bool refvalid = (s_lut[refb] & 32) != 0;
-                    const int sy = cb & 7;                                           // 1..7
-                    if (refvalid && sy <= 4) {
-                        atomicAdd(&s_cnt[L_P + 4 * st + (sy - 1)][lc], 1);           // :379 + :381-391 + :396,423 in one
-                    } else {
-                        atomicAdd(&s_cnt[L_X + st][lc], 1);
-                        if (refvalid) atomicAdd(&s_cnt[L_O + 3 * st + (sy - 5)][lc], 1);
+                for (int u = 0; u < PT_GPL; u++) {
+#pragma unroll
+                    for (int e = 0; e < 4; e++) {
+                        const int base = (bw[u] >> (8 * e)) & 0xFF, refb = (rw[u] >> (8 * e)) & 0xFF;
+                        const int q = (qw[u] >> (8 * e)) & 0xFF;
+                        if (e >= nvv[u] || q < a.qmin_snp) continue;
+                        const int lc = lcv[u] + e;
+                        const int st = fl[u];
+                        const int cb = s_lut[base];
+                        const bool refvalid = (s_lut[refb] & 32) != 0;
+                        const int sy = cb & 7;                                           // 1..7
+                        if (refvalid && sy <= 4) {
+                            atomicAdd(&s_cnt[L_P + 4 * st + (sy - 1)][SW(lc)], 1);       // :379 + :381-391 + :396,423 in one
+                        } else {
+                            atomicAdd(&s_cnt[L_X + st][SW(lc)], 1);
+                            if (refvalid) atomicAdd(&s_cnt[L_O + 3 * st + (sy - 5)][SW(lc)], 1);
+                        }
+                        if (e == lastv[u]) atomicAdd(&s_cnt[L_ANC + st][SW(lc)], 1);
+                        const bool mism = refb != base;                                  // raw bytes, :394
+                        if (mism) atomicAdd(&s_cnt[L_SNP][SW(lc)], 1);
+                        const bool rare = mism && !(refvalid && (cb & 8));
+                        const bool corr = refvalid && (cb & 16);
+                        if (rare || corr) atomicAdd(&s_cnt[L_RARE][SW(lc)], 1);
                     }
-                    if (fl[u] & 2) atomicAdd(&s_cnt[L_ANC + st][lc], 1);
-                    const bool mism = refb != base;                                  // raw bytes, :394
-                    if (mism) atomicAdd(&s_cnt[L_SNP][lc], 1);
-                    const bool rare = mism && !(refvalid && (cb & 8));
-                    const bool corr = refvalid && (cb & 16);
-                    if (rare || corr) atomicAdd(&s_cnt[L_RARE][lc], 1);
                 }
             }
             __syncthreads();  // staging arrays are rewritten by the next op batch
@@ -529,27 +546,27 @@ __global__ __launch_bounds__(PT_THREADS) void k_pileup_tiles(SumArgs a) {
     if (ncol > TILE_COLS) ncol = TILE_COLS;
     for (int lc = tid; lc < ncol; lc += PT_THREADS) {
         const int64_t g = tlo + lc;
-        int cov = s_cnt[L_COVI][lc];
+        int cov = s_cnt[L_COVI][SW(lc)];
 #pragma unroll
         for (int st = 0; st < 2; st++) {
             int sp = 0;
 #pragma unroll
             for (int k = 0; k < 4; k++) {
-                const int v = s_cnt[L_P + 4 * st + k][lc];
+                const int v = s_cnt[L_P + 4 * st + k][SW(lc)];
                 sp += v;
                 a.cnt[(int64_t)(C_PLANE + 8 * st + 1 + k) * NC + g] = -v;
             }
-            const int counted = sp + s_cnt[L_X + st][lc];
+            const int counted = sp + s_cnt[L_X + st][SW(lc)];
             cov += counted;
-            a.cnt[(int64_t)(C_PLANE + 8 * st) * NC + g] = -(counted - s_cnt[L_ANC + st][lc]);
+            a.cnt[(int64_t)(C_PLANE + 8 * st) * NC + g] = -(counted - s_cnt[L_ANC + st][SW(lc)]);
 #pragma unroll
-            for (int k = 0; k < 3; k++) a.cnt[(int64_t)(C_PLANE + 8 * st + 5 + k) * NC + g] = -s_cnt[L_O + 3 * st + k][lc];
+            for (int k = 0; k < 3; k++) a.cnt[(int64_t)(C_PLANE + 8 * st + 5 + k) * NC + g] = -s_cnt[L_O + 3 * st + k][SW(lc)];
         }
         a.cnt[(int64_t)C_COV * NC + g] = cov;
-        a.cnt[(int64_t)C_SNP * NC + g] = s_cnt[L_SNP][lc];
-        a.cnt[(int64_t)C_INS * NC + g] = s_cnt[L_INS][lc];
-        a.cnt[(int64_t)C_DEL * NC + g] = s_cnt[L_DEL][lc];
-        a.cnt[(int64_t)C_RARE * NC + g] = s_cnt[L_RARE][lc];
+        a.cnt[(int64_t)C_SNP * NC + g] = s_cnt[L_SNP][SW(lc)];
+        a.cnt[(int64_t)C_INS * NC + g] = s_cnt[L_INS][SW(lc)];
+        a.cnt[(int64_t)C_DEL * NC + g] = s_cnt[L_DEL][SW(lc)];
+        a.cnt[(int64_t)C_RARE * NC + g] = s_cnt[L_RARE][SW(lc)];
     }
 }
 
@@ -1001,8 +1018,9 @@ __device__ __forceinline__ int polish_feature(int sym, bool rev) { return sym < 
 __global__ __launch_bounds__(PT_THREADS) void k_polish_tiles(SumArgs a) {
     __shared__ int32_t s_cnt[Q_N][TILE_COLS];
     __shared__ uint8_t s_lut[256];           // polish_sym of every byte
-    __shared__ uint16_t s_blk[PT_THREADS * TILE_COLS / 64 + 1];
-    __shared__ int32_t s_pref[PT_THREADS];
+    __shared__ uint16_t s_blk[PT_THREADS * (TILE_COLS + 4) / 64 + 2];
+    __shared__ int32_t s_pref[PT_THREADS];   // inclusive prefix of in-tile aligned bases, every op padded to whole groups of 4
+    __shared__ int32_t s_iend[PT_THREADS];
     __shared__ int32_t s_col0[PT_THREADS];
     __shared__ int64_t s_base[PT_THREADS];
     __shared__ int32_t s_i0[PT_THREADS];
@@ -1065,7 +1083,7 @@ __global__ __launch_bounds__(PT_THREADS) void k_polish_tiles(SumArgs a) {
                     if (p_base0[pslot] + rd + (int64_t)len > p_seqend[pslot]) {
                         set_status(a.diag, PV_ERR_INVALID);  // alt[i] past the end of the read
                     } else {
-                        atomicMax(&s_cnt[Q_LONG][lc], len);
+                        atomicMax(&s_cnt[Q_LONG][SW(lc)], len);
                         a.op_flag[c] = 1;  // counted per insert row by k_polish_insert once the row layout is known
                     }
                 }
@@ -1073,12 +1091,12 @@ __global__ __launch_bounds__(PT_THREADS) void k_polish_tiles(SumArgs a) {
                 int64_t i0 = clo - ref_rel; if (i0 < 0) i0 = 0;
                 int64_t i1 = chi + 1 - ref_rel; if (i1 > len) i1 = len;
                 for (int64_t i = i0; i < i1; i++)
-                    atomicAdd(&s_cnt[Q_STAR + (rev ? 0 : 1)][(int)((int64_t)col_base + ref_rel + i - tlo)], 1);
+                    atomicAdd(&s_cnt[Q_STAR + (rev ? 0 : 1)][SW((int)((int64_t)col_base + ref_rel + i - tlo))], 1);
                 // "coverage[ref_position] += 1.0" sits INSIDE the loop over the deleted columns but is keyed by the
                 // START of the deletion (:110): that column gains one per in-region deleted column, the others nothing.
                 if ((int64_t)ref_rel >= clo && (int64_t)ref_rel <= chi) {
                     int64_t n = (int64_t)R - ref_rel; if (n > len) n = len;
-                    if (n > 0) atomicAdd(&s_cnt[Q_DCOV][(int)(col_base + ref_rel - tlo)], (int)n);
+                    if (n > 0) atomicAdd(&s_cnt[Q_DCOV][SW((int)(col_base + ref_rel - tlo))], (int)n);
                 }
             }
             const bool is_m = active && (op == PV_CIGAR_MATCH || op == PV_CIGAR_EQUAL || op == PV_CIGAR_DIFF);
@@ -1088,36 +1106,50 @@ __global__ __launch_bounds__(PT_THREADS) void k_polish_tiles(SumArgs a) {
                 int64_t hi = chi + 1 - ref_rel; if (hi > len) hi = len;
                 if (hi > lo) { i0 = (int32_t)lo; eff = (int32_t)(hi - lo); }
             }
-            const int32_t incl = block_incl_scan512(eff, s_wsum, tid);
+            const int32_t effp = (eff + 3) & ~3;  // groups of 4 slots never straddle two ops (see k_pileup_tiles)
+            const int32_t incl = block_incl_scan512(effp, s_wsum, tid);
             s_pref[tid] = incl;
             s_col0[tid] = col_base + ref_rel;
             s_base[tid] = (k < total_ops ? p_base0[pslot] : 0) + rd;
-            s_i0[tid] = i0 - (incl - eff);
+            s_i0[tid] = i0 - (incl - effp);
+            s_iend[tid] = i0 + eff;
             s_opfl[tid] = (uint8_t)(rev ? 1 : 0);
             s_opair[tid] = (uint8_t)pslot;
-            for (int32_t bb = (incl - eff + 63) >> 6; (bb << 6) < incl; bb++) s_blk[bb] = (uint16_t)tid;
+            for (int32_t bb = (incl - effp + 63) >> 6; (bb << 6) < incl; bb++) s_blk[bb] = (uint16_t)tid;
             __syncthreads();
             const int32_t total = s_pref[PT_THREADS - 1];
-            for (int32_t jb = 0; jb < total; jb += PT_THREADS * PT_BPL) {
-                int lcv[PT_BPL], basev[PT_BPL], rv[PT_BPL];
-                bool ok[PT_BPL];
+            for (int32_t jb = 0; jb < total; jb += PT_THREADS * PT_GPL * 4) {
+                int lcv[PT_GPL], nvv[PT_GPL], rv[PT_GPL];
+                uint32_t bw[PT_GPL];
 #pragma unroll
-                for (int u = 0; u < PT_BPL; u++) {
-                    const int32_t j = jb + u * PT_THREADS + tid;
-                    ok[u] = j < total;
-                    int owc = ok[u] ? s_blk[j >> 6] : 0;
-                    while (ok[u] && s_pref[owc] <= j) owc++;
+                for (int u = 0; u < PT_GPL; u++) {
+                    const int32_t j = jb + (u * PT_THREADS + tid) * 4;
+                    const bool ok = j < total;
+                    int owc = ok ? s_blk[j >> 6] : 0;
+                    while (ok && s_pref[owc] <= j) owc++;
                     const int32_t i = j + s_i0[owc];
-                    lcv[u] = (int)((int64_t)s_col0[owc] + i - tlo);
+                    int nv = s_iend[owc] - i;
+                    nv = ok ? (nv > 4 ? 4 : nv) : 0;
                     const int64_t bi = s_base[owc] + i;
+                    const int64_t left = p_seqend[s_opair[owc]] - bi;
+                    if (nv > 0 && nv > left) { set_status(a.diag, PV_ERR_INVALID); nv = left > 0 ? (int)left : 0; }
+                    lcv[u] = (int)((int64_t)s_col0[owc] + i - tlo);
+                    nvv[u] = nv;
                     rv[u] = s_opfl[owc] & 1;
-                    if (ok[u] && bi >= p_seqend[s_opair[owc]]) { set_status(a.diag, PV_ERR_INVALID); ok[u] = false; }
-                    basev[u] = ok[u] ? a.in.bases[bi] : 0;
+                    uint32_t b4 = 0;
+                    if (nv > 0) {
+                        if (bi + 4 <= a.n_bases) b4 = *reinterpret_cast<const uint32_t*>(a.in.bases + bi);
+                        else for (int e = 0; e < nv; e++) b4 |= (uint32_t)a.in.bases[bi + e] << (8 * e);
+                    }
+                    bw[u] = b4;
                 }
 #pragma unroll
-                for (int u = 0; u < PT_BPL; u++) {
-                    if (!ok[u]) continue;
-                    atomicAdd(&s_cnt[Q_F + polish_feature(s_lut[basev[u]], rv[u] != 0)][lcv[u]], 1);  // :70-74
+                for (int u = 0; u < PT_GPL; u++) {
+#pragma unroll
+                    for (int e = 0; e < 4; e++) {
+                        if (e >= nvv[u]) continue;
+                        atomicAdd(&s_cnt[Q_F + polish_feature(s_lut[(bw[u] >> (8 * e)) & 0xFF], rv[u] != 0)][SW(lcv[u] + e)], 1);  // :70-74
+                    }
                 }
             }
             __syncthreads();
@@ -1130,15 +1162,15 @@ __global__ __launch_bounds__(PT_THREADS) void k_polish_tiles(SumArgs a) {
     if (ncol > TILE_COLS) ncol = TILE_COLS;
     for (int lc = tid; lc < ncol; lc += PT_THREADS) {
         const int64_t g = tlo + lc;
-        int cov = s_cnt[Q_DCOV][lc];
+        int cov = s_cnt[Q_DCOV][SW(lc)];
 #pragma unroll
         for (int f = 0; f < 10; f++) {
-            const int v = s_cnt[Q_F + f][lc];
+            const int v = s_cnt[Q_F + f][SW(lc)];
             cov += v;  // every aligned base bumps coverage once (:72-73)
-            a.pcnt[(int64_t)f * NC + g] = v + (f == 8 ? s_cnt[Q_STAR][lc] : f == 9 ? s_cnt[Q_STAR + 1][lc] : 0);
+            a.pcnt[(int64_t)f * NC + g] = v + (f == 8 ? s_cnt[Q_STAR][SW(lc)] : f == 9 ? s_cnt[Q_STAR + 1][SW(lc)] : 0);
         }
         a.pcnt[(int64_t)PC_COV * NC + g] = cov;
-        a.pcnt[(int64_t)PC_LONG * NC + g] = s_cnt[Q_LONG][lc];
+        a.pcnt[(int64_t)PC_LONG * NC + g] = s_cnt[Q_LONG][SW(lc)];
     }
 }
 

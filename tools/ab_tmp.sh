@@ -1,5 +1,8 @@
 set -e
 cd /root/repo
 mkdir -p gpurun_out
-timeout -k 10 900 python bench.py > gpurun_out/bench_r01d.json 2> gpurun_out/bench_r01d.err
-bash tools/profile.sh r01d > gpurun_out/profile_r01d.log 2>&1
+{
+echo "== tests"; timeout -k 10 900 python -m pytest tests/test_summary_gpu.py tests/test_polish_gpu.py -x -q -m gpu 2>&1 | tail -3
+echo "== builder"; timeout -k 10 300 python tools/bench_builder.py 8
+echo "== polish"; timeout -k 10 300 python tools/bench_polish.py 8
+} > gpurun_out/ab_pileup.log 2>&1
