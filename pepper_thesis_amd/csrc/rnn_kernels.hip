@@ -648,20 +648,33 @@ __global__ __launch_bounds__(256, 1) void k_head_splitk(HeadArgs a) {
     const __amdgpu_buffer_rsrc_t wr = make_rsrc_sized(a.w1p + (size_t)wv * (HEAD_K / 8) * 4 * 256, (unsigned)((HEAD_K / 8) * 4 * 256 * sizeof(float)));
     f32x4 bq[4][4];
     ring_prime<4>(bq, wr, split * a.steps_per_split * (KC / 8), lane);
+    // A tile (32 rows x 512 of the decoder output at time step t; the buffer is padded to whole tiles) staged through
+    // registers: the loads of step st+1 are issued before step st's MFMAs and written to LDS after them.
+    constexpr int V4 = KC / 4, XR = ROWS * V4 / 256;   // 16 float4 per thread, rows tid/128 + 2u
+    const __amdgpu_buffer_rsrc_t asr = make_rsrc(a.dec + (size_t)b0 * T_STEPS * KC);
+    const unsigned a_g = (unsigned)(((tid >> 7) * T_STEPS * KC + (tid & 127) * 4) * 4);
+    const unsigned a_l = (unsigned)((tid >> 7) * LDA + (tid & 127) * 4);
+    f32x4 xr[XR];
+    auto a_load = [&](int t) {
+#pragma unroll
+        for (int u = 0; u < XR; u++) xr[u] = buf_load4(asr, a_g, (unsigned)((2 * u * T_STEPS + t) * KC * 4));
+    };
+    auto a_store = [&]() {
+#pragma unroll
+        for (int u = 0; u < XR; u++) *reinterpret_cast<f32x4*>(abuf + 2 * u * LDA + a_l) = xr[u];
+    };
+    a_load(split * a.steps_per_split);
+    a_store();
+    __syncthreads();
     for (int st = 0; st < a.steps_per_split; st++) {
         const int t = split * a.steps_per_split + st;
-        constexpr int V4 = KC / 4;
-        __syncthreads();
-#pragma unroll 4
-        for (int i = tid; i < ROWS * V4; i += 256) {
-            const int row = i / V4, c4 = i - row * V4;
-            int64_t b = b0 + row;
-            if (b >= a.B) b = a.B - 1;
-            *reinterpret_cast<f32x4*>(abuf + row * LDA + c4 * 4) =
-                PV_LD_STREAM(reinterpret_cast<const f32x4*>(a.dec + (b * T_STEPS + t) * (int64_t)KC + c4 * 4));
-        }
-        __syncthreads();
+        if (st + 1 < a.steps_per_split) a_load(t + 1);
         mma_stream_ringb<4>(acc, abuf, LDA, KC / 8, wr, t * (KC / 8), bq, lane);
+        if (st + 1 < a.steps_per_split) {
+            __syncthreads();  // every wave is done reading abuf
+            a_store();
+            __syncthreads();
+        }
     }
     float* dst = a.part + (size_t)split * a.B * HEAD_N;
 #pragma unroll
