@@ -18,14 +18,13 @@
 // encoder, the classifier both directions of the decoder); dense + softmax + accumulate and the final
 // argmax are fused into the same launch.
 #include "pv_common.hpp"
+#include "mfma_tiles.hpp"
 
 #include <cstdlib>
 
 namespace {
 
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-typedef float f32x2 __attribute__((ext_vector_type(2)));
+using namespace pvdev;
 
 constexpr int SEQ = 1000, WIN = 100, JUMP = 50, NWIN = 19, FEAT = 10, NCLS = 5;
 constexpr int HG = 128;          // GRU hidden
@@ -33,21 +32,6 @@ constexpr int KPE = 32;          // encoder input (10 features) padded to four k
 constexpr int KPD = 2 * HG;      // decoder input
 constexpr int LDH = HG + 4;      // LDS row strides (floats): % 64 == 4 keeps ds_read_b128 conflict-free
 constexpr int LDXD = KPD + 4;
-
-typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-
-// Raw buffer accesses: a 128-bit resource in SGPRs + one 32-bit lane offset + a scalar offset. Unlike global_load with
-// per-lane 64-bit addresses they need no address VGPRs at all, which is what keeps this kernel (64 accumulator + 48 ring
-// + 32 staging registers per lane) inside the register file.
-__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p) {
-    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, 0x7fffffff, 0x00020000);
-}
-__device__ __forceinline__ f32x4 buf_load4(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
-    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
-}
-__device__ __forceinline__ void buf_store1(float v, __amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
-    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, voff, soff, 0);
-}
 
 __device__ __forceinline__ float rcpf_(float x) { return __builtin_amdgcn_rcpf(x); }
 __device__ __forceinline__ float sigmoidf_(float x) { return rcpf_(1.0f + __expf(-x)); }
@@ -63,35 +47,7 @@ __device__ __forceinline__ float tanhf_(float x) {
 // B, until the workgroups fill the chip); the price is that every weight fragment feeds half as many rows, so the
 // 32-row form stays the choice once 32-row tiles fill all CUs.
 // Per wave: hidden units [32w, 32w+32) of the gates r, z, n. One "gate accumulator" holds those 32 units for TR rows.
-template <int TR> struct Gate;
-template <> struct Gate<32> { f32x16 v; };      // one 32x32 tile: lane -> unit lane&31, rows (e&3) + 8*(e>>2) + 4*(lane>>5)
-template <> struct Gate<16> { f32x4 v[2]; };    // two 16x16 tiles: lane -> unit 16*t + (lane&15), rows 4*(lane>>4) + i
-template <int TR> struct AFrag;
-template <> struct AFrag<32> { typedef f32x4 type; };  // A[row = lane&31][8kb + 4*(lane>>5) + j], j = 0..3
-template <> struct AFrag<16> { typedef f32x2 type; };  // A[row = lane&15][8kb + 2*(lane>>4) + j], j = 0..1
-
-template <int TR> __device__ __forceinline__ void gate_fill(Gate<TR>& g, float x) {
-    if constexpr (TR == 32) {
-#pragma unroll
-        for (int e = 0; e < 16; e++) g.v[e] = x;
-    } else {
-#pragma unroll
-        for (int e = 0; e < 4; e++) { g.v[0][e] = x; g.v[1][e] = x; }
-    }
-}
-template <int TR> __device__ __forceinline__ float gate_get(const Gate<TR>& g, int e) {
-    if constexpr (TR == 32) return g.v[e];
-    else return g.v[e >> 2][e & 3];
-}
-// one k-step (j) of one gate: B fragment layout TR=32: b[j]; TR=16: {tile0 j0, tile0 j1, tile1 j0, tile1 j1}
-template <int TR> __device__ __forceinline__ void gate_mma(Gate<TR>& g, const typename AFrag<TR>::type& a, const f32x4& b, int j) {
-    if constexpr (TR == 32) {
-        g.v = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j], b[j], g.v, 0, 0, 0);
-    } else {
-        g.v[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j], b[j], g.v[0], 0, 0, 0);
-        g.v[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j], b[2 + j], g.v[1], 0, 0, 0);
-    }
-}
+// (Gate<TR>, AFrag<TR>, gate_mma: mfma_tiles.hpp)
 
 // One K loop over [x_t | h_{t-1}] for the three gates of a wave: r and z accumulate both products, n keeps its x- and
 // h-parts apart (anx / anh, PyTorch's GRU: n = tanh(W_in x + b_in + r * (W_hn h + b_hn))). The packed weight stream is
@@ -107,10 +63,8 @@ __device__ __forceinline__ void mma3_ring(Gate<TR>& ar, Gate<TR>& az, Gate<TR>& 
                                           int ldh, int nkbh, __amdgpu_buffer_rsrc_t wr, f32x4 (&bq)[4][3], int lane) {
     typedef typename AFrag<TR>::type afrag;
     constexpr int NJ = TR == 32 ? 4 : 2;
-    const int arow = TR == 32 ? (lane & 31) : (lane & 15);
-    const int acol = TR == 32 ? 4 * (lane >> 5) : 2 * (lane >> 4);
-    const float* apx = X + arow * ldx + acol;
-    const float* aph = Hh + arow * ldh + acol - 8 * nkbx;
+    const float* apx = afrag_ptr<TR>(X, ldx, lane);
+    const float* aph = afrag_ptr<TR>(Hh, ldh, lane) - 8 * nkbx;
     const int nkb = nkbx + nkbh;
     const unsigned lane16 = (unsigned)lane * 16u;
     afrag aq[2];
@@ -181,12 +135,6 @@ struct GruArgs {
     float* hidden_out;      // [B,2,128] or NULL
     float* logits;          // [B,100,5] raw dense1 output of the LAST window, or NULL
 };
-
-// element e of a gate accumulator -> (row, unit) = (lane part) + (compile-time part)
-template <int TR> __device__ __forceinline__ int lane_row(int lane) { return TR == 32 ? 4 * (lane >> 5) : 4 * (lane >> 4); }
-template <int TR> __device__ __forceinline__ int lane_unit(int lane) { return TR == 32 ? (lane & 31) : (lane & 15); }
-template <int TR> __device__ __forceinline__ constexpr int elem_row(int e) { return TR == 32 ? (e & 3) + 8 * (e >> 2) : (e & 3); }
-template <int TR> __device__ __forceinline__ constexpr int elem_unit(int e) { return TR == 32 ? 0 : 16 * (e >> 2); }
 
 // one GRU layer over one 100-column window for this wave's direction.
 // Addressing: every global access is a raw buffer access (wave-uniform resource + 32-bit lane offset computed once +
@@ -260,16 +208,10 @@ __device__ __forceinline__ void gru_window(const GruArgs& a, int win_start, int 
         const int nxt = cur ^ 1;
         if (s + 1 < WIN) x_load(dir ? (WIN - 2 - s) : (s + 1));
         Gate<TR> ar, az, anx, anh;  // r and z accumulate both products; n keeps its x and h parts apart
-        if constexpr (TR == 32) {
-            gate_fill<TR>(ar, b_r[0]); gate_fill<TR>(az, b_z[0]); gate_fill<TR>(anx, b_in[0]); gate_fill<TR>(anh, b_hn[0]);
-        } else {
 #pragma unroll
-            for (int e = 0; e < 4; e++) {
-#pragma unroll
-                for (int t2 = 0; t2 < 2; t2++) {
-                    ar.v[t2][e] = b_r[t2]; az.v[t2][e] = b_z[t2]; anx.v[t2][e] = b_in[t2]; anh.v[t2][e] = b_hn[t2];
-                }
-            }
+        for (int e = 0; e < NE; e++) {
+            const int t2 = TR == 32 ? 0 : e >> 2;  // which 16-unit tile the element belongs to
+            gate_set<TR>(ar, e, b_r[t2]); gate_set<TR>(az, e, b_z[t2]); gate_set<TR>(anx, e, b_in[t2]); gate_set<TR>(anh, e, b_hn[t2]);
         }
         static_assert(NKB_X % 4 == 0 && NKB_H % 4 == 0, "mma3_ring works in groups of four k-blocks");
         mma3_ring<TR>(ar, az, anx, anh, xbuf, LDX, NKB_X, hbuf + cur * TR * LDH, LDH, NKB_H, wr, bq, lane);

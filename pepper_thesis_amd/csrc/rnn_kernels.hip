@@ -19,14 +19,14 @@
 //        deterministic partial slabs (no float atomics).
 //   k_head_tail            sum of slabs + bias + SELU, linear_2..5 + SELU (MFMA), output layer, softmax.
 #include "pv_common.hpp"
+#include "mfma_tiles.hpp"
 
 #include <cmath>
 #include <cstdlib>
 
 namespace {
 
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef float f32x4 __attribute__((ext_vector_type(4)));
+using namespace pvdev;
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 
@@ -37,17 +37,6 @@ constexpr int ROWS = 32;          // batch rows per workgroup (one MFMA M-tile)
 constexpr int HEAD_N = 512;
 constexpr int HEAD_K = T_STEPS * 2 * H;  // 16896
 constexpr int HEAD_MAX_SPLITS = 33;      // split-K factor of linear_1 is chosen per launch from {1, 3, 11, 33}
-
-// Streaming accesses (x_t tiles, layer outputs, the head's A operand) carry the non-temporal hint: they are touched
-// once, and without the hint they push the packed weights (3.1 MB per direction in a 4 MB L2) out of the XCD's L2
-// every time step (rocprofv3 FETCH_SIZE showed the weights re-fetched on each of the 33 steps).
-#ifdef PV_NO_NT
-#define PV_LD_STREAM(p) (*(p))
-#define PV_ST_STREAM(v, p) (*(p) = (v))
-#else
-#define PV_LD_STREAM(p) __builtin_nontemporal_load(p)
-#define PV_ST_STREAM(v, p) __builtin_nontemporal_store((v), (p))
-#endif
 
 // v_exp_f32 / v_rcp_f32 (1 ulp) instead of the IEEE division sequence: ~3x fewer VALU instructions in the
 // cell update; absolute error of sigmoid/tanh stays ~1e-7 (tests pin 2e-5 on layer outputs).
@@ -62,149 +51,33 @@ __device__ __forceinline__ float seluf_(float x) {
     return 1.0507009873554805f * (x > 0.0f ? x : 1.6732632423543772f * (__expf(x) - 1.0f));
 }
 
-// acc[nt] += A[32 x 8*nkb] . B  for NT column tiles of 32. A: LDS, row-major, `lda` floats per row
-// (lda % 4 == 0, lda % 64 == 4 keeps ds_read_b128 conflict-free); lane reads 16 B at
-// A[lane&31][8*kb + 4*(lane>>5)]. Bp: this wave's packed stream, NT*256 floats per k-block:
-// Bp[(kb*NT + nt)*256 + lane*4 + j] = W[n(nt,lane&31)][8*kb + 4*(lane>>5) + j].
-// MFMA j of a k-block multiplies k = 8kb + 4*(lane>>5) + j: lanes 0-31 carry k..k+3 of the low half,
-// lanes 32-63 of the high half; the K order inside a block is a permutation of 0..7, which only
-// changes the (fp32) summation order.
-template <int NT>
-__device__ __forceinline__ void mma_panel(f32x16 (&acc)[NT], const float* __restrict__ A, int lda,
-                                          const float* __restrict__ Bp, int nkb, int lane) {
-    const float* ap = A + (lane & 31) * lda + 4 * (lane >> 5);
-    const f32x4* bp = reinterpret_cast<const f32x4*>(Bp) + lane;
-    f32x4 b0[NT], b1[NT];
-#pragma unroll
-    for (int nt = 0; nt < NT; nt++) b0[nt] = bp[nt * 64];
-    int kb = 0;
-#pragma nounroll
-    for (; kb + 1 < nkb; kb += 2) {
-#pragma unroll
-        for (int nt = 0; nt < NT; nt++) b1[nt] = bp[((kb + 1) * NT + nt) * 64];
-        f32x4 a = *reinterpret_cast<const f32x4*>(ap + 8 * kb);
-#pragma unroll
-        for (int j = 0; j < 4; j++)
-#pragma unroll
-            for (int nt = 0; nt < NT; nt++) acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j], b0[nt][j], acc[nt], 0, 0, 0);
-        if (kb + 2 < nkb) {
-#pragma unroll
-            for (int nt = 0; nt < NT; nt++) b0[nt] = bp[((kb + 2) * NT + nt) * 64];
-        }
-        a = *reinterpret_cast<const f32x4*>(ap + 8 * (kb + 1));
-#pragma unroll
-        for (int j = 0; j < 4; j++)
-#pragma unroll
-            for (int nt = 0; nt < NT; nt++) acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j], b1[nt][j], acc[nt], 0, 0, 0);
-    }
-    if (kb < nkb) {
-        f32x4 a = *reinterpret_cast<const f32x4*>(ap + 8 * kb);
-#pragma unroll
-        for (int j = 0; j < 4; j++)
-#pragma unroll
-            for (int nt = 0; nt < NT; nt++) acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j], b0[nt][j], acc[nt], 0, 0, 0);
-    }
-}
+// ---- weight-fragment rings ------------------------------------------------------------------------------------------
+// The B operand (packed weights, one f32x4 per lane per gate tile per k-block of 8) comes from L2, ~1 us away, while a
+// k-block is 12-16 MFMAs (0.3-0.45 us): fragments run in a ring of FOUR register sets fed by raw buffer loads THREE
+// k-blocks ahead. `sched_barrier` fences keep hipcc from sinking the prefetches back next to their uses. A fragments come
+// from LDS one block ahead.
 
-struct LstmArgs {
-    const int8_t* x_i8;   // [B,33,26]    (encoder)
-    const float* x_f32;   // [B,33,512]   (decoder)
-    const float* wp;      // packed [2 dirs][NW waves][nkb][32/NW tiles][64][4]
-    const float* bias;    // [2][1024] b_ih + b_hh
-    float* out;           // [B,33,512]
-    float* out_cm;        // optional chunk-major copy [512/32][Bp*33][32] (A operand of the bf16x3 decoder GEMM)
-    int64_t cm_rows;      // Bp*33
-    float* out_packed;    // optional [n_tiles][33][64 kb][64 lanes][4]: A-fragment order of the next layer's x operand
-    int64_t B;
-    int n_tiles;
-    unsigned long long* stamps;  // diagnostic builds (-DPV_STAMPS) only
-    int ablate;  // diagnostics only (PV_ABLATE): 1 = trivial cell update, 2 = stage x_t only at step 0, 4 = no global h store
-};
-
-// One software-pipelined K loop over TWO LDS operands ([x_t | h_{t-1}]): k-blocks [0,nkb1) read A1,
-// [nkb1,nkb1+nkb2) read A2; the packed weight stream is contiguous over both. B fragments of block 0
-// are resident in registers (`bres`, identical every time step), blocks kb+1 (B from L2, A from LDS)
-// are fetched while block kb multiplies.
-template <int NT>
-__device__ __forceinline__ void mma_dual(f32x16 (&acc)[NT], const float* __restrict__ A1, int lda1, int nkb1,
-                                         const float* __restrict__ A2, int lda2, int nkb2,
-                                         const float* __restrict__ Bp, const f32x4 (&bres)[NT], int lane) {
-    const float* ap1 = A1 + (lane & 31) * lda1 + 4 * (lane >> 5);
-    const float* ap2 = A2 + (lane & 31) * lda2 + 4 * (lane >> 5) - 8 * nkb1;
-    const f32x4* bp = reinterpret_cast<const f32x4*>(Bp) + lane;
-    const int nkb = nkb1 + nkb2;
-    f32x4 b0[NT], b1[NT], a0, a1;
-#pragma unroll
-    for (int nt = 0; nt < NT; nt++) b0[nt] = bres[nt];
-    a0 = *reinterpret_cast<const f32x4*>((0 < nkb1 ? ap1 : ap2));
-    int kb = 0;
-#pragma nounroll
-    for (; kb + 1 < nkb; kb += 2) {
-#pragma unroll
-#ifndef ABL_NOBLOAD
-        for (int nt = 0; nt < NT; nt++) b1[nt] = bp[((kb + 1) * NT + nt) * 64];
-#else
-        for (int nt = 0; nt < NT; nt++) { b1[nt] = b0[nt]; asm volatile("" : "+v"(b1[nt])); }
-#endif
-        a1 = *reinterpret_cast<const f32x4*>((kb + 1 < nkb1 ? ap1 : ap2) + 8 * (kb + 1));
-#pragma unroll
-        for (int j = 0; j < 4; j++)
-#pragma unroll
-            for (int nt = 0; nt < NT; nt++) acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[j], b0[nt][j], acc[nt], 0, 0, 0);
-        if (kb + 2 < nkb) {
-#pragma unroll
-#ifndef ABL_NOBLOAD
-            for (int nt = 0; nt < NT; nt++) b0[nt] = bp[((kb + 2) * NT + nt) * 64];
-#else
-            for (int nt = 0; nt < NT; nt++) { b0[nt] = b1[nt]; asm volatile("" : "+v"(b0[nt])); }
-#endif
-            a0 = *reinterpret_cast<const f32x4*>((kb + 2 < nkb1 ? ap1 : ap2) + 8 * (kb + 2));
-        }
-#pragma unroll
-        for (int j = 0; j < 4; j++)
-#pragma unroll
-            for (int nt = 0; nt < NT; nt++) acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[j], b1[nt][j], acc[nt], 0, 0, 0);
-    }
-    if (kb < nkb) {
-#pragma unroll
-        for (int j = 0; j < 4; j++)
-#pragma unroll
-            for (int nt = 0; nt < NT; nt++) acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[j], b0[nt][j], acc[nt], 0, 0, 0);
-    }
-}
-
-typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p) {
-    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, 0x7fffffff, 0x00020000);
-}
-__device__ __forceinline__ f32x4 buf_load4(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
-    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
-}
-
-__device__ __forceinline__ void buf_store1(float v, __amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
-    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, voff, soff, 0);
-}
-
-// Same contract as mma_dual, but the B fragments are raw buffer loads (SGPR resource + lane offset + scalar offset: no
-// address VGPRs) into a ring of FOUR register sets requested THREE k-blocks ahead, fenced so that hipcc keeps the
-// distance; the ring wraps into the next time step (same weights every step), so `bq` slots 0..2 must hold k-blocks 0..2
-// on entry and do so again on exit. Requires (nkb1 + nkb2) % 4 == 0.
-template <int NT>
-__device__ __forceinline__ void mma_dual_ringb(f32x16 (&acc)[NT], const float* __restrict__ A1, int lda1, int nkb1,
+// Recurrent form, acc[nt] += [A1 | A2] . B: k-blocks [0,nkb1) read A1 (x_t), [nkb1,nkb1+nkb2) read A2 (h_{t-1}); the packed
+// weight stream is contiguous over both. The ring wraps into the next time step (same weights every step), so `bq` slots
+// 0..2 must hold k-blocks 0..2 on entry and do so again on exit: a step never starts with a cold L2 round trip.
+// (nkb1 + nkb2) % 4 == 0.
+template <int TR, int NT>
+__device__ __forceinline__ void mma_dual_ringb(Gate<TR> (&acc)[NT], const float* __restrict__ A1, int lda1, int nkb1,
                                                const float* __restrict__ A2, int lda2, int nkb2,
                                                __amdgpu_buffer_rsrc_t wr, f32x4 (&bq)[4][NT], int lane) {
-    const float* ap1 = A1 + (lane & 31) * lda1 + 4 * (lane >> 5);
-    const float* ap2 = A2 + (lane & 31) * lda2 + 4 * (lane >> 5) - 8 * nkb1;
+    typedef typename AFrag<TR>::type afrag;
+    constexpr int NJ = TR == 32 ? 4 : 2;
+    const float* ap1 = afrag_ptr<TR>(A1, lda1, lane);
+    const float* ap2 = afrag_ptr<TR>(A2, lda2, lane) - 8 * nkb1;
     const int nkb = nkb1 + nkb2;
     const unsigned lane16 = (unsigned)lane * 16u;
-    f32x4 aq[2];
+    afrag aq[2];
 #define RB_B(slot, kbv) { _Pragma("unroll") for (int nt = 0; nt < NT; nt++) bq[slot][nt] = buf_load4(wr, lane16, (unsigned)(((kbv) * NT + nt) * 1024)); }
-#define RB_A(slot, kbv) { aq[slot] = *reinterpret_cast<const f32x4*>(((kbv) < nkb1 ? ap1 : ap2) + 8 * (kbv)); }
+#define RB_A(slot, kbv) { aq[slot] = *reinterpret_cast<const afrag*>(((kbv) < nkb1 ? ap1 : ap2) + 8 * (kbv)); }
 #define RB_M(bs, as)                                                                    \
     {                                                                                   \
-        _Pragma("unroll") for (int j = 0; j < 4; j++)                                   \
-            _Pragma("unroll") for (int nt = 0; nt < NT; nt++)                           \
-                acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(aq[as][j], bq[bs][nt][j], acc[nt], 0, 0, 0); \
+        _Pragma("unroll") for (int j = 0; j < NJ; j++)                                  \
+            _Pragma("unroll") for (int nt = 0; nt < NT; nt++) gate_mma<TR>(acc[nt], aq[as], bq[bs][nt], j); \
     }
 #define RB_F __builtin_amdgcn_sched_barrier(0);
     RB_A(0, 0)
@@ -224,10 +97,13 @@ __device__ __forceinline__ void mma_dual_ringb(f32x16 (&acc)[NT], const float* _
 #undef RB_F
 }
 
-// Single-operand form over a CONTINUING weight stream: multiplies k-blocks [kpos, kpos + nkb) of the stream behind `wr`
-// with A[32 x 8*nkb] in LDS. On entry bq slots 0..2 hold k-blocks kpos..kpos+2; on exit they hold kpos+nkb..kpos+nkb+2,
-// i.e. the next call's first blocks, so consecutive calls (time steps of linear_1, layers of the head) never start with a
-// cold L2/HBM round trip. Requests beyond the resource's size return zeros (raw buffer bounds check). nkb % 4 == 0.
+// Single-operand form over a CONTINUING weight stream (32-row tiles): multiplies k-blocks [kpos, kpos + nkb) of the stream
+// behind `wr` with A[32 x 8*nkb] in LDS. On entry bq slots 0..2 hold k-blocks kpos..kpos+2; on exit they hold
+// kpos+nkb..kpos+nkb+2, i.e. the next call's first blocks, so consecutive calls (time steps of linear_1) never start with
+// a cold L2/HBM round trip. Requests beyond the resource's size return zeros. nkb % 4 == 0.
+// Fragment layout: wp[(kb*NT + nt)*256 + lane*4 + j] = W[n(nt, lane&31)][8*kb + 4*(lane>>5) + j]; MFMA j of a k-block
+// multiplies k = 8kb + 4*(lane>>5) + j, a permutation of the K order inside a block that only changes the (fp32)
+// summation order.
 template <int NT>
 __device__ __forceinline__ void mma_stream_ringb(f32x16 (&acc)[NT], const float* __restrict__ A, int lda, int nkb,
                                                  __amdgpu_buffer_rsrc_t wr, int kpos, f32x4 (&bq)[4][NT], int lane) {
@@ -265,24 +141,33 @@ __device__ __forceinline__ void ring_prime(f32x4 (&bq)[4][NT], __amdgpu_buffer_r
 #pragma unroll
         for (int nt = 0; nt < NT; nt++) bq[q][nt] = buf_load4(wr, (unsigned)lane * 16u, (unsigned)(((kpos + q) * NT + nt) * 1024));
 }
-__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc_sized(const void* p, unsigned bytes) {
-    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)bytes, 0x00020000);
-}
 
-// KP = padded input width (multiple of 8): 32 for the encoder (26 real), 512 for the decoder.
-// NW = waves per workgroup: 8 (two per SIMD: one wave's LDS/L2 waits and cell update hide behind the
-// other's MFMAs) or 4 (one per SIMD).
-template <int KP, bool INT8, int NW, bool PACKED>
-__global__ __launch_bounds__(NW * 64, NW / 4) void k_lstm_layer(LstmArgs a) {
+struct LstmArgs {
+    const int8_t* x_i8;   // [B,33,26]    (encoder)
+    const float* x_f32;   // [Bp,33,512]  (decoder; padded to whole 32-row tiles)
+    const float* wp;      // packed [2 dirs][8 waves][nkb][4 gates][64][4] in the tile form of the launch
+    const float* bias;    // [2][1024] b_ih + b_hh
+    float* out;           // [Bp,33,512]
+    float* out_cm;        // optional chunk-major copy [512/32][Bp*33][32] (A operand of the bf16x3 decoder GEMM)
+    int64_t cm_rows;      // Bp*33
+    int64_t B;
+    int n_tiles;          // tiles of TR rows
+};
+
+// One LSTM layer. KP = padded input width (multiple of 32): 32 for the encoder (26 real, from int8), 512 for the decoder.
+// TR = batch rows per workgroup (mfma_tiles.hpp). Workgroup = (batch tile, direction), 8 waves (two per SIMD: one wave's
+// LDS/L2 waits and cell update hide behind the other's MFMAs); wave w owns hidden units [32w, 32w+32) of the four gates.
+template <int KP, bool INT8, int TR>
+__global__ __launch_bounds__(512, 2) void k_lstm_layer(LstmArgs a) {
     constexpr int LDX = KP + 4, LDH = H + 4;
     constexpr int NKB_X = KP / 8, NKB_H = H / 8;
-    constexpr int NT = 32 / NW;   // 32-column gate tiles per wave
-    constexpr int S2 = NT / 4;    // 32-unit sub-tiles per wave
-    constexpr int UW = H / NW;    // hidden units per wave
-    constexpr int NTHR = NW * 64;
+    constexpr int NT = 4;         // gates i, f, g, o
+    constexpr int NE = TR / 2;    // accumulator elements per lane per gate
+    constexpr int NTHR = 512;
+    static_assert((NKB_X + NKB_H) % 4 == 0, "mma_dual_ringb works in groups of four k-blocks");
     extern __shared__ float smem[];
-    float* xbuf = smem;                 // [32][LDX]
-    float* hbuf = smem + ROWS * LDX;    // [2][32][LDH]
+    float* xbuf = smem;               // [TR][LDX]
+    float* hbuf = smem + TR * LDX;    // [2][TR][LDH]
     const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);  // SGPR: bases/offsets derived from it stay scalar
     // XCD-aware mapping: blocks b and b+8 share an XCD (round-robin dispatch); give every XCD one
     // direction only so that its L2 holds a single direction's packed weights.
@@ -290,323 +175,113 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void k_lstm_layer(LstmArgs a) {
     const int dir = xcd & 1;
     const int tile = (blockIdx.x >> 3) * 4 + (xcd >> 1);
     if (tile >= a.n_tiles) return;
-    const int64_t b0 = (int64_t)tile * ROWS;
-    const float* wp = a.wp + ((size_t)(dir * NW + wv) * (NKB_X + NKB_H)) * NT * 256;
+    const int64_t b0 = (int64_t)tile * TR;
+    const float* wp = a.wp + ((size_t)(dir * 8 + wv) * (NKB_X + NKB_H)) * NT * 256;
     const float* bias = a.bias + dir * 4 * H;
 
-    for (int i = tid; i < 2 * ROWS * LDH; i += NTHR) hbuf[i] = 0.0f;
-    f32x16 cst[S2];
+    for (int i = tid; i < 2 * TR * LDH; i += NTHR) hbuf[i] = 0.0f;
+    float cst[NE];
 #pragma unroll
-    for (int s2 = 0; s2 < S2; s2++)
+    for (int e = 0; e < NE; e++) cst[e] = 0.0f;
+    const int unit0 = 32 * wv + lane_unit<TR>(lane);
+    float bs[NT][TR == 32 ? 1 : 2];
 #pragma unroll
-        for (int r = 0; r < 16; r++) cst[s2][r] = 0.0f;
-    float bs[NT];
-    f32x4 bres[NT];
+    for (int nt = 0; nt < NT; nt++)
 #pragma unroll
-    for (int nt = 0; nt < NT; nt++) {
-        bs[nt] = bias[(nt / S2) * H + UW * wv + 32 * (nt % S2) + (lane & 31)];
-        bres[nt] = reinterpret_cast<const f32x4*>(wp)[nt * 64 + lane];
-    }
+        for (int t2 = 0; t2 < (TR == 32 ? 1 : 2); t2++) bs[nt][t2] = bias[nt * H + unit0 + 16 * t2];
+    const __amdgpu_buffer_rsrc_t wr = make_rsrc(wp);
+    f32x4 bq[4][NT];
+    ring_prime<NT>(bq, wr, 0, lane);
 
-    // x_t staging through registers: the global loads for step s+1 are issued before step s's MFMAs
-    // and written to LDS after them, so their latency hides behind the matrix work.
-    constexpr int V4 = KP / 4;                                  // float4 per row (fp32 input)
-    constexpr int XR = INT8 ? 1 : (ROWS * V4 + NTHR - 1) / NTHR;  // float4 registers per thread
-    constexpr int XI = (ROWS * KP + NTHR - 1) / NTHR;           // int8 elements per thread (encoder)
+    // x_t staging through registers: the loads for step s+1 are issued before step s's MFMAs and written to LDS after
+    // them, so their latency hides behind the matrix work.
+    constexpr int V4 = KP / 4;                            // float4 per row (fp32 input)
+    constexpr int XR = INT8 ? 1 : TR * V4 / NTHR;         // decoder: float4 per thread, rows tid/128 + 4u
+    constexpr int XI = INT8 ? TR * KP / NTHR : 1;         // encoder: floats per thread, rows tid/32 + 16u
     f32x4 xr[XR];
-    float xi[INT8 ? XI : 1];
+    float xi[XI];
+    int xoff[XI];                                         // encoder: offset of (row's window, feature k) from the tile's first window
+                                                          // (negative when a 16-row half tile lies wholly beyond B)
+    // the decoder input is padded to whole 32-row tiles (rows beyond B replicate row B-1): no clamp, and the address is
+    // (tile resource) + (lane offset, computed once) + (scalar offset of row group u and step t)
     const __amdgpu_buffer_rsrc_t xsr = make_rsrc(INT8 ? (const void*)a.wp : (const void*)(a.x_f32 + (size_t)b0 * T_STEPS * KP));
     const __amdgpu_buffer_rsrc_t osr = make_rsrc(a.out + (size_t)b0 * T_STEPS * 2 * H);
-    const unsigned xg_l = (unsigned)(((tid / V4) * T_STEPS * KP + (tid % V4) * 4) * 4);  // byte offset of this thread's float4 in row group 0, step 0
-    const unsigned og_l = (unsigned)((4 * (lane >> 5) * T_STEPS * 2 * H + (lane & 31)) * 4);
+    const unsigned xg_l = (unsigned)(((tid / V4) * T_STEPS * KP + (tid % V4) * 4) * 4);
+    const unsigned xl_l = (unsigned)((tid / V4) * LDX + (tid % V4) * 4);
+    const unsigned xe_l = (unsigned)((tid >> 5) * LDX + (tid & 31));
+    const bool xe_valid = (tid & 31) < F_IN;
+    if constexpr (INT8) {
+        static_assert(KP == 32, "encoder staging assumes 32 padded features");
+#pragma unroll
+        for (int u = 0; u < XI; u++) {
+            int64_t r = (tid >> 5) + 16 * u;
+            if (b0 + r >= a.B) r = a.B - 1 - b0;   // rows beyond B replicate row B-1 (finite values; never stored to the caller)
+            xoff[u] = (int)(r * T_STEPS * F_IN) + (tid & 31);
+        }
+    }
+    const int8_t* img0 = a.x_i8 + (size_t)b0 * T_STEPS * F_IN;  // uniform
     auto x_load = [&](int t) {
         if constexpr (INT8) {
+            const int8_t* src = img0 + t * F_IN;
 #pragma unroll
-            for (int u = 0; u < XI; u++) {
-                const int i = tid + u * NTHR;
-                const int row = i / KP, k = i - row * KP;
-                int64_t b = b0 + row;
-                if (b >= a.B) b = a.B - 1;
-                xi[u] = (i < ROWS * KP && k < F_IN) ? (float)a.x_i8[(b * T_STEPS + t) * F_IN + k] : 0.0f;
-            }
+            for (int u = 0; u < XI; u++) xi[u] = xe_valid ? (float)src[xoff[u]] : 0.0f;
         } else {
-            // the layer input is padded to whole 32-row tiles (rows beyond B replicate row B-1): no clamp, and the
-            // address is (tile resource) + (lane offset, computed once) + (scalar offset of row group u and step t)
-            static_assert((ROWS * V4) % NTHR == 0, "x staging assumes whole row groups per pass");
 #pragma unroll
-            for (int u = 0; u < XR; u++)
-                xr[u] = buf_load4(xsr, xg_l, (unsigned)(((u * (NTHR / V4)) * T_STEPS + t) * KP * 4));
+            for (int u = 0; u < XR; u++) xr[u] = buf_load4(xsr, xg_l, (unsigned)(((u * (NTHR / V4)) * T_STEPS + t) * KP * 4));
         }
     };
     auto x_store = [&]() {
         if constexpr (INT8) {
 #pragma unroll
-            for (int u = 0; u < XI; u++) {
-                const int i = tid + u * NTHR;
-                const int row = i / KP, k = i - row * KP;
-                if (i < ROWS * KP) xbuf[row * LDX + k] = xi[u];
-            }
+            for (int u = 0; u < XI; u++) (xbuf + u * 16 * LDX)[xe_l] = xi[u];
         } else {
 #pragma unroll
-            for (int u = 0; u < XR; u++) {
-                const int i = tid + u * NTHR;
-                const int row = i / V4, c4 = i - row * V4;
-                if (i < ROWS * V4) *reinterpret_cast<f32x4*>(xbuf + row * LDX + c4 * 4) = xr[u];
-            }
+            for (int u = 0; u < XR; u++) *reinterpret_cast<f32x4*>(xbuf + u * (NTHR / V4) * LDX + xl_l) = xr[u];
         }
     };
-    // NW == 8: weight fragments run in a 4-deep register ring fed by raw buffer loads three k-blocks ahead (mma_dual_ringb)
-    const __amdgpu_buffer_rsrc_t wr = make_rsrc(wp);
-    f32x4 bq[NW == 8 ? 4 : 1][NT];
-    if constexpr (NW == 8) ring_prime<NT>(bq, wr, 0, lane);
+    const unsigned h_l = (unsigned)(lane_row<TR>(lane) * LDH + unit0);                      // lane part of the h tile offset
+    const unsigned og_l = (unsigned)((lane_row<TR>(lane) * T_STEPS * 2 * H + unit0) * 4);   // lane part of the output byte offset
     x_load(dir ? T_STEPS - 1 : 0);
     x_store();
     __syncthreads();
 
-#ifdef PV_STAMPS
-    unsigned long long st_m = 0, st_c = 0, st_b = 0, st_s = 0, t0s, t1s;
-#define STAMPL(v) { __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) :: "memory"); __builtin_amdgcn_sched_barrier(0); }
-#endif
     for (int s = 0; s < T_STEPS; s++) {
         const int t = dir ? (T_STEPS - 1 - s) : s;
         const int cur = s & 1, nxt = cur ^ 1;
-#ifdef PV_STAMPS
-        STAMPL(t0s)
-#endif
-        if (s + 1 < T_STEPS && !(a.ablate & 2)) x_load(dir ? (T_STEPS - 2 - s) : (s + 1));
+        if (s + 1 < T_STEPS) x_load(dir ? (T_STEPS - 2 - s) : (s + 1));
         // ---- gates = bias + [x_t | h_{t-1}] . [W_ih | W_hh]^T -------------------------------------
-        f32x16 acc[NT];
+        Gate<TR> acc[NT];
 #pragma unroll
         for (int nt = 0; nt < NT; nt++)
 #pragma unroll
-            for (int r = 0; r < 16; r++) acc[nt][r] = bs[nt];
-        if constexpr (NW == 8) {
-            mma_dual_ringb<NT>(acc, xbuf, LDX, NKB_X, hbuf + cur * ROWS * LDH, LDH, NKB_H, wr, bq, lane);
-        } else {
-            mma_dual<NT>(acc, xbuf, LDX, NKB_X, hbuf + cur * ROWS * LDH, LDH, NKB_H, wp, bres, lane);
-        }
-#ifdef PV_STAMPS
-        STAMPL(t1s) st_m += t1s - t0s; t0s = t1s;
-#endif
-        // ---- cell update (PyTorch gate order i,f,g,o; nt = gate*S2 + sub-tile) ---------------------
-        float* hn = hbuf + nxt * ROWS * LDH;
+            for (int e = 0; e < NE; e++) gate_set<TR>(acc[nt], e, bs[nt][TR == 32 ? 0 : e >> 2]);
+        mma_dual_ringb<TR, NT>(acc, xbuf, LDX, NKB_X, hbuf + cur * TR * LDH, LDH, NKB_H, wr, bq, lane);
+        // ---- cell update (PyTorch gate order i,f,g,o) ----------------------------------------------
+        float* hn = hbuf + nxt * TR * LDH;
 #pragma unroll
-        for (int s2 = 0; s2 < S2; s2++) {
-            const int unit = UW * wv + 32 * s2 + (lane & 31);
-#pragma unroll
-            for (int r = 0; r < 16; r++) {
-                if (a.ablate & 1) {
-                    const float h = acc[0 * S2 + s2][r] * 1e-3f + acc[1 * S2 + s2][r] * 1e-3f + acc[2 * S2 + s2][r] * 1e-3f + acc[3 * S2 + s2][r] * 1e-3f;
-                    const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                    hn[row * LDH + unit] = h;
-                    if (!(a.ablate & 4)) a.out[((size_t)(b0 + row) * T_STEPS + t) * (2 * H) + dir * H + unit] = h;
-                    continue;
-                }
-                const float ig = sigmoidf_(acc[0 * S2 + s2][r]);
-                const float fg = sigmoidf_(acc[1 * S2 + s2][r]);
-                const float gg = tanhf_(acc[2 * S2 + s2][r]);
-                const float og = sigmoidf_(acc[3 * S2 + s2][r]);
-                const float c = fg * cst[s2][r] + ig * gg;
-                cst[s2][r] = c;
-                const float h = og * tanhf_(c);
-                const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                hn[row * LDH + unit] = h;
-                // outputs are padded to whole 32-row tiles: unconditional stores, uniform base + 32-bit lane offset
-                if constexpr (PACKED) {  // fragment order: [kb = col/8][lane = (col%8/4)*32 + row][col%4]
-                    const unsigned col = dir * H + unit;
-                    float* pk = a.out_packed + ((size_t)tile * T_STEPS + t) * 64 * 256;
-                    pk[(col >> 3) * 256 + ((((col >> 2) & 1) * 32 + row) << 2) + (col & 3)] = h;
-                } else {
-                    const int rr = (r & 3) + 8 * (r >> 2);  // compile-time part of the row
-                    buf_store1(h, osr, og_l, (unsigned)((t * 2 * H + dir * H + UW * wv + 32 * s2 + rr * T_STEPS * 2 * H) * 4));
-                    if (a.out_cm) {
-                        const unsigned col = dir * H + unit;
-                        a.out_cm[((size_t)(col >> 5) * a.cm_rows + (size_t)(b0 + row) * T_STEPS + t) * 32 + (col & 31)] = h;
-                    }
-                }
+        for (int e = 0; e < NE; e++) {
+            const float ig = sigmoidf_(gate_get<TR>(acc[0], e));
+            const float fg = sigmoidf_(gate_get<TR>(acc[1], e));
+            const float gg = tanhf_(gate_get<TR>(acc[2], e));
+            const float og = sigmoidf_(gate_get<TR>(acc[3], e));
+            const float c = fg * cst[e] + ig * gg;
+            cst[e] = c;
+            const float h = og * tanhf_(c);
+            (hn + elem_row<TR>(e) * LDH + elem_unit<TR>(e))[h_l] = h;
+            // outputs are padded to whole tiles: unconditional stores, tile resource + lane offset + scalar offset
+            buf_store1(h, osr, og_l, (unsigned)((t * 2 * H + dir * H + elem_row<TR>(e) * T_STEPS * 2 * H + elem_unit<TR>(e)) * 4));
+            if (a.out_cm) {
+                const int row = lane_row<TR>(lane) + elem_row<TR>(e);
+                const unsigned col = dir * H + unit0 + elem_unit<TR>(e);
+                a.out_cm[((size_t)(col >> 5) * a.cm_rows + (size_t)(b0 + row) * T_STEPS + t) * 32 + (col & 31)] = h;
             }
         }
-#ifdef PV_STAMPS
-        STAMPL(t1s) st_c += t1s - t0s; t0s = t1s;
-#endif
         __syncthreads();  // everyone is done reading xbuf / hbuf[cur]; hbuf[nxt] is complete
-#ifdef PV_STAMPS
-        STAMPL(t1s) st_b += t1s - t0s; t0s = t1s;
-#endif
-        if (s + 1 < T_STEPS && !(a.ablate & 2)) {
+        if (s + 1 < T_STEPS) {
             x_store();
             __syncthreads();
         }
-#ifdef PV_STAMPS
-        STAMPL(t1s) st_s += t1s - t0s;
-#endif
     }
-#ifdef PV_STAMPS
-    if (lane == 0 && a.stamps) {
-        unsigned long long* o = a.stamps + ((size_t)blockIdx.x * 8 + wv) * 4;
-        o[0] = st_m; o[1] = st_c; o[2] = st_b; o[3] = st_s;
-    }
-#endif
-}
-
-
-// ---- decoder LSTM, staggered ------------------------------------------------------------------------------
-// Same math and weight packing as k_lstm_layer<512,false,8>, different choreography:
-//  * the x operand (encoder output) is read straight from HBM/L2 in A-fragment order (the encoder writes a
-//    packed copy), one coalesced 1-KB load per wave per k-block, prefetched like the weights: no x tile in
-//    LDS, no staging barriers;
-//  * the only per-step synchronisation is the h exchange, done with a monotonic LDS counter instead of
-//    s_barrier: a wave may run its x-part MFMAs of step s+1 as soon as its own cell update of step s is
-//    done, and waits only before the h-part;
-//  * waves 4-7 (the SIMD partners of waves 0-3) start half an x-part late, so one partner's cell update
-//    (VALU) overlaps the other's x-part (MFMA) instead of both idling the matrix pipe together.
-struct DecArgs {
-    const float* xp;      // packed encoder output [n_tiles][33][64][64][4]
-    const float* wp;      // packed [2 dirs][8 waves][96 kb][4 tiles][64][4]
-    const float* bias;    // [2][1024]
-    float* out;           // [B,33,512]
-    int64_t B;
-    int n_tiles;
-    int stagger;          // s_sleep(127) iterations for waves 4-7
-    unsigned long long* stamps;  // diagnostic builds (-DPV_STAMPS) only: [grid][8 waves][4] phase cycle sums
-};
-
-__global__ __launch_bounds__(512, 2) void k_lstm_dec_stagger(DecArgs a) {
-    constexpr int LDH = H + 4;
-    constexpr int NKB_X = 64, NKB_H = H / 8, NT = 4, UW = 32;
-    extern __shared__ float smem[];
-    float* hbuf = smem;  // [2][32][LDH]
-    __shared__ int s_hdone;
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int xcd = blockIdx.x & 7;
-    const int dir = xcd & 1;
-    const int tile = (blockIdx.x >> 3) * 4 + (xcd >> 1);
-    if (tile >= a.n_tiles) return;
-    const int64_t b0 = (int64_t)tile * ROWS;
-    const f32x4* wp = reinterpret_cast<const f32x4*>(a.wp + ((size_t)(dir * 8 + wv) * (NKB_X + NKB_H)) * NT * 256) + lane;
-    const f32x4* xp = reinterpret_cast<const f32x4*>(a.xp + (size_t)tile * T_STEPS * NKB_X * 256) + lane;
-    const float* bias = a.bias + dir * 4 * H;
-    for (int i = tid; i < 2 * ROWS * LDH; i += 512) hbuf[i] = 0.0f;
-    if (tid == 0) s_hdone = 0;
-    f32x16 cst;
-#pragma unroll
-    for (int r = 0; r < 16; r++) cst[r] = 0.0f;
-    float bs[NT];
-#pragma unroll
-    for (int nt = 0; nt < NT; nt++) bs[nt] = bias[nt * H + UW * wv + (lane & 31)];
-    __syncthreads();
-    if (wv >= 4)
-        for (int i = 0; i < a.stagger; i++) __builtin_amdgcn_s_sleep(127);
-    const float* ah_base = hbuf + (lane & 31) * LDH + 4 * (lane >> 5);
-
-#ifdef PV_STAMPS
-    unsigned long long st_x = 0, st_w = 0, st_h = 0, st_c = 0, t0s, t1s;
-#define STAMP(v) { __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) :: "memory"); __builtin_amdgcn_sched_barrier(0); }
-#else
-#define STAMP(v)
-#endif
-    for (int s = 0; s < T_STEPS; s++) {
-        const int t = dir ? (T_STEPS - 1 - s) : s;
-        const int cur = s & 1, nxt = cur ^ 1;
-#ifdef PV_STAMPS
-        STAMP(t0s)
-#endif
-        const f32x4* xs = xp + (size_t)t * NKB_X * 64;
-        f32x16 acc[NT];
-#pragma unroll
-        for (int nt = 0; nt < NT; nt++)
-#pragma unroll
-            for (int r = 0; r < 16; r++) acc[nt][r] = bs[nt];
-        // ---- x part: both operands stream from L2/HBM, one k-block ahead (two register sets, compiler-scheduled)
-        f32x4 b0v[NT], b1v[NT], a0, a1;
-#pragma unroll
-        for (int nt = 0; nt < NT; nt++) b0v[nt] = wp[nt * 64];
-        a0 = xs[0];
-#pragma nounroll
-        for (int kb = 0; kb < NKB_X; kb += 2) {
-#pragma unroll
-            for (int nt = 0; nt < NT; nt++) b1v[nt] = wp[((kb + 1) * NT + nt) * 64];
-            a1 = xs[(kb + 1) * 64];
-#pragma unroll
-            for (int j = 0; j < 4; j++)
-#pragma unroll
-                for (int nt = 0; nt < NT; nt++) acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[j], b0v[nt][j], acc[nt], 0, 0, 0);
-#pragma unroll
-            for (int nt = 0; nt < NT; nt++) b0v[nt] = wp[((kb + 2) * NT + nt) * 64];  // kb+2 == NKB_X: first h block
-            if (kb + 2 < NKB_X) a0 = xs[(kb + 2) * 64];
-#pragma unroll
-            for (int j = 0; j < 4; j++)
-#pragma unroll
-                for (int nt = 0; nt < NT; nt++) acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[j], b1v[nt][j], acc[nt], 0, 0, 0);
-        }
-#ifdef PV_STAMPS
-        STAMP(t1s) st_x += t1s - t0s; t0s = t1s;
-#endif
-        // ---- wait for h_{s-1} of every wave ------------------------------------------------------------------
-        if (s > 0) {
-            const int need = 8 * s;
-            while (__hip_atomic_load(&s_hdone, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < need) __builtin_amdgcn_s_sleep(1);
-            asm volatile("" ::: "memory");  // LDS has no cache: program order is enough, and a fence would also drain vmcnt
-        }
-#ifdef PV_STAMPS
-        STAMP(t1s) st_w += t1s - t0s; t0s = t1s;
-#endif
-        // ---- h part: A from LDS, B keeps streaming -------------------------------------------------------------
-        const float* ah = ah_base + cur * ROWS * LDH;
-        a0 = *reinterpret_cast<const f32x4*>(ah);
-#pragma nounroll
-        for (int kb = 0; kb < NKB_H; kb += 2) {
-#pragma unroll
-            for (int nt = 0; nt < NT; nt++) b1v[nt] = wp[((NKB_X + kb + 1) * NT + nt) * 64];
-            a1 = *reinterpret_cast<const f32x4*>(ah + 8 * (kb + 1));
-#pragma unroll
-            for (int j = 0; j < 4; j++)
-#pragma unroll
-                for (int nt = 0; nt < NT; nt++) acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[j], b0v[nt][j], acc[nt], 0, 0, 0);
-            if (kb + 2 < NKB_H) {
-#pragma unroll
-                for (int nt = 0; nt < NT; nt++) b0v[nt] = wp[((NKB_X + kb + 2) * NT + nt) * 64];
-                a0 = *reinterpret_cast<const f32x4*>(ah + 8 * (kb + 2));
-            }
-#pragma unroll
-            for (int j = 0; j < 4; j++)
-#pragma unroll
-                for (int nt = 0; nt < NT; nt++) acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[j], b1v[nt][j], acc[nt], 0, 0, 0);
-        }
-#ifdef PV_STAMPS
-        STAMP(t1s) st_h += t1s - t0s; t0s = t1s;
-#endif
-        // ---- cell update ---------------------------------------------------------------------------------------
-        float* hn = hbuf + nxt * ROWS * LDH;
-        const int unit = UW * wv + (lane & 31);
-#pragma unroll
-        for (int r = 0; r < 16; r++) {
-            const float ig = sigmoidf_(acc[0][r]);
-            const float fg = sigmoidf_(acc[1][r]);
-            const float gg = tanhf_(acc[2][r]);
-            const float og = sigmoidf_(acc[3][r]);
-            const float c = fg * cst[r] + ig * gg;
-            cst[r] = c;
-            const float h = og * tanhf_(c);
-            const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-            hn[row * LDH + unit] = h;
-            float* ob = a.out + ((size_t)b0 * T_STEPS + t) * (2 * H) + dir * H;  // rows padded to the tile: no bounds branch
-            ob[(unsigned)row * (T_STEPS * 2 * H) + (unsigned)unit] = h;
-        }
-        // publish: this wave's slice of h_s is in LDS. Only the LDS queue has to drain (it is in-order per wave);
-        // a workgroup release fence would also wait for the h stores and the prefetched operands (vmcnt(0)).
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        if (lane == 0) __hip_atomic_fetch_add(&s_hdone, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-#ifdef PV_STAMPS
-        STAMP(t1s) st_c += t1s - t0s;
-#endif
-    }
-#ifdef PV_STAMPS
-    if (lane == 0 && a.stamps) {
-        unsigned long long* o = a.stamps + ((size_t)blockIdx.x * 8 + wv) * 4;
-        o[0] = st_x; o[1] = st_w; o[2] = st_h; o[3] = st_c;
-    }
-#endif
 }
 
 struct HeadArgs {
@@ -941,23 +616,22 @@ __global__ __launch_bounds__(512, 2) void k_lstm_rec_g(RecArgs a) {
 #pragma unroll
             for (int r = 0; r < 16; r++) {
                 const int rr = (r & 3) + 8 * (r >> 2);  // compile-time part of the row; the lane part is in gl_l
-                gx[nt][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
-                    gsr, gl_l, (unsigned)((t * 2048 + dir * 1024 + UW * wv + rr * T_STEPS * 2048 + nt * H) * 4), 0));
+                gx[nt][r] = buf_load1(gsr, gl_l, (unsigned)((t * 2048 + dir * 1024 + UW * wv + rr * T_STEPS * 2048 + nt * H) * 4));
             }
-        f32x16 acc[NT];
+        Gate<32> acc[NT];
 #pragma unroll
         for (int nt = 0; nt < NT; nt++)
 #pragma unroll
-            for (int r = 0; r < 16; r++) acc[nt][r] = 0.0f;
-        mma_dual_ringb<NT>(acc, hbuf + cur * ROWS * LDH, LDH, NKB_H, hbuf, LDH, 0, wr, bq, lane);
+            for (int r = 0; r < 16; r++) acc[nt].v[r] = 0.0f;
+        mma_dual_ringb<32, NT>(acc, hbuf + cur * ROWS * LDH, LDH, NKB_H, hbuf, LDH, 0, wr, bq, lane);
         float* hn = hbuf + nxt * ROWS * LDH;
         const __amdgpu_buffer_rsrc_t cmr = make_rsrc(a.out_cm + ((size_t)(t * 16 + dir * 8 + wv) * a.cm_rows + (size_t)b0) * 32);
 #pragma unroll
         for (int r = 0; r < 16; r++) {
-            const float ig = sigmoidf_(acc[0][r] + gx[0][r]);
-            const float fg = sigmoidf_(acc[1][r] + gx[1][r]);
-            const float gg = tanhf_(acc[2][r] + gx[2][r]);
-            const float og = sigmoidf_(acc[3][r] + gx[3][r]);
+            const float ig = sigmoidf_(acc[0].v[r] + gx[0][r]);
+            const float fg = sigmoidf_(acc[1].v[r] + gx[1][r]);
+            const float gg = tanhf_(acc[2].v[r] + gx[2][r]);
+            const float og = sigmoidf_(acc[3].v[r] + gx[3][r]);
             const float c = fg * cst[r] + ig * gg;
             cst[r] = c;
             const float h = og * tanhf_(c);
@@ -973,30 +647,36 @@ __global__ __launch_bounds__(512, 2) void k_lstm_rec_g(RecArgs a) {
 }
 
 // ---- host-side weight packing -----------------------------------------------------------------------
-// LSTM layer, NW waves per workgroup: NT = 32/NW tiles per wave, S2 = NT/4 sub-tiles;
-// gate column of (wave w, tile nt, lane) = (nt/S2)*H + (H/NW)*w + 32*(nt%S2) + (lane&31)
-static void pack_lstm(const pv_rnn_dir* dirs, int K, int KP, int NW, std::vector<float>& wp, std::vector<float>& bias) {
-    const int nkb = (KP + H) / 8, NT = 32 / NW, S2 = NT / 4, UW = H / NW;
+// LSTM layer, 8 waves per workgroup, wave w owns hidden units [32w, 32w+32) of the gates i,f,g,o (nt).
+// Packed stream of one wave: [k-block of 8][gate][lane][4]; K = [x (padded to KP) | h]. Tile forms as in mfma_tiles.hpp:
+//  32 rows: lane -> gate column nt*H + 32w + (lane&31); values k = 8kb + 4*(lane>>5) + j, j = 0..3
+//  16 rows: lane -> columns nt*H + 32w + 16t + (lane&15), t = 0,1; values {t0 j0, t0 j1, t1 j0, t1 j1}, k = 8kb + 2*(lane>>4) + j
+static void pack_lstm(const pv_rnn_dir* dirs, int K, int KP, int TR, std::vector<float>& wp, std::vector<float>& bias) {
+    const int nkb = (KP + H) / 8, NT = 4, NW = 8;
     wp.assign((size_t)2 * NW * nkb * NT * 256, 0.0f);
     bias.assign((size_t)2 * 4 * H, 0.0f);
     for (int d = 0; d < 2; d++) {
         for (int n = 0; n < 4 * H; n++) bias[(size_t)d * 4 * H + n] = dirs[d].b_ih[n] + dirs[d].b_hh[n];
+        auto wval = [&](int n, int k) -> float {
+            if (k < KP) return k < K ? dirs[d].w_ih[(size_t)n * K + k] : 0.0f;
+            return dirs[d].w_hh[(size_t)n * H + (k - KP)];
+        };
         for (int w = 0; w < NW; w++)
             for (int kb = 0; kb < nkb; kb++)
                 for (int nt = 0; nt < NT; nt++)
                     for (int lane = 0; lane < 64; lane++) {
-                        const int n = (nt / S2) * H + UW * w + 32 * (nt % S2) + (lane & 31);
                         float* dst = &wp[((((size_t)(d * NW + w) * nkb + kb) * NT + nt) * 64 + lane) * 4];
-                        for (int j = 0; j < 4; j++) {
-                            const int k = kb * 8 + 4 * (lane >> 5) + j;
-                            float v = 0.0f;
-                            if (k < KP) { if (k < K) v = dirs[d].w_ih[(size_t)n * K + k]; }
-                            else v = dirs[d].w_hh[(size_t)n * H + (k - KP)];
-                            dst[j] = v;
+                        if (TR == 32) {
+                            for (int j = 0; j < 4; j++) dst[j] = wval(nt * H + 32 * w + (lane & 31), kb * 8 + 4 * (lane >> 5) + j);
+                        } else {
+                            for (int t = 0; t < 2; t++)
+                                for (int j = 0; j < 2; j++)
+                                    dst[2 * t + j] = wval(nt * H + 32 * w + 16 * t + (lane & 15), kb * 8 + 2 * (lane >> 4) + j);
                         }
                     }
     }
 }
+
 // Linear [512, K]: column of (wave w, tile nt, lane) = 128w + 32nt + (lane&31)
 static void pack_linear(const float* W, int K, std::vector<float>& wp) {
     const int nkb = K / 8;
@@ -1013,16 +693,16 @@ static void pack_linear(const float* W, int K, std::vector<float>& wp) {
 
 }  // namespace
 
-static constexpr size_t LDS_ENC = (size_t)(ROWS * (32 + 4) + 2 * ROWS * (H + 4)) * sizeof(float);
-static constexpr size_t LDS_DEC = (size_t)(ROWS * (2 * H + 4) + 2 * ROWS * (H + 4)) * sizeof(float);
-static constexpr size_t LDS_DEC_STAGGER = (size_t)(2 * ROWS * (H + 4)) * sizeof(float);
+template <int KP, int TR> constexpr size_t lds_lstm() { return (size_t)(TR * (KP + 4) + 2 * TR * (H + 4)) * sizeof(float); }
+static constexpr size_t LDS_REC = (size_t)(2 * ROWS * (H + 4)) * sizeof(float);
 static constexpr size_t LDS_GEMM = (size_t)4 * 2 * 128 * 40 * 2;  // 4 operand arrays x 2 buffers x 128 rows x 40 bf16
 static constexpr size_t LDS_SPLITK = (size_t)ROWS * (2 * H + 4) * sizeof(float);
 static constexpr size_t LDS_TAIL = (size_t)2 * ROWS * (HEAD_N + 4) * sizeof(float);
 
 struct pv_rnn_p1 {
-    float* enc_wp = nullptr; float* enc_bias = nullptr;
-    float* dec_wp = nullptr; float* dec_bias = nullptr;
+    float* enc_wp[2] = {nullptr, nullptr};  // [0] 32-row tile form, [1] 16-row tile form (mfma_tiles.hpp)
+    float* dec_wp[2] = {nullptr, nullptr};
+    float* enc_bias = nullptr; float* dec_bias = nullptr;
     float* w1p = nullptr; float* b1 = nullptr;
     float* wlp[4] = {nullptr, nullptr, nullptr, nullptr};
     float* bl[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -1031,9 +711,6 @@ struct pv_rnn_p1 {
     // PV_DTYPE_BF16_INPUT_GEMM: bf16 hi/lo splits of the decoder W_ih (both directions, [2048,512]) and linear_1 ([512,16896])
     __bf16* dec_wih_h = nullptr; __bf16* dec_wih_l = nullptr; float* dec_bias_cat = nullptr;
     __bf16* w1_h = nullptr; __bf16* w1_l = nullptr;
-    int nw = 8;  // waves per LSTM workgroup (PV_LSTM_WAVES=4|8)
-    int dec_stagger = -1;  // PV_DEC_STAGGER: -1 (default) = barrier decoder k_lstm_layer<512>; >= 0 = experimental flag-synchronised
-                           // decoder k_lstm_dec_stagger with that many sleep units of stagger (measured slower: DESIGN.md section 6)
     std::vector<void*> owned;
 };
 
@@ -1112,13 +789,14 @@ extern "C" int pv_rnn_load_p1(pv_ctx* ctx, const pv_weights_p1* w, int dtype) {
     m->dtype = dtype;
     std::vector<float> wp, bias;
     int rc;
-    if (const char* e = getenv("PV_LSTM_WAVES")) m->nw = (atoi(e) == 4) ? 4 : 8;
-    if (const char* e = getenv("PV_DEC_STAGGER")) m->dec_stagger = atoi(e);
-    if (m->nw != 8) m->dec_stagger = -1;
-    pack_lstm(w->encoder, F_IN, 32, m->nw, wp, bias);
-    if ((rc = dev_upload(wp, &m->enc_wp, m->owned)) || (rc = dev_upload(bias, &m->enc_bias, m->owned))) return rc;
-    pack_lstm(w->decoder, 2 * H, 2 * H, m->nw, wp, bias);
-    if ((rc = dev_upload(wp, &m->dec_wp, m->owned)) || (rc = dev_upload(bias, &m->dec_bias, m->owned))) return rc;
+    for (int f = 0; f < 2; f++) {
+        pack_lstm(w->encoder, F_IN, 32, f ? 16 : 32, wp, bias);
+        if ((rc = dev_upload(wp, &m->enc_wp[f], m->owned))) return rc;
+        if (!f && (rc = dev_upload(bias, &m->enc_bias, m->owned))) return rc;
+        pack_lstm(w->decoder, 2 * H, 2 * H, f ? 16 : 32, wp, bias);
+        if ((rc = dev_upload(wp, &m->dec_wp[f], m->owned))) return rc;
+        if (!f && (rc = dev_upload(bias, &m->dec_bias, m->owned))) return rc;
+    }
     pack_linear(w->linear_w[0], HEAD_K, wp);
     if ((rc = dev_upload(wp, &m->w1p, m->owned)) || (rc = dev_upload(w->linear_b[0], HEAD_N, &m->b1, m->owned))) return rc;
     for (int i = 0; i < 4; i++) {
@@ -1137,37 +815,32 @@ extern "C" int pv_rnn_load_p1(pv_ctx* ctx, const pv_weights_p1* w, int dtype) {
         if ((rc = dev_upload(bcat, &m->dec_bias_cat, m->owned))) return rc;
         if ((rc = dev_upload_split(w->linear_w[0], HEAD_N, HEAD_K, &m->w1_h, &m->w1_l, m->owned))) return rc;
         PV_HIP(hipFuncSetAttribute((const void*)k_gemm_bf16x3, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_GEMM));
-        PV_HIP(hipFuncSetAttribute((const void*)k_lstm_rec_g, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_DEC_STAGGER));
+        PV_HIP(hipFuncSetAttribute((const void*)k_lstm_rec_g, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_REC));
     }
     // opt in to > 64 KB of dynamic LDS (exact sizes; static LDS counts against the 160 KB too)
-    PV_HIP(hipFuncSetAttribute((const void*)k_lstm_layer<32, true, 4, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_ENC));
-    PV_HIP(hipFuncSetAttribute((const void*)k_lstm_layer<512, false, 4, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_DEC));
-    PV_HIP(hipFuncSetAttribute((const void*)k_lstm_layer<32, true, 8, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_ENC));
-    PV_HIP(hipFuncSetAttribute((const void*)k_lstm_layer<32, true, 8, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_ENC));
-    PV_HIP(hipFuncSetAttribute((const void*)k_lstm_layer<512, false, 8, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_DEC));
-    PV_HIP(hipFuncSetAttribute((const void*)k_lstm_dec_stagger, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_DEC_STAGGER));
+    PV_HIP(hipFuncSetAttribute((const void*)k_lstm_layer<32, true, 32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_lstm<32, 32>()));
+    PV_HIP(hipFuncSetAttribute((const void*)k_lstm_layer<32, true, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_lstm<32, 16>()));
+    PV_HIP(hipFuncSetAttribute((const void*)k_lstm_layer<512, false, 32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_lstm<512, 32>()));
+    PV_HIP(hipFuncSetAttribute((const void*)k_lstm_layer<512, false, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_lstm<512, 16>()));
     PV_HIP(hipFuncSetAttribute((const void*)k_head_splitk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_SPLITK));
     PV_HIP(hipFuncSetAttribute((const void*)k_head_tail, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_TAIL));
     return PV_OK;
 }
 
 static int p1_forward_launch(pv_ctx* ctx, const int8_t* d_images, int64_t B, float* d_probs, float* enc_out,
-                             float* dec_out, float* part, hipStream_t st, float* enc_packed = nullptr) {
+                             float* dec_out, float* part, hipStream_t st) {
     pv_rnn_p1* m = ctx->p1;
-    const int n_tiles = (int)((B + ROWS - 1) / ROWS);
-    const unsigned lstm_grid = (unsigned)(((n_tiles + 3) / 4) * 8);
+    const int n_tiles = (int)((B + ROWS - 1) / ROWS);   // 32-row tiles: the granularity of every buffer and of the head
+    // LSTM tile form: 32-row tiles once (tile, direction) workgroups fill the chip, else 16-row tiles: twice the workgroups,
+    // half the MFMA cycles per time step (the bf16x3 mode keeps 32: its recurrence kernel has one form)
+    int tr = ((int64_t)n_tiles * 2 >= ctx->num_cu || m->dtype != PV_DTYPE_F32) ? 32 : 16;
+    if (const char* ev = getenv("PV_LSTM_ROWS")) { const int v = atoi(ev); if ((v == 16 && m->dtype == PV_DTYPE_F32) || v == 32) tr = v; }
+    const int f = tr == 16 ? 1 : 0;
+    const int n_lt = n_tiles * (ROWS / tr);             // whole 32-row tiles are covered in either form
+    const unsigned lstm_grid = (unsigned)(((n_lt + 3) / 4) * 8);
+    const unsigned rec_grid = (unsigned)(((n_tiles + 3) / 4) * 8);
     LstmArgs e;
-    e.ablate = getenv("PV_ABLATE") ? atoi(getenv("PV_ABLATE")) : 0;
-    e.stamps = nullptr;
-#ifdef PV_STAMPS
-    if (getenv("PV_STAMP_ENC")) {
-        unsigned long long* sp = nullptr;
-        if (pv_get(ctx, "p1.stamps", (size_t)lstm_grid * 8 * 4, &sp) == PV_OK) e.stamps = sp;
-    }
-#endif
-    const bool stag = m->dec_stagger >= 0 && enc_packed != nullptr && m->dtype == PV_DTYPE_F32;
-    e.x_i8 = d_images; e.x_f32 = nullptr; e.wp = m->enc_wp; e.bias = m->enc_bias; e.out = enc_out; e.B = B; e.n_tiles = n_tiles;
-    e.out_packed = stag ? enc_packed : nullptr;
+    e.x_i8 = d_images; e.x_f32 = nullptr; e.wp = m->enc_wp[f]; e.bias = m->enc_bias; e.out = enc_out; e.B = B; e.n_tiles = n_lt;
     e.out_cm = nullptr; e.cm_rows = 0;
     struct { float *enc_cm, *dec_cm; } bf = {nullptr, nullptr};
     if (m->dtype == PV_DTYPE_BF16_INPUT_GEMM) {
@@ -1178,9 +851,8 @@ static int p1_forward_launch(pv_ctx* ctx, const int8_t* d_images, int64_t B, flo
     }
     {
         pv_prof_scope ps(ctx, "k_lstm_layer_enc", st);
-        if (m->nw == 8 && stag) k_lstm_layer<32, true, 8, true><<<lstm_grid, 512, LDS_ENC, st>>>(e);
-        else if (m->nw == 8) k_lstm_layer<32, true, 8, false><<<lstm_grid, 512, LDS_ENC, st>>>(e);
-        else k_lstm_layer<32, true, 4, false><<<lstm_grid, 256, LDS_ENC, st>>>(e);
+        if (tr == 32) k_lstm_layer<32, true, 32><<<lstm_grid, 512, lds_lstm<32, 32>(), st>>>(e);
+        else k_lstm_layer<32, true, 16><<<lstm_grid, 512, lds_lstm<32, 16>(), st>>>(e);
     }
     if (m->dtype == PV_DTYPE_BF16_INPUT_GEMM) {
         // decoder: G = enc_out . W_ih^T + b on the bf16 MFMA (3-term split), then the fp32 recurrence on G
@@ -1196,10 +868,10 @@ static int p1_forward_launch(pv_ctx* ctx, const int8_t* d_images, int64_t B, flo
             k_gemm_bf16x3<<<dim3((unsigned)(((M + 127) / 128) * (2048 / 128)), 1), 256, LDS_GEMM, st>>>(ga);
         }
         RecArgs ra;
-        ra.G = G; ra.wp = m->dec_wp; ra.out = dec_out; ra.out_cm = bf.dec_cm; ra.cm_rows = Bp; ra.n_tiles = n_tiles;
+        ra.G = G; ra.wp = m->dec_wp[0]; ra.out = dec_out; ra.out_cm = bf.dec_cm; ra.cm_rows = Bp; ra.n_tiles = n_tiles;
         {
             pv_prof_scope ps(ctx, "k_lstm_rec_g", st);
-            k_lstm_rec_g<<<lstm_grid, 512, LDS_DEC_STAGGER, st>>>(ra);
+            k_lstm_rec_g<<<rec_grid, 512, LDS_REC, st>>>(ra);
         }
         // linear_1 as a split-K bf16x3 GEMM into slabs [splits][Bp][512]
         const int64_t mtiles = (Bp + 127) / 128;
@@ -1221,32 +893,11 @@ static int p1_forward_launch(pv_ctx* ctx, const int8_t* d_images, int64_t B, flo
         return PV_OK;
     }
     LstmArgs d = e;
-    d.stamps = nullptr;
-    d.x_i8 = nullptr; d.x_f32 = enc_out; d.wp = m->dec_wp; d.bias = m->dec_bias; d.out = dec_out;
-    d.out_packed = nullptr;
-#ifdef PV_STAMPS
+    d.x_i8 = nullptr; d.x_f32 = enc_out; d.wp = m->dec_wp[f]; d.bias = m->dec_bias; d.out = dec_out;
     {
-        unsigned long long* sp = nullptr;
-        if (!getenv("PV_STAMP_ENC") && pv_get(ctx, "p1.stamps", (size_t)lstm_grid * 8 * 4, &sp) == PV_OK) d.stamps = sp;
-    }
-#endif
-    if (stag) {
-        DecArgs da;
-        da.xp = enc_packed; da.wp = m->dec_wp; da.bias = m->dec_bias; da.out = dec_out; da.B = B; da.n_tiles = n_tiles;
-        da.stagger = m->dec_stagger;
-        da.stamps = nullptr;
-#ifdef PV_STAMPS
-        {
-            unsigned long long* sp = nullptr;
-            if (pv_get(ctx, "p1.stamps", (size_t)lstm_grid * 8 * 4, &sp) == PV_OK) da.stamps = sp;
-        }
-#endif
         pv_prof_scope ps(ctx, "k_lstm_layer_dec", st);
-        k_lstm_dec_stagger<<<lstm_grid, 512, LDS_DEC_STAGGER, st>>>(da);
-    } else {
-        pv_prof_scope ps(ctx, "k_lstm_layer_dec", st);
-        if (m->nw == 8) k_lstm_layer<512, false, 8, false><<<lstm_grid, 512, LDS_DEC, st>>>(d);
-        else k_lstm_layer<512, false, 4, false><<<lstm_grid, 256, LDS_DEC, st>>>(d);
+        if (tr == 32) k_lstm_layer<512, false, 32><<<lstm_grid, 512, lds_lstm<512, 32>(), st>>>(d);
+        else k_lstm_layer<512, false, 16><<<lstm_grid, 512, lds_lstm<512, 16>(), st>>>(d);
     }
     HeadArgs h;
     // split-K factor: 11 slabs of 3 time steps; 33 single-step slabs only for batches too small to fill the chip
@@ -1267,12 +918,8 @@ static int p1_forward_launch(pv_ctx* ctx, const int8_t* d_images, int64_t B, flo
     return PV_OK;
 }
 
-static int p1_workspace(pv_ctx* ctx, int64_t B, float** enc, float** dec, float** part, float** enc_packed = nullptr) {
+static int p1_workspace(pv_ctx* ctx, int64_t B, float** enc, float** dec, float** part) {
     int rc;
-    if (enc_packed) {
-        const size_t n_tiles = (size_t)((B + ROWS - 1) / ROWS);
-        if ((rc = pv_get(ctx, "p1.enc_packed", n_tiles * T_STEPS * 64 * 256, enc_packed))) return rc;
-    }
     const size_t Bp = (size_t)((B + ROWS - 1) / ROWS) * ROWS;  // LSTM kernels store whole 32-row tiles
     if ((rc = pv_get(ctx, "p1.enc_out", Bp * T_STEPS * 2 * H, enc))) return rc;
     if ((rc = pv_get(ctx, "p1.dec_out", Bp * T_STEPS * 2 * H, dec))) return rc;
@@ -1287,10 +934,9 @@ extern "C" int pv_rnn_forward_p1_dev(pv_ctx* ctx, const int8_t* d_images, int64_
     if (B == 0) return PV_OK;
     PV_HIP(hipSetDevice(ctx->device));
     float *enc, *dec, *part;
-    float* encp = nullptr;
-    int rc = p1_workspace(ctx, B, &enc, &dec, &part, ctx->p1->dec_stagger >= 0 ? &encp : nullptr);
+    int rc = p1_workspace(ctx, B, &enc, &dec, &part);
     if (rc) return rc;
-    return p1_forward_launch(ctx, d_images, B, d_probs, enc, dec, part, pv_pick_stream(ctx, stream), encp);
+    return p1_forward_launch(ctx, d_images, B, d_probs, enc, dec, part, pv_pick_stream(ctx, stream));
 }
 
 extern "C" int pv_rnn_forward_p1_debug(pv_ctx* ctx, const int8_t* images, int64_t B, float* probs, float* enc_out,
@@ -1303,15 +949,12 @@ extern "C" int pv_rnn_forward_p1_debug(pv_ctx* ctx, const int8_t* images, int64_
     hipStream_t st = ctx->stream;
     float *enc, *dec, *part, *d_probs;
     int8_t* d_img;
-    // the encoder tap needs the row-major encoder output, which only the barrier decoder path produces
-    float* encp = nullptr;
-    const bool want_packed = ctx->p1->dec_stagger >= 0 && !enc_out;
-    int rc = p1_workspace(ctx, B, &enc, &dec, &part, want_packed ? &encp : nullptr);
+    int rc = p1_workspace(ctx, B, &enc, &dec, &part);
     if (rc) return rc;
     if ((rc = pv_get(ctx, "p1.images", (size_t)B * PV_WINDOW_BYTES, &d_img))) return rc;
     if ((rc = pv_get(ctx, "p1.probs", (size_t)B * 3, &d_probs))) return rc;
     PV_HIP(hipMemcpyAsync(d_img, images, (size_t)B * PV_WINDOW_BYTES, hipMemcpyHostToDevice, st));
-    if ((rc = p1_forward_launch(ctx, d_img, B, d_probs, enc, dec, part, st, encp))) return rc;
+    if ((rc = p1_forward_launch(ctx, d_img, B, d_probs, enc, dec, part, st))) return rc;
     PV_HIP(hipMemcpyAsync(probs, d_probs, (size_t)B * 3 * sizeof(float), hipMemcpyDeviceToHost, st));
     const size_t nb = (size_t)B * T_STEPS * 2 * H * sizeof(float);
     if (enc_out) PV_HIP(hipMemcpyAsync(enc_out, enc, nb, hipMemcpyDeviceToHost, st));
@@ -1326,13 +969,3 @@ extern "C" int pv_rnn_forward_p1(pv_ctx* ctx, const int8_t* images, int64_t B, f
 
 // ---- P2 (bi-GRU polisher model): see rnn_gru.hip ----------------------------------------------------
 
-#ifdef PV_STAMPS
-// diagnostic builds only: copy the phase stamps of the last staggered-decoder launch to the host
-extern "C" int pv_debug_read_stamps(pv_ctx* ctx, unsigned long long* out, int64_t n) {
-    unsigned long long* sp = nullptr;
-    if (pv_get(ctx, "p1.stamps", (size_t)n, &sp)) return PV_ERR_HIP;
-    PV_HIP(hipDeviceSynchronize());
-    PV_HIP(hipMemcpy(out, sp, (size_t)n * sizeof(unsigned long long), hipMemcpyDeviceToHost));
-    return PV_OK;
-}
-#endif

@@ -20,8 +20,10 @@ def gold():
     return np.load(GOLD, allow_pickle=False)
 
 
+@pytest.mark.parametrize("rows", ["16", "32"])
 @pytest.mark.parametrize("tag", ["p1", "p1sharp"])
-def test_p1_matches_reference_golden(hip_ctx, gold, tag):
+def test_p1_matches_reference_golden(hip_ctx, gold, tag, rows, monkeypatch):
+    monkeypatch.setenv("PV_LSTM_ROWS", rows)  # both tile forms of k_lstm_layer (16x16x4 and 32x32x2 MFMA)
     w = synth.make_weights_p1(int(gold[tag + "/seed"][0]), float(gold[tag + "/gain"][0]))
     hip_ctx.load_p1(w)
     probs, enc, dec = hip_ctx.forward_p1(gold[tag + "/images"], taps=True)
@@ -30,9 +32,11 @@ def test_p1_matches_reference_golden(hip_ctx, gold, tag):
     np.testing.assert_allclose(probs, gold[tag + "/probs"], atol=TOL_PROBS, rtol=0)
 
 
-@pytest.mark.parametrize("B", [1, 31, 32, 33, 100, 512])
-def test_p1_ragged_batches_vs_oracle(hip_ctx, B):
-    """batch sizes around the 32-row tile edge; the oracle runs in float64"""
+@pytest.mark.parametrize("rows", ["16", "32"])
+@pytest.mark.parametrize("B", [1, 15, 16, 17, 31, 32, 33, 100, 512])
+def test_p1_ragged_batches_vs_oracle(hip_ctx, B, rows, monkeypatch):
+    """batch sizes around the 16- and 32-row tile edges, both tile forms; the oracle runs in float64"""
+    monkeypatch.setenv("PV_LSTM_ROWS", rows)
     w = synth.make_weights_p1(99, 2.5)
     hip_ctx.load_p1(w)
     x = synth.synth_windows(1000 + B, B)
