@@ -97,26 +97,25 @@ __device__ __forceinline__ void mma_dual_ringb(Gate<TR> (&acc)[NT], const float*
 #undef RB_F
 }
 
-// Single-operand form over a CONTINUING weight stream (32-row tiles): multiplies k-blocks [kpos, kpos + nkb) of the stream
-// behind `wr` with A[32 x 8*nkb] in LDS. On entry bq slots 0..2 hold k-blocks kpos..kpos+2; on exit they hold
-// kpos+nkb..kpos+nkb+2, i.e. the next call's first blocks, so consecutive calls (time steps of linear_1) never start with
-// a cold L2/HBM round trip. Requests beyond the resource's size return zeros. nkb % 4 == 0.
-// Fragment layout: wp[(kb*NT + nt)*256 + lane*4 + j] = W[n(nt, lane&31)][8*kb + 4*(lane>>5) + j]; MFMA j of a k-block
-// multiplies k = 8kb + 4*(lane>>5) + j, a permutation of the K order inside a block that only changes the (fp32)
-// summation order.
-template <int NT>
-__device__ __forceinline__ void mma_stream_ringb(f32x16 (&acc)[NT], const float* __restrict__ A, int lda, int nkb,
+// Single-operand form over a CONTINUING weight stream: multiplies k-blocks [kpos, kpos + nkb) of the stream behind `wr`
+// with A[TR x 8*nkb] in LDS. On entry bq slots 0..2 hold k-blocks kpos..kpos+2; on exit they hold kpos+nkb..kpos+nkb+2,
+// i.e. the next call's first blocks, so consecutive calls (time steps of linear_1) never start with a cold L2/HBM round
+// trip. Requests beyond the resource's size return zeros. nkb % 4 == 0. Fragment layouts: mfma_tiles.hpp (the K order
+// inside a k-block is a permutation of 0..7, which only changes the fp32 summation order).
+template <int TR, int NT>
+__device__ __forceinline__ void mma_stream_ringb(Gate<TR> (&acc)[NT], const float* __restrict__ A, int lda, int nkb,
                                                  __amdgpu_buffer_rsrc_t wr, int kpos, f32x4 (&bq)[4][NT], int lane) {
-    const float* ap = A + (lane & 31) * lda + 4 * (lane >> 5);
+    typedef typename AFrag<TR>::type afrag;
+    constexpr int NJ = TR == 32 ? 4 : 2;
+    const float* ap = afrag_ptr<TR>(A, lda, lane);
     const unsigned lane16 = (unsigned)lane * 16u;
-    f32x4 aq[2];
+    afrag aq[2];
 #define RB_B(slot, kbv) { _Pragma("unroll") for (int nt = 0; nt < NT; nt++) bq[slot][nt] = buf_load4(wr, lane16, (unsigned)(((kpos + (kbv)) * NT + nt) * 1024)); }
-#define RB_A(slot, kbv) { aq[slot] = *reinterpret_cast<const f32x4*>(ap + 8 * (kbv)); }
+#define RB_A(slot, kbv) { aq[slot] = *reinterpret_cast<const afrag*>(ap + 8 * (kbv)); }
 #define RB_M(bs, as)                                                                    \
     {                                                                                   \
-        _Pragma("unroll") for (int j = 0; j < 4; j++)                                   \
-            _Pragma("unroll") for (int nt = 0; nt < NT; nt++)                           \
-                acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(aq[as][j], bq[bs][nt][j], acc[nt], 0, 0, 0); \
+        _Pragma("unroll") for (int j = 0; j < NJ; j++)                                  \
+            _Pragma("unroll") for (int nt = 0; nt < NT; nt++) gate_mma<TR>(acc[nt], aq[as], bq[bs][nt], j); \
     }
 #define RB_F __builtin_amdgcn_sched_barrier(0);
     RB_A(0, 0)
@@ -314,11 +313,11 @@ __global__ __launch_bounds__(256, 1) void k_head_splitk(HeadArgs a) {
         tile = blockIdx.x / a.splits; split = blockIdx.x - tile * a.splits;
     }
     const int64_t b0 = (int64_t)tile * ROWS;
-    f32x16 acc[4];
+    Gate<32> acc[4];
 #pragma unroll
     for (int nt = 0; nt < 4; nt++)
 #pragma unroll
-        for (int r = 0; r < 16; r++) acc[nt][r] = 0.0f;
+        for (int r = 0; r < 16; r++) acc[nt].v[r] = 0.0f;
     // this wave's slice of the packed linear_1 weights is one contiguous stream over all 33 time steps
     const __amdgpu_buffer_rsrc_t wr = make_rsrc_sized(a.w1p + (size_t)wv * (HEAD_K / 8) * 4 * 256, (unsigned)((HEAD_K / 8) * 4 * 256 * sizeof(float)));
     f32x4 bq[4][4];
@@ -344,7 +343,7 @@ __global__ __launch_bounds__(256, 1) void k_head_splitk(HeadArgs a) {
     for (int st = 0; st < a.steps_per_split; st++) {
         const int t = split * a.steps_per_split + st;
         if (st + 1 < a.steps_per_split) a_load(t + 1);
-        mma_stream_ringb<4>(acc, abuf, LDA, KC / 8, wr, t * (KC / 8), bq, lane);
+        mma_stream_ringb<32, 4>(acc, abuf, LDA, KC / 8, wr, t * (KC / 8), bq, lane);
         if (st + 1 < a.steps_per_split) {
             __syncthreads();  // every wave is done reading abuf
             a_store();
@@ -358,7 +357,7 @@ __global__ __launch_bounds__(256, 1) void k_head_splitk(HeadArgs a) {
 #pragma unroll
         for (int r = 0; r < 16; r++) {
             const int64_t b = b0 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-            if (b < a.B) dst[b * HEAD_N + n] = acc[nt][r];
+            if (b < a.B) dst[b * HEAD_N + n] = acc[nt].v[r];
         }
     }
 }
@@ -376,16 +375,20 @@ struct TailArgs {
     int64_t B;
 };
 
+// TR = batch rows per workgroup: 32, or 16 when 32-row tiles would leave CUs idle (the tail is a chain of four dependent
+// 512x512 layers per tile). wp[layer] is the packed stream of the matching tile form (pack_linear).
+template <int TR>
 __global__ __launch_bounds__(256, 1) void k_head_tail(TailArgs a) {
     constexpr int LDY = HEAD_N + 4;
+    constexpr int NE = TR / 2;
     extern __shared__ float smem[];
-    float* y0 = smem;               // [32][LDY]
-    float* y1 = smem + ROWS * LDY;  // [32][LDY]
-    __shared__ float logits[ROWS][4];
+    float* y0 = smem;             // [TR][LDY]
+    float* y1 = smem + TR * LDY;  // [TR][LDY]
+    __shared__ float logits[TR][4];
     const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int64_t b0 = (int64_t)blockIdx.x * ROWS;
+    const int64_t b0 = (int64_t)blockIdx.x * TR;
     // y0 = selu(sum of slabs + b1)   (simple_model.py:57-59)
-    for (int i = tid; i < ROWS * HEAD_N; i += 256) {
+    for (int i = tid; i < TR * HEAD_N; i += 256) {
         const int row = i / HEAD_N, n = i - row * HEAD_N;
         int64_t b = b0 + row;
         if (b >= a.B) b = a.B - 1;
@@ -397,37 +400,32 @@ __global__ __launch_bounds__(256, 1) void k_head_tail(TailArgs a) {
     __syncthreads();
     float* src = y0;
     float* dst = y1;
+    const int unit0 = 128 * wv + lane_unit<TR>(lane);  // + 32*nt + elem_unit(e)
     for (int layer = 0; layer < 4; layer++) {  // linear_2..5 + SELU (:61-76)
-        f32x16 acc[4];
+        Gate<TR> acc[4];
 #pragma unroll
-        for (int nt = 0; nt < 4; nt++) {
-            const float bv = a.b[layer][128 * wv + 32 * nt + (lane & 31)];
+        for (int nt = 0; nt < 4; nt++)
 #pragma unroll
-            for (int r = 0; r < 16; r++) acc[nt][r] = bv;
-        }
+            for (int e = 0; e < NE; e++) gate_set<TR>(acc[nt], e, a.b[layer][unit0 + 32 * nt + elem_unit<TR>(e)]);
         {
             const __amdgpu_buffer_rsrc_t wr = make_rsrc_sized(a.wp[layer] + (size_t)wv * (HEAD_N / 8) * 4 * 256,
                                                               (unsigned)((HEAD_N / 8) * 4 * 256 * sizeof(float)));
             f32x4 bq[4][4];
             ring_prime<4>(bq, wr, 0, lane);
-            mma_stream_ringb<4>(acc, src, LDY, HEAD_N / 8, wr, 0, bq, lane);
+            mma_stream_ringb<TR, 4>(acc, src, LDY, HEAD_N / 8, wr, 0, bq, lane);
         }
 #pragma unroll
-        for (int nt = 0; nt < 4; nt++) {
-            const int n = 128 * wv + 32 * nt + (lane & 31);
+        for (int nt = 0; nt < 4; nt++)
 #pragma unroll
-            for (int r = 0; r < 16; r++) {
-                const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                dst[row * LDY + n] = seluf_(acc[nt][r]);
-            }
-        }
+            for (int e = 0; e < NE; e++)
+                dst[(lane_row<TR>(lane) + elem_row<TR>(e)) * LDY + unit0 + 32 * nt + elem_unit<TR>(e)] = seluf_(gate_get<TR>(acc[nt], e));
         __syncthreads();
         float* tmp = src; src = dst; dst = tmp;
     }
     // output_layer_type (512 -> 3) + softmax(dim=1) (:77-82): 8 lanes per (row, class) pair
     {
         const int pair = tid >> 3, sub = tid & 7;  // 32 pairs per pass
-        for (int p = pair; p < ROWS * 3; p += 32) {
+        for (int p = pair; p < TR * 3; p += 32) {
             const int row = p / 3, cls = p - row * 3;
             float s = 0.0f;
             for (int k = sub; k < HEAD_N; k += 8) s += src[row * LDY + k] * a.wo[cls * HEAD_N + k];
@@ -438,7 +436,7 @@ __global__ __launch_bounds__(256, 1) void k_head_tail(TailArgs a) {
         }
     }
     __syncthreads();
-    if (tid < ROWS) {
+    if (tid < TR) {
         const int64_t b = b0 + tid;
         if (b < a.B) {
             const float l0 = logits[tid][0], l1 = logits[tid][1], l2 = logits[tid][2];
@@ -677,17 +675,23 @@ static void pack_lstm(const pv_rnn_dir* dirs, int K, int KP, int TR, std::vector
     }
 }
 
-// Linear [512, K]: column of (wave w, tile nt, lane) = 128w + 32nt + (lane&31)
-static void pack_linear(const float* W, int K, std::vector<float>& wp) {
+// Linear [512, K]: wave w owns columns [128w, 128w+128) as four 32-column "gate tiles" nt; tile forms as in pack_lstm
+static void pack_linear(const float* W, int K, int TR, std::vector<float>& wp) {
     const int nkb = K / 8;
     wp.assign((size_t)4 * nkb * 4 * 256, 0.0f);
     for (int w = 0; w < 4; w++)
         for (int kb = 0; kb < nkb; kb++)
             for (int nt = 0; nt < 4; nt++)
                 for (int lane = 0; lane < 64; lane++) {
-                    const int n = 128 * w + 32 * nt + (lane & 31);
                     float* dst = &wp[((((size_t)w * nkb + kb) * 4 + nt) * 64 + lane) * 4];
-                    for (int j = 0; j < 4; j++) dst[j] = W[(size_t)n * K + kb * 8 + 4 * (lane >> 5) + j];
+                    if (TR == 32) {
+                        const int n = 128 * w + 32 * nt + (lane & 31);
+                        for (int j = 0; j < 4; j++) dst[j] = W[(size_t)n * K + kb * 8 + 4 * (lane >> 5) + j];
+                    } else {
+                        for (int t = 0; t < 2; t++)
+                            for (int j = 0; j < 2; j++)
+                                dst[2 * t + j] = W[(size_t)(128 * w + 32 * nt + 16 * t + (lane & 15)) * K + kb * 8 + 2 * (lane >> 4) + j];
+                    }
                 }
 }
 
@@ -697,14 +701,14 @@ template <int KP, int TR> constexpr size_t lds_lstm() { return (size_t)(TR * (KP
 static constexpr size_t LDS_REC = (size_t)(2 * ROWS * (H + 4)) * sizeof(float);
 static constexpr size_t LDS_GEMM = (size_t)4 * 2 * 128 * 40 * 2;  // 4 operand arrays x 2 buffers x 128 rows x 40 bf16
 static constexpr size_t LDS_SPLITK = (size_t)ROWS * (2 * H + 4) * sizeof(float);
-static constexpr size_t LDS_TAIL = (size_t)2 * ROWS * (HEAD_N + 4) * sizeof(float);
+template <int TR> constexpr size_t lds_tail() { return (size_t)2 * TR * (HEAD_N + 4) * sizeof(float); }
 
 struct pv_rnn_p1 {
     float* enc_wp[2] = {nullptr, nullptr};  // [0] 32-row tile form, [1] 16-row tile form (mfma_tiles.hpp)
     float* dec_wp[2] = {nullptr, nullptr};
     float* enc_bias = nullptr; float* dec_bias = nullptr;
     float* w1p = nullptr; float* b1 = nullptr;
-    float* wlp[4] = {nullptr, nullptr, nullptr, nullptr};
+    float* wlp[2][4] = {{nullptr, nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr, nullptr}};  // [tile form][layer]
     float* bl[4] = {nullptr, nullptr, nullptr, nullptr};
     float* wo = nullptr; float* bo = nullptr;
     int dtype = PV_DTYPE_F32;
@@ -797,12 +801,14 @@ extern "C" int pv_rnn_load_p1(pv_ctx* ctx, const pv_weights_p1* w, int dtype) {
         if ((rc = dev_upload(wp, &m->dec_wp[f], m->owned))) return rc;
         if (!f && (rc = dev_upload(bias, &m->dec_bias, m->owned))) return rc;
     }
-    pack_linear(w->linear_w[0], HEAD_K, wp);
+    pack_linear(w->linear_w[0], HEAD_K, 32, wp);
     if ((rc = dev_upload(wp, &m->w1p, m->owned)) || (rc = dev_upload(w->linear_b[0], HEAD_N, &m->b1, m->owned))) return rc;
     for (int i = 0; i < 4; i++) {
-        pack_linear(w->linear_w[i + 1], HEAD_N, wp);
-        if ((rc = dev_upload(wp, &m->wlp[i], m->owned)) || (rc = dev_upload(w->linear_b[i + 1], HEAD_N, &m->bl[i], m->owned)))
-            return rc;
+        for (int f = 0; f < 2; f++) {
+            pack_linear(w->linear_w[i + 1], HEAD_N, f ? 16 : 32, wp);
+            if ((rc = dev_upload(wp, &m->wlp[f][i], m->owned))) return rc;
+        }
+        if ((rc = dev_upload(w->linear_b[i + 1], HEAD_N, &m->bl[i], m->owned))) return rc;
     }
     if ((rc = dev_upload(w->out_w, 3 * HEAD_N, &m->wo, m->owned)) || (rc = dev_upload(w->out_b, 3, &m->bo, m->owned))) return rc;
     if (dtype == PV_DTYPE_BF16_INPUT_GEMM) {
@@ -823,8 +829,19 @@ extern "C" int pv_rnn_load_p1(pv_ctx* ctx, const pv_weights_p1* w, int dtype) {
     PV_HIP(hipFuncSetAttribute((const void*)k_lstm_layer<512, false, 32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_lstm<512, 32>()));
     PV_HIP(hipFuncSetAttribute((const void*)k_lstm_layer<512, false, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_lstm<512, 16>()));
     PV_HIP(hipFuncSetAttribute((const void*)k_head_splitk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_SPLITK));
-    PV_HIP(hipFuncSetAttribute((const void*)k_head_tail, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_TAIL));
+    PV_HIP(hipFuncSetAttribute((const void*)k_head_tail<32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_tail<32>()));
+    PV_HIP(hipFuncSetAttribute((const void*)k_head_tail<16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_tail<16>()));
     return PV_OK;
+}
+
+// tail of the head: 16-row tiles unless 32-row tiles already fill the chip
+static void launch_tail(pv_ctx* ctx, pv_rnn_p1* m, TailArgs& t, int n_tiles32, hipStream_t st) {
+    int tr = n_tiles32 >= ctx->num_cu ? 32 : 16;
+    if (const char* ev = getenv("PV_TAIL_ROWS")) { const int v = atoi(ev); if (v == 16 || v == 32) tr = v; }
+    for (int i = 0; i < 4; i++) { t.wp[i] = m->wlp[tr == 16 ? 1 : 0][i]; t.b[i] = m->bl[i]; }
+    pv_prof_scope ps(ctx, "k_head_tail", st);
+    if (tr == 32) k_head_tail<32><<<(unsigned)n_tiles32, 256, lds_tail<32>(), st>>>(t);
+    else k_head_tail<16><<<(unsigned)(2 * n_tiles32), 256, lds_tail<16>(), st>>>(t);
 }
 
 static int p1_forward_launch(pv_ctx* ctx, const int8_t* d_images, int64_t B, float* d_probs, float* enc_out,
@@ -886,9 +903,8 @@ static int p1_forward_launch(pv_ctx* ctx, const int8_t* d_images, int64_t B, flo
         }
         TailArgs tb;
         tb.part = part; tb.b1 = m->b1; tb.splits = gs; tb.part_rows = Bp;
-        for (int i = 0; i < 4; i++) { tb.wp[i] = m->wlp[i]; tb.b[i] = m->bl[i]; }
         tb.wo = m->wo; tb.bo = m->bo; tb.probs = d_probs; tb.B = B;
-        { pv_prof_scope ps(ctx, "k_head_tail", st); k_head_tail<<<(unsigned)n_tiles, 256, LDS_TAIL, st>>>(tb); }
+        launch_tail(ctx, m, tb, n_tiles, st);
         PV_HIP(hipGetLastError());
         return PV_OK;
     }
@@ -911,9 +927,8 @@ static int p1_forward_launch(pv_ctx* ctx, const int8_t* d_images, int64_t B, flo
     { pv_prof_scope ps(ctx, "k_head_splitk", st); k_head_splitk<<<head_grid, 256, LDS_SPLITK, st>>>(h); }
     TailArgs t;
     t.part = part; t.b1 = m->b1; t.splits = splits; t.part_rows = B;
-    for (int i = 0; i < 4; i++) { t.wp[i] = m->wlp[i]; t.b[i] = m->bl[i]; }
     t.wo = m->wo; t.bo = m->bo; t.probs = d_probs; t.B = B;
-    { pv_prof_scope ps(ctx, "k_head_tail", st); k_head_tail<<<(unsigned)n_tiles, 256, LDS_TAIL, st>>>(t); }
+    launch_tail(ctx, m, t, n_tiles, st);
     PV_HIP(hipGetLastError());
     return PV_OK;
 }
