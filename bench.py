@@ -167,6 +167,29 @@ def p2_secondary(ctx, dev):
     return out
 
 
+def single_call_secondary(ctx, dev):
+    """secondary: ONE caller's batches through pv_rnn_forward_p1_dev alone (no caller fusion, no image builder), i.e. what
+    a single `run_inference -bs 512` loop sees, and the same call at 2048 and 4096 windows. Not part of `value`."""
+    import torch
+    from pepper_thesis_amd import synth
+    out = {}
+    for B in (512, 2048, 4096):
+        x = torch.from_numpy(synth.synth_windows(3, B)).to(dev)
+        probs = torch.zeros((B, 3), dtype=torch.float32, device=dev)
+        for _ in range(2):
+            ctx.forward_p1_dev(x.data_ptr(), B, probs.data_ptr())
+        ctx.synchronize()
+        ctx.profile_begin()
+        for _ in range(5):
+            ctx.forward_p1_dev(x.data_ptr(), B, probs.data_ptr())
+        prof = ctx.profile_end()
+        ms = sum(v[0] / v[1] for v in prof.values())
+        out["B%d" % B] = {"ms": ms, "windows_per_s": B / ms * 1e3, "tflops": FLOP_PER_WINDOW * B / ms / 1e9,
+                          "frac_of_f32_peak": FLOP_PER_WINDOW * B / ms / 1e9 / PEAK_F32_TFLOPS}
+        del x, probs
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -333,6 +356,10 @@ def main():
             except Exception as e:
                 out["config2_bf16_input_gemm"] = {"error": repr(e)}
         if world == 1 and not args.no_p2:
+            try:
+                out["p1_single_call"] = single_call_secondary(ctx, dev)
+            except Exception as e:
+                out["p1_single_call"] = {"error": repr(e)}
             try:
                 out["p2_bigru"] = p2_secondary(ctx, dev)
             except Exception as e:

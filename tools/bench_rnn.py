@@ -25,4 +25,4 @@ tot = 0.0
 for k, (ms, n) in prof.items():
     print("%-20s %8.3f ms" % (k, ms / n))
     tot += ms / n
-print("B=%d total %.3f ms -> %.0f windows/s (PV_LSTM_WAVES=%s)" % (B, tot, B / tot * 1e3, os.environ.get("PV_LSTM_WAVES", "8")) + " dtype=" + os.environ.get("PV_BENCH_DTYPE", "0"))
+print("B=%d total %.3f ms -> %.0f windows/s (PV_LSTM_ROWS=%s)" % (B, tot, B / tot * 1e3, os.environ.get("PV_LSTM_ROWS", "auto")) + " dtype=" + os.environ.get("PV_BENCH_DTYPE", "0"))
