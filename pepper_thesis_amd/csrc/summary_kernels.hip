@@ -353,6 +353,13 @@ __global__ __launch_bounds__(PT_THREADS) void k_pileup_tiles(SumArgs a) {
     __shared__ int32_t s_wsum[PT_THREADS / 64];
     const int tid = threadIdx.x;
     const int64_t tile = blockIdx.x;
+#ifdef PV_PSTAMPS
+    unsigned long long ps_t0, ps_t1, ps_acc[6] = {0, 0, 0, 0, 0, 0};
+#define PSTAMP(i) { asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(ps_t1) :: "memory"); ps_acc[i] += ps_t1 - ps_t0; ps_t0 = ps_t1; }
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(ps_t0) :: "memory");
+#else
+#define PSTAMP(i)
+#endif
     const int64_t tlo = tile * TILE_COLS, thi = tlo + TILE_COLS - 1;  // global columns of this tile
     for (int i = tid; i < L_N * TILE_COLS; i += PT_THREADS) (&s_cnt[0][0])[i] = 0;
     for (int i = tid; i < TILE_COLS + 4; i += PT_THREADS) s_ref[i] = (i < TILE_COLS && tlo + i < a.n_cols) ? a.in.ref[tlo + i] : (uint8_t)'N';
@@ -375,6 +382,7 @@ __global__ __launch_bounds__(PT_THREADS) void k_pileup_tiles(SumArgs a) {
         if (tid == 0) p_off[0] = 0;
         __syncthreads();
         const int total_ops = p_off[npb];
+        PSTAMP(0)  // pair batch
         for (int ob = 0; ob < total_ops; ob += PT_THREADS) {
             // ---- op batch: one thread per op -----------------------------------------------------------
             const int k = ob + tid;
@@ -417,9 +425,20 @@ __global__ __launch_bounds__(PT_THREADS) void k_pileup_tiles(SumArgs a) {
                         set_status(a.diag, PV_ERR_INVALID);
                     } else {
                         int64_t qs = 0;
-                        for (int64_t i = 0; i < L; i++) qs += a.in.quals[start + i];
+                        int q0;
+                        if (L <= 8 && start + 8 <= a.n_bases) {  // the usual short insert: ONE round trip instead of L dependent ones
+                            uint32_t lo = *reinterpret_cast<const uint32_t*>(a.in.quals + start);
+                            uint32_t hi = *reinterpret_cast<const uint32_t*>(a.in.quals + start + 4);
+                            if (L <= 4) { hi = 0; if (L < 4) lo &= (1u << (8 * (int)L)) - 1u; }
+                            else if (L < 8) hi &= (1u << (8 * ((int)L - 4))) - 1u;
+                            q0 = (int)(lo & 0xFF);
+                            qs = (int64_t)__builtin_amdgcn_sad_u8(lo, 0u, __builtin_amdgcn_sad_u8(hi, 0u, 0u));
+                        } else {
+                            for (int64_t i = 0; i < L; i++) qs += a.in.quals[start + i];
+                            q0 = a.in.quals[start];
+                        }
                         const bool qok = (double)qs >= a.p.min_indel_baseq * (double)L;
-                        if (qok && (double)a.in.quals[start] < a.p.min_snp_baseq) atomicAdd(&s_cnt[L_COVI][SW(lc)], 1);  // :453
+                        if (qok && (double)q0 < a.p.min_snp_baseq) atomicAdd(&s_cnt[L_COVI][SW(lc)], 1);  // :453
                         if (1 + L <= PV_MAX_ALLELE_KEY && qok) {
                             if (is_acgt(up(s_ref[lc]))) atomicAdd(&s_cnt[so + 0][SW(lc)], 1);
                             atomicAdd(&s_cnt[L_INS][SW(lc)], 1);
@@ -447,6 +466,7 @@ __global__ __launch_bounds__(PT_THREADS) void k_pileup_tiles(SumArgs a) {
                 }
             }
             // (2) aligned bases of the batch's M/=/X ops, clipped to tile and region
+            PSTAMP(1)  // op lookup + indel ops
             const bool is_m = active && (op == PV_CIGAR_MATCH || op == PV_CIGAR_EQUAL || op == PV_CIGAR_DIFF);
             int32_t i0 = 0, eff = 0;
             if (is_m) {
@@ -469,10 +489,11 @@ __global__ __launch_bounds__(PT_THREADS) void k_pileup_tiles(SumArgs a) {
             for (int32_t bb = (incl - effp + 63) >> 6; (bb << 6) < incl; bb++) s_blk[bb] = (uint16_t)tid;  // blocks starting inside this op
             __syncthreads();
             const int32_t total = s_pref[PT_THREADS - 1];
-            // ---- expansion: PT_GPL groups of 4 consecutive bases per thread per trip -----------------------------
-            for (int32_t jb = 0; jb < total; jb += PT_THREADS * PT_GPL * 4) {
-                int lcv[PT_GPL], nvv[PT_GPL], fl[PT_GPL], lastv[PT_GPL];
-                uint32_t bw[PT_GPL], qw[PT_GPL], rw[PT_GPL];
+            PSTAMP(2)  // scan + staging + barrier
+            // ---- expansion: PT_GPL groups of 4 consecutive bases per thread per trip; the owner lookups and the loads of
+            // trip t+1 are issued before trip t is counted, so the HBM round trip of the bases hides behind the ds_adds ----
+            struct Grp { int lc, nv, fl, last; uint32_t bw, qw, rw; };
+            auto look = [&](int32_t jb, Grp (&g)[PT_GPL]) {
 #pragma unroll
                 for (int u = 0; u < PT_GPL; u++) {
                     // consecutive lanes take consecutive groups: the dword loads of a wave cover 256 consecutive bytes of a run
@@ -487,11 +508,11 @@ __global__ __launch_bounds__(PT_THREADS) void k_pileup_tiles(SumArgs a) {
                     const int64_t left = p_seqend[s_opair[owc]] - bi;
                     if (nv > 0 && nv > left) { set_status(a.diag, PV_ERR_INVALID); nv = left > 0 ? (int)left : 0; }
                     const int lc = (int)((int64_t)s_col0[owc] + i - tlo);
-                    lcv[u] = lc;
-                    nvv[u] = nv;
+                    g[u].lc = lc;
+                    g[u].nv = nv;
                     const int f = s_opfl[owc];
-                    fl[u] = f & 1;
-                    lastv[u] = (f & 2) ? s_meta[owc] - i : -1;  // group position of the op's last base, if that base anchors an indel
+                    g[u].fl = f & 1;
+                    g[u].last = (f & 2) ? s_meta[owc] - i : -1;  // group position of the op's last base, if that base anchors an indel
                     uint32_t b4 = 0, q4 = 0;
                     if (nv > 0) {
                         if (bi + 4 <= a.n_bases) {  // unaligned dword loads
@@ -504,19 +525,21 @@ __global__ __launch_bounds__(PT_THREADS) void k_pileup_tiles(SumArgs a) {
                             }
                         }
                     }
-                    bw[u] = b4; qw[u] = q4;
+                    g[u].bw = b4; g[u].qw = q4;
                     const int lcr = nv > 0 ? lc : 0;
-                    rw[u] = (uint32_t)s_ref[lcr] | ((uint32_t)s_ref[lcr + 1] << 8) | ((uint32_t)s_ref[lcr + 2] << 16) | ((uint32_t)s_ref[lcr + 3] << 24);
+                    g[u].rw = (uint32_t)s_ref[lcr] | ((uint32_t)s_ref[lcr + 1] << 8) | ((uint32_t)s_ref[lcr + 2] << 16) | ((uint32_t)s_ref[lcr + 3] << 24);
                 }
+            };
+            auto count = [&](const Grp (&g)[PT_GPL]) {
 #pragma unroll
                 for (int u = 0; u < PT_GPL; u++) {
 #pragma unroll
                     for (int e = 0; e < 4; e++) {
-                        const int base = (bw[u] >> (8 * e)) & 0xFF, refb = (rw[u] >> (8 * e)) & 0xFF;
-                        const int q = (qw[u] >> (8 * e)) & 0xFF;
-                        if (e >= nvv[u] || q < a.qmin_snp) continue;
-                        const int lc = lcv[u] + e;
-                        const int st = fl[u];
+                        const int base = (g[u].bw >> (8 * e)) & 0xFF, refb = (g[u].rw >> (8 * e)) & 0xFF;
+                        const int q = (g[u].qw >> (8 * e)) & 0xFF;
+                        if (e >= g[u].nv || q < a.qmin_snp) continue;
+                        const int lc = g[u].lc + e;
+                        const int st = g[u].fl;
                         const int cb = s_lut[base];
                         const bool refvalid = (s_lut[refb] & 32) != 0;
                         const int sy = cb & 7;                                           // 1..7
@@ -526,7 +549,7 @@ __global__ __launch_bounds__(PT_THREADS) void k_pileup_tiles(SumArgs a) {
                             atomicAdd(&s_cnt[L_X + st][SW(lc)], 1);
                             if (refvalid) atomicAdd(&s_cnt[L_O + 3 * st + (sy - 5)][SW(lc)], 1);
                         }
-                        if (e == lastv[u]) atomicAdd(&s_cnt[L_ANC + st][SW(lc)], 1);
+                        if (e == g[u].last) atomicAdd(&s_cnt[L_ANC + st][SW(lc)], 1);
                         const bool mism = refb != base;                                  // raw bytes, :394
                         if (mism) atomicAdd(&s_cnt[L_SNP][SW(lc)], 1);
                         const bool rare = mism && !(refvalid && (cb & 8));
@@ -534,13 +557,27 @@ __global__ __launch_bounds__(PT_THREADS) void k_pileup_tiles(SumArgs a) {
                         if (rare || corr) atomicAdd(&s_cnt[L_RARE][SW(lc)], 1);
                     }
                 }
+            };
+            constexpr int32_t TRIP = PT_THREADS * PT_GPL * 4;
+            Grp ga[PT_GPL], gb[PT_GPL];
+            if (total > 0) look(0, ga);
+            for (int32_t jb = 0; jb < total; jb += 2 * TRIP) {
+                if (jb + TRIP < total) look(jb + TRIP, gb);
+                count(ga);
+                if (jb + TRIP < total) {
+                    if (jb + 2 * TRIP < total) look(jb + 2 * TRIP, ga);
+                    count(gb);
+                }
             }
+            PSTAMP(3)  // expansion
             __syncthreads();  // staging arrays are rewritten by the next op batch
+            PSTAMP(4)
         }
         __syncthreads();  // pair arrays are rewritten by the next pair batch
     }
     __syncthreads();
     // flush: derive the global plane-major counters (negative counts, as the reference keeps them)
+    PSTAMP(4)
     const int64_t NC = a.n_cols;
     int64_t ncol = NC - tlo;
     if (ncol > TILE_COLS) ncol = TILE_COLS;
@@ -568,6 +605,13 @@ __global__ __launch_bounds__(PT_THREADS) void k_pileup_tiles(SumArgs a) {
         a.cnt[(int64_t)C_DEL * NC + g] = s_cnt[L_DEL][SW(lc)];
         a.cnt[(int64_t)C_RARE * NC + g] = s_cnt[L_RARE][SW(lc)];
     }
+#ifdef PV_PSTAMPS
+    PSTAMP(5)  // flush
+    if (tid == 0 && a.site_strbytes) {  // debug: reuse a workspace array that is written later in the pipeline
+        for (int i = 0; i < 6; i++) atomicAdd((unsigned long long*)&a.diag[D_NDIAG + i], ps_acc[i]);
+    }
+#endif
+#undef PSTAMP
 }
 
 // ---- K3 -------------------------------------------------------------------------------------------
@@ -1308,7 +1352,11 @@ __global__ __launch_bounds__(256) void k_polish_chunks(SumArgs a) {
 }
 
 __global__ void k_zero_diag(int64_t* diag) {
+#ifdef PV_PSTAMPS
+    if (threadIdx.x < D_NDIAG + 8) diag[threadIdx.x] = 0;
+#else
     if (threadIdx.x < D_NDIAG) diag[threadIdx.x] = 0;
+#endif
 }
 
 }  // namespace
@@ -1370,7 +1418,7 @@ static int summarize_launch(pv_ctx* ctx, const pv_batch_in* in, const pv_params*
     if ((rc = pv_get(ctx, "sum.site_stroff", max_sites, &a.site_stroff))) return rc;
     if ((rc = pv_get(ctx, "sum.ev", max_events, &a.ev))) return rc;
     if ((rc = pv_get(ctx, "sum.rec", max_events + 4 * max_sites, &a.rec))) return rc;
-    if ((rc = pv_get(ctx, "sum.diag", (size_t)D_NDIAG, &a.diag))) return rc;
+    if ((rc = pv_get(ctx, "sum.diag", (size_t)D_NDIAG + 8, &a.diag))) return rc;
 
     pv_prof_scope ps_all(ctx, "summary_pipeline", st);
     k_zero_diag<<<1, 64, 0, st>>>(a.diag);
@@ -1574,7 +1622,7 @@ static int polish_launch(pv_ctx* ctx, const pv_batch_in* in, int64_t n_reads, in
     if ((rc = pv_get(ctx, "pol.ins_cnt", (size_t)(max_ins_rows > 0 ? max_ins_rows : 1) * 10, &a.ins_cnt))) return rc;
     if ((rc = pv_get(ctx, "pol.reg_rows", (size_t)G + 1, &a.reg_rows))) return rc;
     if ((rc = pv_get(ctx, "pol.reg_chunks", (size_t)G + 1, &a.reg_chunks))) return rc;
-    if ((rc = pv_get(ctx, "sum.diag", (size_t)D_NDIAG, &a.diag))) return rc;
+    if ((rc = pv_get(ctx, "sum.diag", (size_t)D_NDIAG + 8, &a.diag))) return rc;
     if (out->flat_images) {
         PV_CHECK(out->flat_position && out->flat_index, PV_ERR_INVALID, "flat_position / flat_index missing");
         a.flat_img = out->flat_images; a.flat_pos = out->flat_position; a.flat_idx = out->flat_index;
@@ -1733,3 +1781,14 @@ extern "C" int pv_polish_summarize_regions(pv_ctx* ctx, const pv_batch_in* in, i
     PV_HIP(hipStreamSynchronize(st));
     return PV_OK;
 }
+
+#ifdef PV_PSTAMPS
+// diagnostic builds only: phase cycle sums of the last k_pileup_tiles launch (6 values)
+extern "C" int pv_debug_read_pstamps(pv_ctx* ctx, unsigned long long* out) {
+    int64_t* d = nullptr;
+    if (pv_get(ctx, "sum.diag", (size_t)D_NDIAG + 8, &d)) return PV_ERR_HIP;
+    PV_HIP(hipDeviceSynchronize());
+    PV_HIP(hipMemcpy(out, d + D_NDIAG, 6 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    return PV_OK;
+}
+#endif

@@ -1,6 +1,8 @@
 set -e
 cd /root/repo
 mkdir -p gpurun_out
-timeout -k 10 1000 python -m pytest tests -x -q -m gpu > gpurun_out/full_gpu_tests.log 2>&1
-PV_BENCH_OVERLAP=1 timeout -k 10 600 python bench.py --no-cpu-baseline --no-p2 --no-bf16 > gpurun_out/bench_ov1.json 2> gpurun_out/bench_ov1.err
-PV_BENCH_OVERLAP=0 timeout -k 10 600 python bench.py --no-cpu-baseline --no-p2 --no-bf16 > gpurun_out/bench_ov0.json 2> gpurun_out/bench_ov0.err
+{
+echo "== tests"; timeout -k 10 900 python -m pytest tests/test_summary_gpu.py tests/test_polish_gpu.py -x -q -m gpu 2>&1 | tail -3
+echo "== builder"; timeout -k 10 300 python tools/bench_builder.py 8
+echo "== stamps"; PEPPER_HIP_LIB=/root/repo/variants/libpepper_hip_pstamps.so timeout -k 10 300 python tools/pstamps.py
+} > gpurun_out/ab_pileup2.log 2>&1
