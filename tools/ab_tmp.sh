@@ -1,8 +1,7 @@
 set -e
 cd /root/repo
-mkdir -p gpurun_out
-{
-echo "== tests"; timeout -k 10 900 python -m pytest tests/test_summary_gpu.py tests/test_polish_gpu.py -x -q -m gpu 2>&1 | tail -3
-echo "== builder"; timeout -k 10 300 python tools/bench_builder.py 8
-echo "== stamps"; PEPPER_HIP_LIB=/root/repo/variants/libpepper_hip_pstamps.so timeout -k 10 300 python tools/pstamps.py
-} > gpurun_out/ab_pileup2.log 2>&1
+export TMPDIR=/tmp
+OUT=$GRAFT_REPO_ROOT/gpurun_out/prof_r01e
+mkdir -p $OUT
+rm -rf $OUT/trace
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 bench.py --steps 160 --warmup 16 --no-cpu-baseline --no-p2 --no-bf16 > $OUT/bench_trace.json 2> $OUT/bench_trace.err
