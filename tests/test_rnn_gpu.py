@@ -167,3 +167,15 @@ def test_p1_bf16_input_gemm_mode_meets_the_bar(gold, tag):
     np.testing.assert_allclose(dec[:48], ref_dec, atol=1e-4, rtol=0)
     np.testing.assert_allclose(probs[:48], ref_p, atol=TOL_PROBS, rtol=0)
     ctx.close()
+
+
+def test_repeatable_bits(hip_ctx):
+    """fixed summation orders everywhere (no float atomics): the same batch gives the same bits, P1 and P2"""
+    hip_ctx.load_p1(synth.make_weights_p1(7, 2.0))
+    x = synth.synth_windows(77, 300)
+    a, b = hip_ctx.forward_p1(x), hip_ctx.forward_p1(x)
+    assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+    hip_ctx.load_p2(synth.make_weights_p2(8, 2.0))
+    y = synth.synth_p2_images(78, 20)
+    (l1, a1), (l2, a2) = hip_ctx.forward_p2(y, want_acc=True), hip_ctx.forward_p2(y, want_acc=True)
+    assert np.array_equal(l1, l2) and np.array_equal(a1.view(np.uint32), a2.view(np.uint32))

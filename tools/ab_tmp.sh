@@ -1,7 +1,4 @@
 set -e
 cd /root/repo
-export TMPDIR=/tmp
-OUT=$GRAFT_REPO_ROOT/gpurun_out/prof_r01e
-mkdir -p $OUT
-rm -rf $OUT/trace
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 bench.py --steps 160 --warmup 16 --no-cpu-baseline --no-p2 --no-bf16 > $OUT/bench_trace.json 2> $OUT/bench_trace.err
+mkdir -p gpurun_out
+PV_BENCH_BACKEND=gloo timeout -k 10 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 2 --steps 32 --warmup 8 > gpurun_out/bench_n2.log 2> gpurun_out/bench_n2.err
