@@ -3,21 +3,22 @@
 // P1 (pepper_variant): images int8 [B,33,26] -> bi-LSTM(256) -> bi-LSTM(256) -> flatten 16896 ->
 //     5 x (Linear 512 + SELU) -> Linear 3 -> softmax        (reference: models/simple_model.py:48-82)
 //
-// Kernel family (one 256-thread workgroup = 4 waves, one wave per SIMD, owns a 32-row batch tile):
-//   k_lstm_layer<KP,INT8>  one launch per LSTM layer; a workgroup = (batch tile, direction). Per time
-//        step the gate pre-activations [32 x 1024] = [x_t | h_{t-1}] . [W_ih | W_hh]^T are ONE
-//        concatenated-K product on the f32 MFMA (v_mfma_f32_32x32x2_f32, bitwise an fmaf chain), so
-//        the "input-projection GEMM" and the recurrent product share accumulators and no
-//        pre-activation tensor ever goes to HBM. A operand (x_t, h_{t-1}) lives in LDS; the B operand
-//        (weights) is pre-packed on the host in exact MFMA fragment order and streamed from L2 with
-//        one coalesced 16-B load per lane per 4 MFMAs; wave w owns hidden units [64w,64w+64) for all
-//        four gates so the cell update is purely in-register (C/D layout puts i,f,g,o of one
-//        (row,unit) in the same lane and register index). c stays in registers for all 33 steps, h is
-//        exchanged between the 4 waves through a double-buffered LDS tile. XCD-aware block mapping
-//        keeps one direction's weights (<= 3 MB) per XCD L2.
+// Kernel family:
+//   k_lstm_layer<KP,INT8,TR>  one launch per LSTM layer; a workgroup (8 waves) = (TR-row batch tile, direction). Per
+//        time step the gate pre-activations [TR x 1024] = [x_t | h_{t-1}] . [W_ih | W_hh]^T are ONE concatenated-K
+//        product on the f32 MFMA (bitwise an fmaf chain), so the "input-projection GEMM" and the recurrent product
+//        share accumulators and no pre-activation tensor ever goes to HBM. A operand (x_t, h_{t-1}) lives in LDS; the
+//        B operand (weights) is pre-packed on the host in exact MFMA fragment order and streamed from L2 through a
+//        four-deep register ring fed by raw buffer loads three k-blocks ahead; wave w owns hidden units
+//        [32w, 32w+32) of all four gates so the cell update is purely in-register. c stays in registers for all 33
+//        steps, h is exchanged between the waves through a double-buffered LDS tile. XCD-aware block mapping keeps
+//        one direction's weights (<= 3 MB) per XCD L2. Two tile forms (mfma_tiles.hpp): TR = 32 on 32x32x2 MFMAs when
+//        the workgroups fill the chip, TR = 16 on 16x16x4 MFMAs below that.
 //   k_head_splitk          linear_1 (K = 16896) as a split-K MFMA product over time-step chunks,
 //        deterministic partial slabs (no float atomics).
-//   k_head_tail            sum of slabs + bias + SELU, linear_2..5 + SELU (MFMA), output layer, softmax.
+//   k_head_tail<TR>        sum of slabs + bias + SELU, linear_2..5 + SELU (MFMA), output layer, softmax.
+//   k_gemm_bf16x3, k_lstm_rec_g   PV_DTYPE_BF16_INPUT_GEMM: decoder input projection and linear_1 as 3-term bf16 split
+//        GEMMs on the bf16 MFMA, recurrence on the pre-computed projections in fp32.
 #include "pv_common.hpp"
 #include "mfma_tiles.hpp"
 

@@ -15,7 +15,8 @@
 //
 // Pipeline (all on one stream, no host round trip in the middle):
 //   k_cigar_scan     wave per read: prefix sums over CIGAR ops -> per-op (column, read index)
-//   k_pileup         wave per 64 ops: load-balanced expansion of aligned bases over lanes; counters
+//   k_tile_fill      lane per (read, 512-column tile): op range of the read that can touch the tile
+//   k_pileup_tiles   workgroup per tile: counters in LDS, aligned bases dealt to lanes in padded groups of 4
 //   k_site_scan      thread per column: frequency thresholds -> site flags, per-block site counts
 //   k_scan_*         single-block exclusive scans (tiny arrays)
 //   k_site_rank      column -> site rank, site list, per-site event bucket sizes
