@@ -179,3 +179,20 @@ def test_repeatable_bits(hip_ctx):
     y = synth.synth_p2_images(78, 20)
     (l1, a1), (l2, a2) = hip_ctx.forward_p2(y, want_acc=True), hip_ctx.forward_p2(y, want_acc=True)
     assert np.array_equal(l1, l2) and np.array_equal(a1.view(np.uint32), a2.view(np.uint32))
+
+
+@pytest.mark.parametrize("B", [4096, 8200])
+def test_p1_full_batches_properties(hip_ctx, B):
+    """BASELINE-size batches (the 32-row tile form, one and two rounds of workgroups): rows are independent, so any slice
+    equals the same windows run alone (a small batch runs in the 16-row tile form: same sums, other MFMA shape and order
+    inside a k-block, hence 1e-6 and not bitwise), and the leading rows match the float64 oracle."""
+    w = synth.make_weights_p1(5, 2.0)
+    hip_ctx.load_p1(w)
+    x = synth.synth_windows(2000 + B, B)
+    probs = hip_ctx.forward_p1(x)
+    assert np.isfinite(probs).all() and np.abs(probs.sum(1) - 1).max() < 1e-5
+    for lo in (0, B // 2 - 17, B - 40):
+        alone = hip_ctx.forward_p1(x[lo:lo + 40])
+        np.testing.assert_allclose(probs[lo:lo + 40], alone, atol=1e-6, rtol=0)
+    ref = rnn_oracle.p1_forward(w, x[:16], np.float64)
+    np.testing.assert_allclose(probs[:16], ref, atol=TOL_PROBS, rtol=0)
