@@ -255,7 +255,9 @@ __global__ __launch_bounds__(512, 2) void k_lstm_layer(LstmArgs a) {
         for (int nt = 0; nt < NT; nt++)
 #pragma unroll
             for (int e = 0; e < NE; e++) gate_set<TR>(acc[nt], e, bs[nt][TR == 32 ? 0 : e >> 2]);
-        mma_dual_ringb<TR, NT>(acc, xbuf, LDX, NKB_X, hbuf + cur * TR * LDH, LDH, NKB_H, wr, bq, lane);
+        // h_0 = 0 (simple_model.py:50-54 passes no initial state): the recurrent product of the first step is zero, skip it
+        static_assert(NKB_X % 4 == 0, "the x-only first step needs whole groups of four k-blocks");
+        mma_dual_ringb<TR, NT>(acc, xbuf, LDX, NKB_X, hbuf + cur * TR * LDH, LDH, s == 0 ? 0 : NKB_H, wr, bq, lane);
         // ---- cell update (PyTorch gate order i,f,g,o) ----------------------------------------------
         float* hn = hbuf + nxt * TR * LDH;
 #pragma unroll
@@ -622,7 +624,7 @@ __global__ __launch_bounds__(512, 2) void k_lstm_rec_g(RecArgs a) {
         for (int nt = 0; nt < NT; nt++)
 #pragma unroll
             for (int r = 0; r < 16; r++) acc[nt].v[r] = 0.0f;
-        mma_dual_ringb<32, NT>(acc, hbuf + cur * ROWS * LDH, LDH, NKB_H, hbuf, LDH, 0, wr, bq, lane);
+        mma_dual_ringb<32, NT>(acc, hbuf + cur * ROWS * LDH, LDH, s == 0 ? 0 : NKB_H, hbuf, LDH, 0, wr, bq, lane);  // h_0 = 0
         float* hn = hbuf + nxt * ROWS * LDH;
         const __amdgpu_buffer_rsrc_t cmr = make_rsrc(a.out_cm + ((size_t)(t * 16 + dir * 8 + wv) * a.cm_rows + (size_t)b0) * 32);
 #pragma unroll
