@@ -28,6 +28,14 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc_sized(const void* p,
 __device__ __forceinline__ f32x4 buf_load4(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
     return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
 }
+// streaming forms (aux bit 1 = nt): data touched once; the hint lets L2 evict it first, so that operands that ARE reused
+// (the packed weights, 3.1 MB per direction in a 4 MB L2) stay resident
+__device__ __forceinline__ f32x4 buf_load4_nt(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 2));
+}
+__device__ __forceinline__ void buf_store1_nt(float v, __amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, voff, soff, 2);
+}
 __device__ __forceinline__ float buf_load1(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
     return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
 }

@@ -142,6 +142,12 @@ __device__ __forceinline__ void ring_prime(f32x4 (&bq)[4][NT], __amdgpu_buffer_r
         for (int nt = 0; nt < NT; nt++) bq[q][nt] = buf_load4(wr, (unsigned)lane * 16u, (unsigned)(((kpos + q) * NT + nt) * 1024));
 }
 
+// x tiles and layer outputs are touched once: streaming (nt) forms, so that the packed weights (3.1 MB per direction in a
+// 4 MB L2) stay resident. rocprofv3 FETCH_SIZE of the decoder: 664 MB per launch without the hint (weights re-fetched on
+// every time step), 299 MB with it (= the 277 MB x tensor + weights); run time unchanged (the misses were Infinity Cache hits).
+#define PV_XLOAD buf_load4_nt
+#define PV_OSTORE buf_store1_nt
+
 struct LstmArgs {
     const int8_t* x_i8;   // [B,33,26]    (encoder)
     const float* x_f32;   // [Bp,33,512]  (decoder; padded to whole 32-row tiles)
@@ -227,7 +233,7 @@ __global__ __launch_bounds__(512, 2) void k_lstm_layer(LstmArgs a) {
             for (int u = 0; u < XI; u++) xi[u] = xe_valid ? (float)src[xoff[u]] : 0.0f;
         } else {
 #pragma unroll
-            for (int u = 0; u < XR; u++) xr[u] = buf_load4(xsr, xg_l, (unsigned)(((u * (NTHR / V4)) * T_STEPS + t) * KP * 4));
+            for (int u = 0; u < XR; u++) xr[u] = PV_XLOAD(xsr, xg_l, (unsigned)(((u * (NTHR / V4)) * T_STEPS + t) * KP * 4));
         }
     };
     auto x_store = [&]() {
@@ -271,7 +277,7 @@ __global__ __launch_bounds__(512, 2) void k_lstm_layer(LstmArgs a) {
             const float h = og * tanhf_(c);
             (hn + elem_row<TR>(e) * LDH + elem_unit<TR>(e))[h_l] = h;
             // outputs are padded to whole tiles: unconditional stores, tile resource + lane offset + scalar offset
-            buf_store1(h, osr, og_l, (unsigned)((t * 2 * H + dir * H + elem_row<TR>(e) * T_STEPS * 2 * H + elem_unit<TR>(e)) * 4));
+            PV_OSTORE(h, osr, og_l, (unsigned)((t * 2 * H + dir * H + elem_row<TR>(e) * T_STEPS * 2 * H + elem_unit<TR>(e)) * 4));
             if (a.out_cm) {
                 const int row = lane_row<TR>(lane) + elem_row<TR>(e);
                 const unsigned col = dir * H + unit0 + elem_unit<TR>(e);
@@ -334,7 +340,7 @@ __global__ __launch_bounds__(256, 1) void k_head_splitk(HeadArgs a) {
     f32x4 xr[XR];
     auto a_load = [&](int t) {
 #pragma unroll
-        for (int u = 0; u < XR; u++) xr[u] = buf_load4(asr, a_g, (unsigned)((2 * u * T_STEPS + t) * KC * 4));
+        for (int u = 0; u < XR; u++) xr[u] = buf_load4_nt(asr, a_g, (unsigned)((2 * u * T_STEPS + t) * KC * 4));
     };
     auto a_store = [&]() {
 #pragma unroll
