@@ -1,4 +1,4 @@
 set -e
 cd /root/repo
 mkdir -p gpurun_out
-bash tools/pmc_rnn.sh nt > gpurun_out/pmc_rnn.log 2>&1
+timeout -k 10 900 python bench.py > gpurun_out/bench_r01f.json 2> gpurun_out/bench_r01f.err
