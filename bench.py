@@ -312,6 +312,9 @@ def main():
 
     # ---- timed region ----------------------------------------------------------------------------------
     if dist is not None:
+        # untimed warm-up of the one exchange step as well: the first all_gather of a communicator sets up its channels
+        # and loads its kernels (RCCL does that lazily), which must not land inside the timed region
+        gather_predictions(probs.view(-1, 3), dst=0)
         dist.barrier()
     torch.cuda.synchronize()
     ctx.profile_begin()
