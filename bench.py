@@ -9,8 +9,10 @@ offline, so inputs are the synthetic shapes SURVEY.md 8(d) fixes (R = 100 200 co
 One STEP = one 100.2 kb region through the image builder + one 512-window batch through the RNN
 (every window the region yields is inferred; the batch is topped up to exactly 512 with resident
 synthetic windows). Like the reference's `callers_per_gpu` (RunInferenceArguments.py:67-74) the host
-loop keeps CALLERS = 8 steps in flight, here by fusing them into ONE launch chain per group
-(8 regions per builder call, 4096 windows per RNN call) so that a single stream fills all 256 CUs.
+loop keeps CALLERS = 16 steps in flight (reference default 4, "up to 10 on an 11 GB GPU"), here by fusing them
+into ONE launch chain per group (16 regions per builder call, 8192 windows per RNN call): a single stream then fills all
+256 CUs for two back-to-back rounds of workgroups per kernel. --steps K times exactly K steps (K // 16 full chains and
+one shorter chain for the remainder).
 
   python bench.py [--gpus N] [--steps K] [--warmup W]
 N > 1: launched by torch.distributed.run, one rank per GPU; regions shard across ranks (no data-path
@@ -29,7 +31,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 BATCH = 512
-CALLERS = int(os.environ.get("PV_BENCH_CALLERS", "8"))   # steps fused per launch chain (callers_per_gpu analogue)
+CALLERS = int(os.environ.get("PV_BENCH_CALLERS", "16"))  # steps fused per launch chain (callers_per_gpu analogue)
 REGION_LEN = 100_200             # 100 kb interval + 2 x 100 safe bases (AlignmentSummarizer.py:181-182)
 DEPTH = 60
 READ_LEN = 10_000
@@ -193,8 +195,8 @@ def single_call_secondary(ctx, dev):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=64)
-    ap.add_argument("--warmup", type=int, default=8)
+    ap.add_argument("--steps", type=int, default=128)
+    ap.add_argument("--warmup", type=int, default=16)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-p2", action="store_true", help="skip the secondary bi-GRU (P2) figures")
     ap.add_argument("--no-bf16", action="store_true", help="skip the secondary configs[2] (bf16 input GEMM) figure")
@@ -226,11 +228,9 @@ def main():
     from pepper_thesis_amd.dist import gather_predictions
 
     K, W = int(args.steps), int(args.warmup)
-    groups = (K + CALLERS - 1) // CALLERS
-    wgroups = (W + CALLERS - 1) // CALLERS
-    if K % CALLERS:
-        log("--steps %d is not a multiple of %d: timing %d steps" % (K, CALLERS, groups * CALLERS))
-    K = groups * CALLERS
+    full, rem = divmod(K, CALLERS)          # exactly K steps: `full` chains of CALLERS steps + one chain of `rem` steps
+    wfull, wrem = divmod(W, CALLERS)
+    groups = full + (1 if rem else 0)
 
     # ---- synthetic workload (seeded; rank r gets its own regions: regions shard across GPUs) ---------
     t0 = time.time()
@@ -276,14 +276,21 @@ def main():
     if not overlap:
         s_build = s_rnn
 
-    def group(g):
+    # chains shorter than CALLERS steps (K or W not a multiple of CALLERS): the first regions of batch 0
+    rem_batches = {n: DeviceBatch(batches[0].select(list(range(n))), dev) for n in {rem, wrem} if n}
+    rem_douts = {n: [DeviceOut(n * BATCH, n * BATCH * 16, dev, images=w) for w in wins] for n in rem_batches}
+
+    def group(g, ncall=CALLERS):
         k = state["n"] & 1
         if state["n"] >= 2:
             s_build.wait_event(ev_used[k])
-        ctx.summarize_dev(dbatches[g % NBATCH], P, douts[k], stream=s_build.cuda_stream)
+        if ncall == CALLERS:
+            ctx.summarize_dev(dbatches[g % NBATCH], P, douts[k], stream=s_build.cuda_stream)
+        else:
+            ctx.summarize_dev(rem_batches[ncall], P, rem_douts[ncall][k], stream=s_build.cuda_stream)
         ev_built[k].record(s_build)
         s_rnn.wait_event(ev_built[k])
-        ctx.forward_p1_dev(wins[k].data_ptr(), CALLERS * BATCH, probs[g % groups].data_ptr(), stream=s_rnn.cuda_stream)
+        ctx.forward_p1_dev(wins[k].data_ptr(), ncall * BATCH, probs[g % groups].data_ptr(), stream=s_rnn.cuda_stream)
         ev_used[k].record(s_rnn)
         state["n"] += 1
 
@@ -296,14 +303,18 @@ def main():
     for db in dbatches + [dbatch]:  # first calls size the workspace arena (every batch once: their read / op counts differ)
         ctx.summarize_dev(db, P, douts[0], stream=s_build.cuda_stream)
     s_build.synchronize()
+    ctx.forward_p1_dev(wins[0].data_ptr(), CALLERS * BATCH, probs[0].data_ptr(), stream=s_rnn.cuda_stream)  # RNN workspace at full size
+    s_rnn.synchronize()
     ctx.profile_begin()
     for _ in range(10):
         ctx.summarize_dev(dbatch, P, douts[0], stream=s_build.cuda_stream)
     prof_builder = ctx.profile_end()
     dout = douts[0]
     n_windows_region = dout.n_out()   # windows of batch 0 (the batch the isolated builder measurement used)
-    for g in range(wgroups):
+    for g in range(wfull):
         group(g)
+    if wrem:
+        group(wfull, wrem)
     drain()
     for d_ in douts:
         assert d_.status() == 0, "device status %d" % d_.status()
@@ -319,8 +330,10 @@ def main():
     torch.cuda.synchronize()
     ctx.profile_begin()
     t0 = time.perf_counter()
-    for g in range(groups):
+    for g in range(full):
         group(g)
+    if rem:
+        group(full, rem)
     gathered = None
     if dist is not None:
         drain()
@@ -341,14 +354,14 @@ def main():
         value = total_windows / dt
         dec_ms, dec_n = prof.get("k_lstm_layer_dec", (0.0, 0))
         dec_avg_s = dec_ms / max(dec_n, 1) / 1e3
-        achieved_tf = FLOP_DEC_PER_WINDOW * CALLERS * BATCH / dec_avg_s / 1e12 if dec_avg_s > 0 else 0.0
+        achieved_tf = FLOP_DEC_PER_WINDOW * K * BATCH / (dec_ms / 1e3) / 1e12 if dec_ms > 0 else 0.0  # all launches of the timed region
         sum_ms, sum_n = prof_builder.get("summary_pipeline", (0.0, 0))
         pile_ms, pile_n = prof_builder.get("k_pileup", (0.0, 0))
         traffic = pmc_traffic()
         alg_bytes = batch.algorithmic_bytes(n_windows_region)
         out = {
             "metric": "pileup windows/sec (whole node) + Mbp/sec inferred, HG003 chr20 ONT R9",
-            "value": value, "unit": "windows/s", "n_gpus": world, "steps": K, "warmup": wgroups * CALLERS,
+            "value": value, "unit": "windows/s", "n_gpus": world, "steps": K, "warmup": W,
             "ms_per_step": dt / K * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": "configs[1]: HG003-chr20-shaped ONT R9 synthetic, batch=512 windows/step, fp32 bi-LSTM P1, "
