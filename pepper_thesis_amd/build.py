@@ -62,5 +62,23 @@ def build(force=False, verbose=False):
     return LIB
 
 
+def build_variant(name, extra_flags):
+    """Diagnostic / A-B builds: variants/libpepper_hip_<name>.so with extra compile flags (e.g. ["-DPV_PSTAMPS"]); select it
+    at run time with PEPPER_HIP_LIB=<path>. variants/ is git-ignored but travels to the GPU box with gpurun."""
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    if not os.path.exists(hipcc):
+        hipcc = "hipcc"
+    vdir = os.path.normpath(os.path.join(HERE, "..", "variants"))
+    os.makedirs(vdir, exist_ok=True)
+    objs = []
+    for src in SOURCES:
+        o = os.path.join(vdir, "%s_%s" % (name, src.replace(".hip", ".o")))
+        subprocess.check_call([hipcc] + FLAGS + list(extra_flags) + ["-c", os.path.join(CSRC, src), "-o", o])
+        objs.append(o)
+    lib = os.path.join(vdir, "libpepper_hip_%s.so" % name)
+    subprocess.check_call([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib] + objs)
+    return lib
+
+
 if __name__ == "__main__":
     print(build(force="--force" in sys.argv, verbose=True))

@@ -1,5 +1,7 @@
 #!/usr/bin/env python3
-"""Diagnostic: phase cycle sums of k_pileup_tiles (needs a -DPV_PSTAMPS build: PEPPER_HIP_LIB=variants/libpepper_hip_pstamps.so)."""
+"""Diagnostic: phase cycle sums of k_pileup_tiles. Needs a -DPV_PSTAMPS build:
+    python -c "from pepper_thesis_amd import build; print(build.build_variant('pstamps', ['-DPV_PSTAMPS']))"
+    PEPPER_HIP_LIB=$PWD/variants/libpepper_hip_pstamps.so python tools/pstamps.py        (on the GPU box)"""
 import ctypes as C
 import os
 import sys
