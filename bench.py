@@ -11,7 +11,7 @@ One STEP = one 100.2 kb region through the image builder + one 512-window batch 
 synthetic windows). Like the reference's `callers_per_gpu` (RunInferenceArguments.py:67-74) the host
 loop keeps CALLERS = 16 steps in flight (reference default 4, "up to 10 on an 11 GB GPU"), here by fusing them
 into ONE launch chain per group (16 regions per builder call, 8192 windows per RNN call): a single stream then fills all
-256 CUs for two back-to-back rounds of workgroups per kernel. --steps K times exactly K steps (K // 16 full chains and
+256 CUs for two back-to-back rounds of workgroups per kernel. --steps K times exactly K steps (K // 16 full chains, a chain of 8 and
 one shorter chain for the remainder).
 
   python bench.py [--gpus N] [--steps K] [--warmup W]
@@ -228,9 +228,21 @@ def main():
     from pepper_thesis_amd.dist import gather_predictions
 
     K, W = int(args.steps), int(args.warmup)
-    full, rem = divmod(K, CALLERS)          # exactly K steps: `full` chains of CALLERS steps + one chain of `rem` steps
-    wfull, wrem = divmod(W, CALLERS)
-    groups = full + (1 if rem else 0)
+    def chains_for(n):
+        """exactly n steps as launch chains: as many chains of CALLERS steps as fit, then (if the rest allows) one chain of
+        CALLERS/2 steps (still a whole round of workgroups), then the remainder"""
+        out = [CALLERS] * (n // CALLERS)
+        r = n % CALLERS
+        half = CALLERS // 2
+        if half and r >= half:
+            out.append(half)
+            r -= half
+        if r:
+            out.append(r)
+        return out
+
+    chains, wchains = chains_for(K), chains_for(W)
+    groups = max(len(chains), 1)
 
     # ---- synthetic workload (seeded; rank r gets its own regions: regions shard across GPUs) ---------
     t0 = time.time()
@@ -277,7 +289,7 @@ def main():
         s_build = s_rnn
 
     # chains shorter than CALLERS steps (K or W not a multiple of CALLERS): the first regions of batch 0
-    rem_batches = {n: DeviceBatch(batches[0].select(list(range(n))), dev) for n in {rem, wrem} if n}
+    rem_batches = {n: DeviceBatch(batches[0].select(list(range(n))), dev) for n in set(chains + wchains) if n != CALLERS}
     rem_douts = {n: [DeviceOut(n * BATCH, n * BATCH * 16, dev, images=w) for w in wins] for n in rem_batches}
 
     def group(g, ncall=CALLERS):
@@ -311,10 +323,8 @@ def main():
     prof_builder = ctx.profile_end()
     dout = douts[0]
     n_windows_region = dout.n_out()   # windows of batch 0 (the batch the isolated builder measurement used)
-    for g in range(wfull):
-        group(g)
-    if wrem:
-        group(wfull, wrem)
+    for g, nc in enumerate(wchains):
+        group(g, nc)
     drain()
     for d_ in douts:
         assert d_.status() == 0, "device status %d" % d_.status()
@@ -330,10 +340,8 @@ def main():
     torch.cuda.synchronize()
     ctx.profile_begin()
     t0 = time.perf_counter()
-    for g in range(full):
-        group(g)
-    if rem:
-        group(full, rem)
+    for g, nc in enumerate(chains):
+        group(g, nc)
     gathered = None
     if dist is not None:
         drain()
