@@ -139,3 +139,33 @@ def chunk_images(summary: SummaryGenerator, chunk_size: int = SEQ_LENGTH, chunk_
     labels = [[0] * chunk_size for _ in images]
     positions = [list(zip(p.tolist(), i.tolist())) for p, i in zip(out.position, out.index)]
     return images, labels, positions, out.chunk_id.tolist()
+
+
+MAX_READS_IN_REGION = 1500  # AlingerOptions.MAX_READS_IN_REGION (pepper/modules/python/Options.py:28)
+
+
+def region_from_files(bam, fasta, contig: str, start: int, end: int) -> Optional[Region]:
+    """The inference branch of the polisher's AlignmentSummarizer.create_summary up to the builder call
+    (pepper/modules/python/AlignmentSummarizer.py:296-347): get_reads(contig, max(0, start), end, no supplementary, mapq 0,
+    baseq 0), reservoir sampling to 1500 reads with RandomState(2719747673), reference fetch [start, end]. The optional SSW
+    realignment (`realignment_flag`) is outside this path. None when the region has no reads (the reference returns empty lists)."""
+    from .make_images import downsample_indices
+    reads = bam.get_reads(contig, max(0, int(start)), int(end), False, 0, 0)
+    if not reads:
+        return None
+    keep = downsample_indices(len(reads), 1.0, MAX_READS_IN_REGION)
+    reads = [reads[i] for i in keep]
+    R = int(end) - int(start) + 1
+    ref = fasta.get_reference_sequence(contig, int(start), int(end) + 1).encode()
+    if len(ref) < R:
+        ref = ref + b"N" * (R - len(ref))  # past the contig end: columns without reads; the polisher never reads the bytes
+    return Region(int(start), int(end), ref, reads, contig=contig)
+
+
+def polish_regions(ctx, regions: Sequence[Region], want_acc: bool = False):
+    """builder -> bi-GRU for a batch of regions: (PolishOut, labels uint8 [n_chunks, 1000][, accumulated softmax]).
+    pv_rnn_load_p2 must have been called on ctx. positions/index of PolishOut name the reference position of every label,
+    which is what the polisher's prediction file stores per chunk (DataStorePredict.write_prediction)."""
+    out = polish_summarize(ctx, pack_regions(list(regions)), SEQ_LENGTH, SEQ_OVERLAP)
+    res = ctx.forward_p2(out.images, want_acc=want_acc)
+    return (out,) + (res if want_acc else (res,))

@@ -144,3 +144,30 @@ def test_device_resident_builder_into_gru(hip_ctx, oracle_lib):
     np.testing.assert_allclose(acc[:3].cpu().numpy(), ar, atol=1e-4, rtol=0)
     diff = labels[:3].cpu().numpy() != lr
     assert diff.mean() < 2e-3
+
+
+def test_bam_to_polish_labels(hip_ctx, oracle_lib, tmp_path):
+    """BAM + FASTA -> native readers -> polisher builder -> bi-GRU labels; equal to the oracle chain on the same clipped reads"""
+    import bam_writer as bw
+    from pepper_thesis_amd import bamio, build
+    build.build_io()
+    rng = np.random.default_rng(21)
+    ref = "".join(rng.choice(list("ACGT"), size=20_000))
+    bw.write_fasta(str(tmp_path / "ref.fa"), [("ctg1", ref)])
+    recs = bw.random_records(rng, 300, 20_000, tid=0, mean_len=1500)   # includes N / P ops: deletions for the polisher
+    for r in recs:
+        r["mapq"] = int(rng.integers(0, 61))
+    bw.write_bam(str(tmp_path / "reads.bam"), [("ctg1", len(ref))], recs)
+    b, f = bamio.BamHandler(str(tmp_path / "reads.bam")), bamio.FastaHandler(str(tmp_path / "ref.fa"))
+    ivs = [(1000, 4999), (5000, 8200), (19_000, 19_999)]
+    regs = [polish_summary.region_from_files(b, f, "ctg1", s, e) for s, e in ivs]
+    assert all(r is not None and len(r.reads) > 5 for r in regs)
+    w = synth.make_weights_p2(31, 3.0)
+    hip_ctx.load_p2(w)
+    out, labels, acc = polish_summary.polish_regions(hip_ctx, regs, want_acc=True)
+    exp = oracle_lib.polish_summarize(pack_regions(regs), want_flat=False)
+    assert np.array_equal(out.images, exp.images) and np.array_equal(out.position, exp.position)
+    assert out.region.tolist() == exp.region.tolist() and len(out.images) >= 8
+    lr, ar = rnn_oracle.p2_forward(w, exp.images[:2], np.float64)
+    np.testing.assert_allclose(acc[:2], ar, atol=1e-4, rtol=0)
+    assert (labels[:2] != lr).mean() < 2e-3
