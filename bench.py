@@ -4,24 +4,33 @@
 Metric (BASELINE.json): pileup windows/s (+ Mbp/s inferred) on the HG003-chr20-shaped ONT R9 workload,
 configs[1]: batch = 512 windows per step, fp32, one MI355X per rank. No real BAM / checkpoint exists
 offline, so inputs are the synthetic shapes SURVEY.md 8(d) fixes (R = 100 200 columns at 60x with
-10 kb reads; random-init weights of the pepper_variant architecture).
+10 kb reads, planted sites for ~500 windows per region; random-init weights of the pepper_variant
+architecture).
 
 One STEP = one 100.2 kb region through the image builder + one 512-window batch through the RNN
 (every window the region yields is inferred; the batch is topped up to exactly 512 with resident
-synthetic windows). Like the reference's `callers_per_gpu` (RunInferenceArguments.py:67-74) the host
-loop keeps CALLERS = 16 steps in flight (reference default 4, "up to 10 on an 11 GB GPU"), here by fusing them
-into ONE launch chain per group (16 regions per builder call, 8192 windows per RNN call): a single stream then fills all
-256 CUs for two back-to-back rounds of workgroups per kernel. --steps K times exactly K steps (K // 16 full chains, a chain of 8 and
-one shorter chain for the remainder).
+synthetic windows; `windows_from_builder_per_s` counts only what the builder produced). Like the
+reference's `callers_per_gpu` (RunInferenceArguments.py:67-74) the host loop keeps CALLERS = 16 steps in
+flight by fusing them into ONE launch chain (16 regions per builder call, 8192 windows per RNN call).
 
-  python bench.py [--gpus N] [--steps K] [--warmup W]
-N > 1: launched by torch.distributed.run, one rank per GPU; regions shard across ranks (no data-path
-collective); one RCCL gather of the per-window predictions to rank 0 ends the timed region.
-Prints ONE JSON line on rank 0.
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--min-seconds S]
+
+Timed region: the K-step pattern is repeated R times back to back (R*K steps as full chains of 16; R is
+the smallest count that makes the region last >= S seconds, default 1 s, and R*K a whole number of
+chains), bracketed by barrier + synchronize on both sides, MAX over ranks. `steps` = K, `repeats` = R,
+`ms_per_step` = time / (R*K), `value` = R*K*512*ranks / time. Every launch in the region has the same
+size, so `roofline.launch_ms` x launches, `flop_per_launch` and `achieved` belong together.
+
+N > 1: either launched by torch.distributed.run (RANK/LOCAL_RANK/WORLD_SIZE in the env), or — when those are
+absent — this program starts the N ranks itself BEFORE touching the GPU (the fan-out the reference does in
+RunInference.py:24-91) and relays rank 0's JSON line. One rank per GPU over RCCL (backend nccl); regions
+shard across ranks (no data-path collective); one gather of the per-window predictions to rank 0 ends the
+timed region. Prints ONE JSON line on rank 0.
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -35,11 +44,12 @@ CALLERS = int(os.environ.get("PV_BENCH_CALLERS", "16"))  # steps fused per launc
 REGION_LEN = 100_200             # 100 kb interval + 2 x 100 safe bases (AlignmentSummarizer.py:181-182)
 DEPTH = 60
 READ_LEN = 10_000
-SITE_EVERY = 260                 # planted sites: ~430-480 windows per region (< 512 by construction)
+SITE_EVERY = int(os.environ.get("PV_BENCH_SITE_EVERY", "198"))  # planted sites: ~495-505 windows per region (~500)
 FLOP_PER_WINDOW = 161_328_128
 FLOP_DEC_PER_WINDOW = 103_809_024
 FLOP_ENC_PER_WINDOW = 38_117_376
 PEAK_F32_TFLOPS = 157.3          # MI355X_MICROARCH.md: f32 MFMA == f32 vector peak
+PEAK_BF16_TFLOPS = 2500.0
 PEAK_HBM_GBS = 8000.0
 
 
@@ -48,39 +58,88 @@ def log(msg):
     sys.stderr.flush()
 
 
-def cpu_baseline(weights, region, threads):
-    """CPU baseline on a bounded sample of the same workload: one region through the image builder
-    (the REFERENCE's region_summary.cpp if oracle/_ref was built, else the C oracle) + 512-window
-    batches through the stock-torch twin of the reference's eager predict loop."""
+# ------------------------------------------------------------------------------------------------------
+# launcher: `python bench.py --gpus N` with no torchrun environment
+# ------------------------------------------------------------------------------------------------------
+def _free_port():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def launch(args, argv):
+    """Parent of a self-launched multi-rank run. Touches no GPU API (a process that has initialised the GPU must
+    not be replaced or forked into ranks): it only counts devices, starts `torch.distributed.run` as a child with
+    one rank per GPU, lets rank 0's JSON line through on stdout, and returns the child's exit code."""
+    n = int(args.gpus)
+    backend = os.environ.get("PV_BENCH_BACKEND", "nccl")
+    if not args.selftest_launcher and backend == "nccl":
+        import torch
+        n_dev = torch.cuda.device_count()  # does not initialise the GPU
+        if n > n_dev:
+            sys.stderr.write("[bench] ERROR: --gpus %d but only %d HIP device(s) are visible; ranks never share a GPU "
+                             "(one rank per GPU over RCCL). Nothing was run.\n" % (n, n_dev))
+            return 2
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + list(argv)
+    log("launching %d ranks: %s" % (n, " ".join(cmd)))
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.call(cmd, env=env)
+
+
+def selftest_launcher(args):
+    """CPU rehearsal of the N-rank control path (tests/test_bench_launcher.py): join the process group, shard,
+    gather to rank 0. No GPU, no measurement."""
     import torch
-    from oracle import oracle, rnn_torch_twin
-    from pepper_thesis_amd import synth
-    from pepper_thesis_amd.batch import PRESETS, pack_regions
-    P = PRESETS["ont_r9_guppy5_sup"]
-    b = pack_regions([region])
-    kind_builder = "reference" if oracle.have_reference() else "port"
-    fn = oracle.reference_summarize if oracle.have_reference() else oracle.summarize
-    if not oracle.have_reference():
-        oracle.build()
-    t0 = time.perf_counter()
-    out = fn(b, P)
-    t_builder = time.perf_counter() - t0
-    torch.set_num_threads(threads)
-    model = rnn_torch_twin.build_p1(weights)
-    x = synth.synth_windows(5, 2 * BATCH)
-    rnn_torch_twin.predict_p1(model, x[:64])  # warm
-    t0 = time.perf_counter()
-    rnn_torch_twin.predict_p1(model, x, BATCH)
-    t_rnn = (time.perf_counter() - t0) / 2.0
-    per_step = t_builder + t_rnn
+    import torch.distributed as dist
+    from pepper_thesis_amd.dist import gather_predictions, shard_regions
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    dist.init_process_group("gloo")
+    assert dist.get_world_size() == world == int(args.gpus), (dist.get_world_size(), world, args.gpus)
+    mine = shard_regions(11, rank, world)
+    local = torch.tensor([[float(i), float(rank), 1.0] for i in mine], dtype=torch.float32).reshape(-1, 3)
+    res = gather_predictions(local, dst=0, keys=torch.tensor(mine, dtype=torch.int64))
+    dist.barrier()
+    if rank == 0:
+        rows, keys, counts = res
+        ok = sorted(keys.tolist()) == list(range(11)) and all(int(r[0]) == int(k) and int(r[1]) == int(k) % world
+                                                                for r, k in zip(rows.tolist(), keys.tolist()))
+        print(json.dumps({"selftest": "launcher", "n_gpus": world, "ranks_joined": dist.get_world_size(),
+                          "counts": counts, "ok": bool(ok)}))
+        sys.stdout.flush()
+    else:
+        assert res is None
+    dist.destroy_process_group()
+    return 0
+
+
+# ------------------------------------------------------------------------------------------------------
+# secondary figures
+# ------------------------------------------------------------------------------------------------------
+def cpu_baseline(region_batch, procs):
+    """CPU baseline on a bounded sample of the same workload (oracle/cpu_baseline.py): one process per core, one
+    torch thread each, as the reference's CPU fan-out does (RunInference.py:101-116); each process runs one
+    full-size region through the image builder and 512 windows through the eager predict loop."""
+    from oracle import cpu_baseline as cb
+    kind_builder, res = cb.measure(region_batch, procs)
+    one, many = res[1], res[max(res)]
     return {
-        "value": BATCH / per_step, "unit": "windows/s", "cores": threads,
-        "kind": "port",
-        "sample": "1 region (%d windows) through the %s image builder on 1 core: %.3f s; 2 x 512 windows through the "
-                  "stock torch.nn twin of the reference's eager predict loop on %d threads: %.3f s per 512"
-                  % (len(out), "reference C++ (oracle/_ref)" if kind_builder == "reference" else "C oracle",
-                     t_builder, threads, t_rnn),
-        "mbp_per_s": REGION_LEN / 1e6 / per_step,
+        "value": many["windows_per_s"], "unit": "windows/s", "cores": many["procs"],
+        "kind": "reference" if kind_builder == "reference-c++" else "port",
+        "kind_detail": "image builder: %s; RNN: torch-twin (stock torch.nn modules = the reference's eager PyTorch predict "
+                       "loop; its default onnxruntime path is not installed)" % kind_builder,
+        "sample": "per process: 1 region (R=%d, %dx, %d windows) through the image builder + 512 windows through the eager "
+                  "predict loop, 1 torch thread per process; %d processes side by side (slowest process bounds each leg)"
+                  % (REGION_LEN, DEPTH, one["windows_per_region"], many["procs"]),
+        "value_1core": one["windows_per_s"],
+        "builder_regions_per_s": {"1": one["builder_regions_per_s"], str(many["procs"]): many["builder_regions_per_s"]},
+        "rnn_windows_per_s": {"1": one["rnn_windows_per_s"], str(many["procs"]): many["rnn_windows_per_s"]},
+        "mbp_per_s": many["windows_per_s"] / 512 * REGION_LEN / 1e6,
     }
 
 
@@ -94,7 +153,8 @@ def pmc_traffic():
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_per_launch.csv")))
     if not files:
         return {}
-    out = {"note": "HBM bytes/launch from %s (FETCH_SIZE x2 + WRITE_SIZE)" % os.path.basename(files[-1])}
+    out = {"note": "HBM bytes/launch from %s (FETCH_SIZE x2 + WRITE_SIZE; the x2 of the guide's wide-load correction over-counts "
+                   "where raw FETCH_SIZE already equals the input bytes)" % os.path.basename(files[-1])}
     builder = 0.0
     for row in csv.DictReader(open(files[-1])):
         k = row["kernel"]
@@ -108,7 +168,7 @@ def pmc_traffic():
 
 
 def bf16_secondary(device_id, weights, dbatch, P, dev, pad, groups=6):
-    """BASELINE configs[2] flavour: the same step (1 region + 512 windows, 8 fused per launch chain) with
+    """BASELINE configs[2] flavour: the same step (1 region + 512 windows, 16 fused per launch chain) with
     PV_DTYPE_BF16_INPUT_GEMM: decoder input projection and linear_1 on the bf16 MFMA as a 3-term hi/lo split
     (softmax still within 1e-4 of the reference), recurrence fp32. Not part of `value`."""
     import torch
@@ -134,25 +194,44 @@ def bf16_secondary(device_id, weights, dbatch, P, dev, pad, groups=6):
     dt = time.perf_counter() - t0
     prof = c2.profile_end()
     c2.close()
-    gemm_ms = prof["k_gemm_bf16x3_dec"][0] / prof["k_gemm_bf16x3_dec"][1]
-    flop = 3 * 2.0 * (CALLERS * BATCH * 33) * 2048 * 512
-    return {"value": groups * CALLERS * BATCH / dt, "unit": "windows/s", "dtype": "bf16x3 input GEMMs + f32 recurrence",
-            "steps": groups * CALLERS, "ms_per_step": dt / (groups * CALLERS) * 1e3,
-            "input_gemm": {"kernel": "k_gemm_bf16x3 (decoder input projection, M=%d N=2048 K=512, 3 MFMA terms)" % (CALLERS * BATCH * 33),
-                           "launch_ms": gemm_ms, "achieved": flop / gemm_ms / 1e9, "peak": 2500.0, "unit": "TFLOP/s (bf16 MFMA)",
-                           "frac": flop / gemm_ms / 1e9 / 2500.0},
-            "kernel_ms": {k: v[0] / max(v[1], 1) for k, v in prof.items() if k.startswith("k_") and "summary" not in k}}
+    gname = next((k for k in prof if k.startswith("k_gemm_bf16x3_dec")), None)
+    out = {"value": groups * CALLERS * BATCH / dt, "unit": "windows/s", "dtype": "bf16x3 input GEMMs + f32 recurrence",
+           "steps": groups * CALLERS, "ms_per_step": dt / (groups * CALLERS) * 1e3,
+           "kernel_ms": {k: v[0] / max(v[1], 1) for k, v in prof.items() if k.startswith("k_") and "summary" not in k}}
+    if gname:
+        gemm_ms = prof[gname][0] / prof[gname][1]
+        flop = 3 * 2.0 * (CALLERS * BATCH * 33) * 2048 * 512
+        out["input_gemm"] = {"kernel": "%s (decoder input projection, M=%d N=2048 K=512, 3 bf16 MFMA terms)" % (gname, CALLERS * BATCH * 33),
+                             "launch_ms": gemm_ms, "achieved": flop / gemm_ms / 1e9, "peak": PEAK_BF16_TFLOPS,
+                             "unit": "TFLOP/s (bf16 MFMA)", "frac": flop / gemm_ms / 1e9 / PEAK_BF16_TFLOPS}
+    return out
 
 
 def p2_secondary(ctx, dev):
-    """secondary figures for the bi-GRU polisher plan (north_star's '1000 x 100 x feature' shape): the 19-window
-    sliding loop over [B,1000,10] chunks at the SURVEY 8(d) batch (64 chunks), at 1000 chunks and at a
-    chip-filling batch. Not part of `value`."""
+    """secondary figures for the bi-GRU polisher plan: north_star's literal '1000 windows x 100 columns x 10 features'
+    shape as ONE single-window model call (pv_rnn_forward_p2_window, host buffers in and out), and the 19-window
+    sliding loop over [B,1000,10] chunks at the SURVEY 8(d) batch (64 chunks), at 1000 chunks and at a chip-filling
+    batch. Not part of `value`."""
     import torch
     from pepper_thesis_amd import _ffi, synth
     ctx.load_p2(synth.make_weights_p2(4321))
     lib = _ffi.load()
     out = {"flop_per_100col_window": 80_435_200, "windows_per_chunk": 19}
+    # north_star literal: B = 1000 windows of [100, 10] through one TransducerGRU.forward call (host in/out)
+    xw = synth.synth_p2_images(11, 1000, seq_len=100)
+    ctx.forward_p2_window(xw)
+    t0 = time.perf_counter()
+    reps = 5
+    ctx.profile_begin()
+    for _ in range(reps):
+        ctx.forward_p2_window(xw)
+    prof = ctx.profile_end()
+    dt = (time.perf_counter() - t0) / reps
+    kms = sum(v[0] for k, v in prof.items()) / reps
+    out["single_window_B1000"] = {"call": "pv_rnn_forward_p2_window (host buffers, PCIe-inclusive)", "ms_per_call": dt * 1e3,
+                                  "windows_100col_per_s": 1000 / dt, "kernel_ms": kms,
+                                  "kernel_tflops": 80_435_200 * 1000 / kms / 1e9 if kms > 0 else None,
+                                  "frac_of_f32_peak": 80_435_200 * 1000 / kms / 1e9 / PEAK_F32_TFLOPS if kms > 0 else None}
     for B in (64, 1000, 8192):
         x = torch.from_numpy(synth.synth_p2_images(7, B)).to(dev)
         labels = torch.zeros((B, 1000), dtype=torch.uint8, device=dev)
@@ -161,8 +240,8 @@ def p2_secondary(ctx, dev):
         ctx.profile_begin()
         for _ in range(2):
             _ffi.check(lib.pv_rnn_forward_p2_dev(ctx.handle, x.data_ptr(), B, labels.data_ptr(), None, None))
-        ms, n = ctx.profile_end()["k_gru_p2"]
-        ms /= n
+        prof = ctx.profile_end()
+        ms = sum(v[0] for v in prof.values()) / 2
         out["B%d" % B] = {"ms": ms, "chunks_per_s": B / ms * 1e3, "windows_100col_per_s": 19 * B / ms * 1e3,
                           "tflops": 80_435_200 * 19 * B / ms / 1e9, "frac_of_f32_peak": 80_435_200 * 19 * B / ms / 1e9 / PEAK_F32_TFLOPS}
         del x, labels
@@ -181,53 +260,92 @@ def single_call_secondary(ctx, dev):
         for _ in range(2):
             ctx.forward_p1_dev(x.data_ptr(), B, probs.data_ptr())
         ctx.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(20):
+            ctx.forward_p1_dev(x.data_ptr(), B, probs.data_ptr())
+        ctx.synchronize()
+        wall_ms = (time.perf_counter() - t0) / 20 * 1e3
         ctx.profile_begin()
         for _ in range(5):
             ctx.forward_p1_dev(x.data_ptr(), B, probs.data_ptr())
         prof = ctx.profile_end()
         ms = sum(v[0] / v[1] for v in prof.values())
-        out["B%d" % B] = {"ms": ms, "windows_per_s": B / ms * 1e3, "tflops": FLOP_PER_WINDOW * B / ms / 1e9,
-                          "frac_of_f32_peak": FLOP_PER_WINDOW * B / ms / 1e9 / PEAK_F32_TFLOPS}
+        out["B%d" % B] = {"kernel_ms": ms, "wall_ms_per_call_back_to_back": wall_ms, "windows_per_s": B / wall_ms * 1e3,
+                          "tflops": FLOP_PER_WINDOW * B / wall_ms / 1e9,
+                          "frac_of_f32_peak": FLOP_PER_WINDOW * B / wall_ms / 1e9 / PEAK_F32_TFLOPS}
         del x, probs
     return out
 
 
-def main():
+# ------------------------------------------------------------------------------------------------------
+def main(argv=None):
+    argv = list(sys.argv[1:] if argv is None else argv)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=128)
     ap.add_argument("--warmup", type=int, default=16)
+    ap.add_argument("--min-seconds", type=float, default=float(os.environ.get("PV_BENCH_MIN_SECONDS", "1.0")),
+                    help="repeat the K-step pattern until the timed region lasts at least this long")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-p2", action="store_true", help="skip the secondary bi-GRU (P2) figures")
+    ap.add_argument("--no-p2", action="store_true", help="skip the secondary bi-GRU (P2) and single-call figures")
     ap.add_argument("--no-bf16", action="store_true", help="skip the secondary configs[2] (bf16 input GEMM) figure")
-    args = ap.parse_args()
+    ap.add_argument("--no-h2d", action="store_true", help="skip the secondary PCIe-inclusive (overlapped H2D) figure")
+    ap.add_argument("--no-filepath", action="store_true", help="skip the secondary BAM -> images -> predictions file-path figure")
+    ap.add_argument("--selftest-launcher", action="store_true",
+                    help="CPU rehearsal of the N-rank launcher / gather path over gloo (no GPU, no measurement)")
+    args = ap.parse_args(argv)
+
+    in_torchrun = "WORLD_SIZE" in os.environ and "RANK" in os.environ
+    if args.gpus > 1 and not in_torchrun:
+        return launch(args, argv)          # parent: starts the ranks, never touches the GPU
+    if args.selftest_launcher:
+        if not in_torchrun:
+            sys.stderr.write("[bench] --selftest-launcher needs --gpus N > 1\n")
+            return 2
+        return selftest_launcher(args)
 
     import torch
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    backend = os.environ.get("PV_BENCH_BACKEND", "nccl")  # nccl == RCCL on ROCm; gloo only for single-GPU rehearsals
     n_dev = torch.cuda.device_count()
-    dev_id = local_rank % max(n_dev, 1)  # one rank per GPU; (rehearsals with more ranks than GPUs share devices)
+    if world != int(args.gpus):
+        sys.stderr.write("[bench] ERROR: --gpus %d but WORLD_SIZE=%d: start exactly one rank per GPU\n" % (args.gpus, world))
+        return 2
+    if n_dev < 1:
+        sys.stderr.write("[bench] ERROR: no HIP device visible (there is no CPU path)\n")
+        return 2
+    if world > 1 and backend == "nccl" and (world > n_dev or local_rank >= n_dev):
+        sys.stderr.write("[bench] ERROR: %d ranks but %d HIP device(s): ranks never share a GPU over RCCL\n" % (world, n_dev))
+        return 2
+    dev_id = local_rank % n_dev   # == local_rank except in gloo rehearsals on one GPU (PV_BENCH_BACKEND=gloo)
+    torch.cuda.set_device(dev_id)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(dev_id)
-        backend = os.environ.get("PV_BENCH_BACKEND", "nccl")  # nccl == RCCL on ROCm; gloo only for single-GPU rehearsals
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", dev_id))
         else:
             dist.init_process_group(backend)
+        assert dist.get_world_size() == world
+        # one rank per GPU, checked: every rank reports the device it will create its pv_ctx on
+        ids = [None] * world
+        dist.all_gather_object(ids, (os.uname().nodename, dev_id))
+        if backend == "nccl" and len(set(ids)) != world:
+            sys.stderr.write("[bench] ERROR: ranks share a device: %r\n" % (ids,))
+            return 2
     else:
         dist = None
-        torch.cuda.set_device(dev_id)
     dev = "cuda:%d" % dev_id
 
     from pepper_thesis_amd import runtime, synth
     from pepper_thesis_amd.batch import PRESETS, pack_regions
-    from pepper_thesis_amd.device import DeviceBatch, DeviceOut
+    from pepper_thesis_amd.device import DeviceBatch, DeviceOut, PinnedBatch
     from pepper_thesis_amd.dist import gather_predictions
 
-    K, W = int(args.steps), int(args.warmup)
+    K, W = max(1, int(args.steps)), max(0, int(args.warmup))
+
     def chains_for(n):
         """exactly n steps as launch chains: as many chains of CALLERS steps as fit, then (if the rest allows) one chain of
         CALLERS/2 steps (still a whole round of workgroups), then the remainder"""
@@ -241,111 +359,144 @@ def main():
             out.append(r)
         return out
 
-    chains, wchains = chains_for(K), chains_for(W)
-    groups = max(len(chains), 1)
+    wchains = chains_for(W)
 
     # ---- synthetic workload (seeded; rank r gets its own regions: regions shard across GPUs) ---------
     t0 = time.time()
-    # NBATCH distinct batches of CALLERS regions, used round-robin by the launch chains, so that the image builder never
-    # finds its inputs (116 MB per batch) in the 256 MB Infinity Cache from the previous chain
+    # CALLERS distinct regions per rank; NBATCH batches = rotations of them at distinct HBM addresses, used round-robin by
+    # the launch chains so that the image builder never finds its inputs (116 MB per batch) in the 256 MB Infinity Cache
+    # from the previous chain (caches are address-based: a rotated copy is as cold as different data)
     NBATCH = max(1, int(os.environ.get("PV_BENCH_NBATCH", "4")))
-    batches = []
-    for j in range(NBATCH):
-        regs_j = [synth.synth_region(1234 + 97 * ((rank * NBATCH + j) * CALLERS + i), region_len=REGION_LEN, depth=DEPTH,
-                                     read_len=READ_LEN, site_every=SITE_EVERY,
-                                     ref_start=1_000_000 + ((rank * NBATCH + j) * CALLERS + i) * (REGION_LEN - 200))
-                  for i in range(CALLERS)]
-        if j == 0:
-            regions = regs_j
-        batches.append(pack_regions(regs_j))
+    regions = [synth.synth_region(1234 + 97 * (rank * CALLERS + i), region_len=REGION_LEN, depth=DEPTH,
+                                  read_len=READ_LEN, site_every=SITE_EVERY,
+                                  ref_start=1_000_000 + (rank * CALLERS + i) * (REGION_LEN - 200))
+               for i in range(CALLERS)]
+    rot = max(1, CALLERS // NBATCH)
+    batches = [pack_regions(regions[j * rot:] + regions[:j * rot]) for j in range(NBATCH)]
     batch = batches[0]
     weights = synth.make_weights_p1(1234)
     pad = synth.synth_windows(4242 + rank, CALLERS * BATCH)
     log("rank %d: generated %d regions (%d reads, %.1f M bases) in %.1f s" %
-        (rank, NBATCH * CALLERS, sum(b.n_reads for b in batches), sum(b.n_bases for b in batches) / 1e6, time.time() - t0))
+        (rank, CALLERS, batch.n_reads, batch.n_bases / 1e6, time.time() - t0))
     P = PRESETS["ont_r9_guppy5_sup"]
 
     ctx = runtime.Context(dev_id)
     ctx.load_p1(weights)
     dbatches = [DeviceBatch(b, dev) for b in batches]
     dbatch = dbatches[0]
-    # Two window buffers: the image builder of group g+1 (stream s_build) overlaps the RNN of group g
-    # (stream s_rnn); events order builder(g) -> rnn(g) and rnn(g) -> builder(g+2) (buffer reuse).
-    wins = [torch.from_numpy(pad).to(dev) for _ in range(2)]          # [4096,33,26] int8, builder writes the front
+    # Two window buffers, so that with PV_BENCH_OVERLAP=1 the image builder of group g+1 (stream s_build) may run beside the
+    # RNN of group g (stream s_rnn); events order builder(g) -> rnn(g) and rnn(g) -> builder(g+2) (buffer reuse).
+    wins = [torch.from_numpy(pad).to(dev) for _ in range(2)]          # [8192,33,26] int8, builder writes the front
     douts = [DeviceOut(CALLERS * BATCH, CALLERS * BATCH * 16, dev, images=w) for w in wins]
-    probs = torch.zeros((groups, CALLERS * BATCH, 3), dtype=torch.float32, device=dev)
     s_build, s_rnn = torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)
+    s_copy = torch.cuda.Stream(device=dev)
     ev_built = [torch.cuda.Event() for _ in range(2)]
     ev_used = [torch.cuda.Event() for _ in range(2)]
     torch.cuda.synchronize()
     state = {"n": 0}
 
     # Default: ONE stream, builder and RNN of a group back to back. The LSTM workgroups take whole CUs (2 x 255 VGPRs per
-    # SIMD, 132 KB LDS), so a second stream (PV_BENCH_OVERLAP=1: builder of group g+1 beside the RNN of group g) only lets
-    # builder kernels slip into the RNN's kernel boundaries: +1 % throughput, but every kernel's duration is then stretched by
-    # its neighbours and the live per-kernel times no longer agree with the rocprofv3 averages.
+    # SIMD, 132 KB LDS), so a second stream (PV_BENCH_OVERLAP=1) only lets builder kernels slip into the RNN's kernel
+    # boundaries: +1 % throughput, but every kernel's duration is then stretched by its neighbours and the live per-kernel
+    # times no longer agree with the rocprofv3 averages.
     overlap = os.environ.get("PV_BENCH_OVERLAP", "0") != "0"
     if not overlap:
         s_build = s_rnn
 
-    # chains shorter than CALLERS steps (K or W not a multiple of CALLERS): the first regions of batch 0
-    rem_batches = {n: DeviceBatch(batches[0].select(list(range(n))), dev) for n in set(chains + wchains) if n != CALLERS}
+    # chains shorter than CALLERS steps (only the warm-up can have them): the first regions of batch 0
+    rem_batches = {n: DeviceBatch(batches[0].select(list(range(n))), dev) for n in set(wchains) if n != CALLERS}
     rem_douts = {n: [DeviceOut(n * BATCH, n * BATCH * 16, dev, images=w) for w in wins] for n in rem_batches}
+    probs_holder = {"t": torch.zeros((1, CALLERS * BATCH, 3), dtype=torch.float32, device=dev)}
 
-    def group(g, ncall=CALLERS):
+    def group(g, ncall=CALLERS, h2d=None):
         k = state["n"] & 1
+        probs = probs_holder["t"]
         if state["n"] >= 2:
             s_build.wait_event(ev_used[k])
-        if ncall == CALLERS:
+        if h2d is not None:
+            # PCIe-inclusive form: this chain's regions arrive from page-locked host memory on the copy stream (the previous
+            # chain's kernels are still running meanwhile); the builder waits for them
+            dsets, pinned, ev_copied, ev_consumed = h2d
+            s_copy.wait_event(ev_consumed[k])
+            dsets[k].upload_async(pinned[g % len(pinned)], s_copy)
+            ev_copied[k].record(s_copy)
+            s_build.wait_event(ev_copied[k])
+            ctx.summarize_dev(dsets[k], P, douts[k], stream=s_build.cuda_stream)
+            ev_consumed[k].record(s_build)
+        elif ncall == CALLERS:
             ctx.summarize_dev(dbatches[g % NBATCH], P, douts[k], stream=s_build.cuda_stream)
         else:
             ctx.summarize_dev(rem_batches[ncall], P, rem_douts[ncall][k], stream=s_build.cuda_stream)
         ev_built[k].record(s_build)
         s_rnn.wait_event(ev_built[k])
-        ctx.forward_p1_dev(wins[k].data_ptr(), ncall * BATCH, probs[g % groups].data_ptr(), stream=s_rnn.cuda_stream)
+        ctx.forward_p1_dev(wins[k].data_ptr(), ncall * BATCH, probs[g % probs.shape[0]].data_ptr(), stream=s_rnn.cuda_stream)
         ev_used[k].record(s_rnn)
         state["n"] += 1
 
     def drain():
+        s_copy.synchronize()
         s_build.synchronize()
         s_rnn.synchronize()
 
-    # image-builder roofline: measured in isolation (its launches overlap the RNN in the timed region,
-    # which stretches their event-bracketed durations)
-    for db in dbatches + [dbatch]:  # first calls size the workspace arena (every batch once: their read / op counts differ)
+    # ---- warm-up: workspace sizing, the isolated image-builder measurement, W steps, calibration ------------------------
+    n_out_batch = []
+    for db in dbatches:  # first calls size the workspace arena (every batch once)
         ctx.summarize_dev(db, P, douts[0], stream=s_build.cuda_stream)
-    s_build.synchronize()
-    ctx.forward_p1_dev(wins[0].data_ptr(), CALLERS * BATCH, probs[0].data_ptr(), stream=s_rnn.cuda_stream)  # RNN workspace at full size
+        s_build.synchronize()
+        assert douts[0].status() == 0, "device status %d" % douts[0].status()
+        n_out_batch.append(douts[0].n_out())
+        assert n_out_batch[-1] <= CALLERS * BATCH, "regions yield %d windows > %d: raise PV_BENCH_SITE_EVERY" % (n_out_batch[-1], CALLERS * BATCH)
+    ctx.forward_p1_dev(wins[0].data_ptr(), CALLERS * BATCH, probs_holder["t"][0].data_ptr(), stream=s_rnn.cuda_stream)  # RNN workspace at full size
     s_rnn.synchronize()
+    # image-builder roofline: measured in isolation (16 regions per launch chain), cold inputs (round-robin batches)
     ctx.profile_begin()
-    for _ in range(10):
-        ctx.summarize_dev(dbatch, P, douts[0], stream=s_build.cuda_stream)
+    for i in range(12):
+        ctx.summarize_dev(dbatches[i % NBATCH], P, douts[0], stream=s_build.cuda_stream)
     prof_builder = ctx.profile_end()
-    dout = douts[0]
-    n_windows_region = dout.n_out()   # windows of batch 0 (the batch the isolated builder measurement used)
+    n_windows_region = n_out_batch[0]
     for g, nc in enumerate(wchains):
         group(g, nc)
     drain()
-    for d_ in douts:
-        assert d_.status() == 0, "device status %d" % d_.status()
-        assert d_.n_out() <= CALLERS * BATCH, "regions yield %d windows > %d" % (d_.n_out(), CALLERS * BATCH)
-    assert n_windows_region <= CALLERS * BATCH, "regions yield %d windows > %d" % (n_windows_region, CALLERS * BATCH)
+    # calibration (untimed): two full chains -> how many repeats of the K-step pattern make >= min_seconds
+    t0 = time.perf_counter()
+    for g in range(2):
+        group(g)
+    drain()
+    est_step = (time.perf_counter() - t0) / (2 * CALLERS)
+    if dist is not None:
+        t_est = torch.tensor([est_step], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+        dist.all_reduce(t_est, op=dist.ReduceOp.MAX)   # every rank must choose the same repeat count
+        est_step = float(t_est.item())
+    import math
+    unit = CALLERS // math.gcd(K, CALLERS)             # repeats come in multiples of this: R*K is a whole number of chains
+    R = max(1, math.ceil(args.min_seconds / max(est_step * K, 1e-9)))
+    R = ((R + unit - 1) // unit) * unit
+    total_steps = R * K
+    n_chains = total_steps // CALLERS
+    assert n_chains * CALLERS == total_steps
+    probs_holder["t"] = torch.zeros((n_chains, CALLERS * BATCH, 3), dtype=torch.float32, device=dev)
+    chain_ev = [torch.cuda.Event(enable_timing=True) for _ in range(n_chains + 1)]
+    for g in range(2):   # touch the new probs buffer, settle the clocks
+        group(g)
+    drain()
 
     # ---- timed region ----------------------------------------------------------------------------------
     if dist is not None:
-        # untimed warm-up of the one exchange step as well: the first all_gather of a communicator sets up its channels
+        # untimed warm-up of the one exchange step as well: the first collective of a communicator sets up its channels
         # and loads its kernels (RCCL does that lazily), which must not land inside the timed region
-        gather_predictions(probs.view(-1, 3), dst=0)
+        gather_predictions(probs_holder["t"].view(-1, 3), dst=0)
         dist.barrier()
     torch.cuda.synchronize()
     ctx.profile_begin()
     t0 = time.perf_counter()
-    for g, nc in enumerate(chains):
-        group(g, nc)
+    chain_ev[0].record(s_rnn)
+    for g in range(n_chains):
+        group(g)
+        chain_ev[g + 1].record(s_rnn)
     gathered = None
     if dist is not None:
         drain()
-        gathered = gather_predictions(probs.view(-1, 3), dst=0)
+        gathered = gather_predictions(probs_holder["t"].view(-1, 3), dst=0)
     drain()
     torch.cuda.synchronize()
     if dist is not None:
@@ -353,16 +504,23 @@ def main():
     dt = time.perf_counter() - t0
     prof = ctx.profile_end()
     if dist is not None:
-        tmax = torch.tensor([dt], dtype=torch.float64, device=dev if dist.get_backend() == "nccl" else "cpu")
+        tmax = torch.tensor([dt], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
+        if rank == 0:
+            assert gathered is not None and gathered[0].shape[0] == world * total_steps * BATCH, "gather lost rows"
+    chain_ms = sorted(chain_ev[g].elapsed_time(chain_ev[g + 1]) for g in range(n_chains))
+    median_chain_ms = chain_ms[len(chain_ms) // 2]
 
+    rc = 0
     if rank == 0:
-        total_windows = K * BATCH * world
+        total_windows = total_steps * BATCH * world
         value = total_windows / dt
+        builder_windows = sum(n_out_batch[g % NBATCH] for g in range(n_chains)) * world   # what the builder really produced
         dec_ms, dec_n = prof.get("k_lstm_layer_dec", (0.0, 0))
-        dec_avg_s = dec_ms / max(dec_n, 1) / 1e3
-        achieved_tf = FLOP_DEC_PER_WINDOW * K * BATCH / (dec_ms / 1e3) / 1e12 if dec_ms > 0 else 0.0  # all launches of the timed region
+        dec_launch_ms = dec_ms / max(dec_n, 1)
+        flop_per_launch = FLOP_DEC_PER_WINDOW * CALLERS * BATCH
+        achieved_tf = flop_per_launch / (dec_launch_ms / 1e3) / 1e12 if dec_ms > 0 else 0.0
         sum_ms, sum_n = prof_builder.get("summary_pipeline", (0.0, 0))
         pile_ms, pile_n = prof_builder.get("k_pileup", (0.0, 0))
         traffic = pmc_traffic()
@@ -370,18 +528,23 @@ def main():
         out = {
             "metric": "pileup windows/sec (whole node) + Mbp/sec inferred, HG003 chr20 ONT R9",
             "value": value, "unit": "windows/s", "n_gpus": world, "steps": K, "warmup": W,
-            "ms_per_step": dt / K * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": dt / total_steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
+            "repeats": R, "timed_steps": total_steps, "timed_seconds": dt,
+            "median_chain_ms": median_chain_ms, "windows_per_s_from_median_chain": CALLERS * BATCH * world / (median_chain_ms / 1e3),
+            "windows_from_builder_per_s": builder_windows / dt,
             "config": {"workload": "configs[1]: HG003-chr20-shaped ONT R9 synthetic, batch=512 windows/step, fp32 bi-LSTM P1, "
                                    "1 region (R=100200, 60x, 10 kb reads) per step, %d steps fused per launch chain" % CALLERS,
                        "batch": BATCH, "callers": CALLERS, "region_len": REGION_LEN, "depth": DEPTH,
-                       "windows_per_region": n_windows_region / CALLERS, "parallelism": "region-sharded x%d" % world},
-            "mbp_per_s": K * world * REGION_LEN / 1e6 / dt,
+                       "windows_per_region": n_windows_region / CALLERS, "parallelism": "region-sharded x%d" % world,
+                       "backend": backend if world > 1 else None},
+            "mbp_per_s": total_steps * world * REGION_LEN / 1e6 / dt,
             "roofline": {"bound": "mfma", "kernel": "k_lstm_layer<512> (decoder bi-LSTM, fused input projection + recurrence)",
                          "achieved": achieved_tf, "peak": PEAK_F32_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved_tf / PEAK_F32_TFLOPS, "traffic": traffic.get("k_lstm_layer<512"),
                          "traffic_note": traffic.get("note"),
-                         "launch_ms": dec_avg_s * 1e3, "flop_per_launch": FLOP_DEC_PER_WINDOW * CALLERS * BATCH},
+                         "launch_ms": dec_launch_ms, "launches": dec_n, "windows_per_launch": CALLERS * BATCH,
+                         "flop_per_launch": flop_per_launch},
             "roofline_builder": {"bound": "hbm", "kernel": "summary pipeline (k_cigar_scan .. k_write_windows), %d regions/launch" % CALLERS,
                                  "achieved": alg_bytes / (sum_ms / max(sum_n, 1) / 1e3) / 1e9 if sum_ms > 0 else 0.0,
                                  "peak": PEAK_HBM_GBS, "unit": "GB/s",
@@ -392,12 +555,38 @@ def main():
             "kernel_ms": {k: v[0] / max(v[1], 1) for k, v in prof.items()},
             "rnn_model_tflops": FLOP_PER_WINDOW * value / 1e12,
         }
-        if world == 1 and not args.no_bf16:
+        secondary = world == 1
+        if secondary and not args.no_h2d:
+            try:
+                # PCIe-inclusive secondary: every chain's 16 regions are copied from page-locked host memory on a second
+                # stream inside the timed loop (double-buffered device batches); never `value`
+                pinned = [PinnedBatch(b) for b in batches]
+                dsets = [DeviceBatch(batches[0], dev) for _ in range(2)]
+                ev_copied = [torch.cuda.Event() for _ in range(2)]
+                ev_consumed = [torch.cuda.Event() for _ in range(2)]
+                h2d = (dsets, pinned, ev_copied, ev_consumed)
+                for g in range(2):
+                    group(g, h2d=h2d)
+                drain()
+                nch = max(4, n_chains // 4)
+                t0 = time.perf_counter()
+                for g in range(nch):
+                    group(g, h2d=h2d)
+                drain()
+                dth = time.perf_counter() - t0
+                out["h2d_overlapped"] = {"value": nch * CALLERS * BATCH / dth, "unit": "windows/s", "ms_per_step": dth / (nch * CALLERS) * 1e3,
+                                         "bytes_per_step": pinned[0].nbytes / CALLERS, "pcie_GBps": nch * pinned[0].nbytes / dth / 1e9,
+                                         "note": "per-chain H2D of the 16 regions from pinned memory on a copy stream, overlapped with the "
+                                                 "previous chain's kernels", "ratio_to_value": nch * CALLERS * BATCH / dth / value}
+                del pinned, dsets
+            except Exception as e:
+                out["h2d_overlapped"] = {"error": repr(e)}
+        if secondary and not args.no_bf16:
             try:
                 out["config2_bf16_input_gemm"] = bf16_secondary(dev_id, weights, dbatch, P, dev, pad)
             except Exception as e:
                 out["config2_bf16_input_gemm"] = {"error": repr(e)}
-        if world == 1 and not args.no_p2:
+        if secondary and not args.no_p2:
             try:
                 out["p1_single_call"] = single_call_secondary(ctx, dev)
             except Exception as e:
@@ -406,9 +595,15 @@ def main():
                 out["p2_bigru"] = p2_secondary(ctx, dev)
             except Exception as e:
                 out["p2_bigru"] = {"error": repr(e)}
-        if world == 1 and not args.no_cpu_baseline:
+        if secondary and not args.no_filepath:
             try:
-                out["cpu_baseline"] = cpu_baseline(weights, regions[0], min(len(os.sched_getaffinity(0)), 16))
+                from tools import bench_filepath
+                out["file_path"] = bench_filepath.run(ctx, weights, dev)
+            except Exception as e:
+                out["file_path"] = {"error": repr(e)}
+        if secondary and not args.no_cpu_baseline:
+            try:
+                out["cpu_baseline"] = cpu_baseline(batches[0].select([0]), len(os.sched_getaffinity(0)))
             except Exception as e:  # the baseline is reporting only; never fail the bench for it
                 out["cpu_baseline"] = {"value": None, "unit": "windows/s", "cores": 0, "kind": "port", "sample": "failed: %r" % (e,)}
         print(json.dumps(out))
@@ -417,7 +612,8 @@ def main():
         dist.barrier()
         dist.destroy_process_group()
     ctx.close()
+    return rc
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main() or 0)

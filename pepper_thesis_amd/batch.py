@@ -205,6 +205,17 @@ PRESETS = {
 }
 
 
+# options.min_mapq per platform preset (SetParameters.py:16-17,71-72,126-127,180-181,234-235): BAM_handler.get_reads drops
+# reads with MAPQ below it before the image builder sees them
+PRESET_MIN_MAPQ = {
+    "ont_r9_guppy5_sup": 5,
+    "ont_r9_guppy4_hac": 5,
+    "ont_r10_q20": 1,
+    "hifi": 5,
+    "clr": 5,
+}
+
+
 @dataclass
 class SummaryOut:
     """Host-side view of pv_batch_out after a call."""

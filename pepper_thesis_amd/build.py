@@ -11,7 +11,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(CSRC, "libpepper_hip.so")
 SOURCES = ["pv_api.hip", "summary_kernels.hip", "rnn_kernels.hip", "rnn_gru.hip"]
-HEADERS = ["pv_common.hpp", os.path.join("..", "..", "include", "pepper_hip.h")]
+HEADERS = ["pv_common.hpp", "mfma_tiles.hpp", os.path.join("..", "..", "include", "pepper_hip.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
          "-fgpu-rdc" if False else "-fno-gpu-rdc"]
 

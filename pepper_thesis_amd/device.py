@@ -10,6 +10,22 @@ from . import _ffi
 from .batch import RegionBatch
 
 
+def _as_tensor(a: np.ndarray) -> torch.Tensor:
+    if a.dtype == np.uint32:  # torch has no uint32 arithmetic; reinterpret the bits
+        return torch.from_numpy(a.view(np.int32).copy())
+    return torch.from_numpy(np.ascontiguousarray(a))
+
+
+class PinnedBatch:
+    """Page-locked host copy of a RegionBatch's arrays: the source of asynchronous H2D copies
+    (DeviceBatch.upload_async) when a reader thread hands batches to the GPU one ahead of the kernels."""
+
+    def __init__(self, batch: RegionBatch):
+        self.host = batch
+        self.t = {f: _as_tensor(getattr(batch, f)).pin_memory() for f in RegionBatch.FIELDS}
+        self.nbytes = sum(t.numel() * t.element_size() for t in self.t.values())
+
+
 class DeviceBatch:
     """A RegionBatch uploaded to HBM once (the benchmark's 'inputs already resident' state)."""
 
@@ -19,11 +35,7 @@ class DeviceBatch:
         c = _ffi.pv_batch_in()
         c.n_regions = batch.n_regions
         for f in RegionBatch.FIELDS:
-            a = getattr(batch, f)
-            if a.dtype == np.uint32:  # torch has no uint32 arithmetic; reinterpret the bits
-                t = torch.from_numpy(a.view(np.int32).copy()).to(device)
-            else:
-                t = torch.from_numpy(np.ascontiguousarray(a)).to(device)
+            t = _as_tensor(getattr(batch, f)).to(device)
             if t.numel() == 0:
                 t = torch.zeros(1, dtype=t.dtype, device=device)
             self.t[f] = t
@@ -32,6 +44,17 @@ class DeviceBatch:
         self.n_reads, self.n_bases, self.n_cigar = batch.n_reads, batch.n_bases, batch.n_cigar
         self.n_ref_bytes = int(batch.ref.shape[0])
         self.max_region_len = batch.max_region_len
+
+    def upload_async(self, pinned: PinnedBatch, stream: "torch.cuda.Stream"):
+        """overwrite the device arrays with another batch of IDENTICAL array sizes, asynchronously on `stream`
+        (PCIe copies from page-locked memory; the caller orders the kernels behind them with an event)"""
+        with torch.cuda.stream(stream):
+            for f, t in self.t.items():
+                src = pinned.t[f]
+                if src.numel() == 0:
+                    continue
+                assert src.shape == t.shape, (f, src.shape, t.shape)
+                t.copy_(src, non_blocking=True)
 
 
 class DeviceOut:

@@ -4,7 +4,9 @@ The reference distributes by process fan-out only: interval i goes to worker i %
 (pepper_variant/modules/python/ImageGenerationUI.py:211) and files to callers i % callers
 (RunInference.py:101-106); every caller writes its own prediction file and no gather exists. Here one
 process drives one GPU, regions are dealt the same round-robin way, and the per-window predictions
-are gathered to rank 0 with ONE collective (RCCL when the backend is nccl; gloo in CPU tests).
+are gathered to ONE rank (`dst`) with a gather, not an all-gather: the other ranks receive nothing
+(RCCL send/recv when the backend is nccl; gloo in CPU tests). The same exchange is exported from the
+C-ABI as pv_gather (include/pepper_hip.h) for hosts that do not carry torch.distributed.
 """
 from typing import List, Optional, Sequence
 
@@ -17,11 +19,21 @@ def shard_regions(n_items: int, rank: int, world: int) -> List[int]:
     return [i for i in range(n_items) if i % world == rank]
 
 
-def gather_predictions(local: torch.Tensor, dst: int = 0, keys: Optional[torch.Tensor] = None):
-    """Gather [n_r, C] float rows (and optional int64 keys [n_r]) from every rank to `dst`.
+def _gather_padded(t: torch.Tensor, m: int, dst: int, world: int, rank: int):
+    """pad `t` (rows along dim 0) to m rows and gather to dst; returns the list of per-rank padded tensors on dst"""
+    pad = torch.zeros((m,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
+    pad[: t.shape[0]] = t
+    bufs = [torch.empty_like(pad) for _ in range(world)] if rank == dst else None
+    dist.gather(pad, bufs, dst=dst)
+    return bufs
 
-    Ranks may hold different row counts: counts are all-gathered first, payloads are padded to the
-    maximum and moved with one all_gather_into_tensor (a few MB at most: ~16 B per window).
+
+def gather_predictions(local: torch.Tensor, dst: int = 0, keys: Optional[torch.Tensor] = None):
+    """Gather [n_r, C] float rows (and optional int64 keys [n_r]) from every rank to rank `dst`.
+
+    Ranks may hold different row counts: the counts are all-gathered (8 B per rank, every rank needs the
+    padded size), the payloads are padded to the maximum and moved with ONE gather to `dst`
+    (~12-20 B per window; only `dst` allocates receive buffers).
     Returns (rows [sum n_r, C], keys or None, counts) on dst, None elsewhere."""
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
         return local, keys, [int(local.shape[0])]
@@ -35,21 +47,12 @@ def gather_predictions(local: torch.Tensor, dst: int = 0, keys: Optional[torch.T
     dist.all_gather_into_tensor(counts, n)
     counts_l = [int(c) for c in counts.tolist()]
     m = max(max(counts_l), 1)
-    C = int(local.shape[1])
-    pad = torch.zeros((m, C), dtype=local.dtype, device=dev)
-    pad[: local.shape[0]] = local
-    allrows = torch.empty((world * m, C), dtype=local.dtype, device=dev)
-    dist.all_gather_into_tensor(allrows, pad)
-    allkeys = None
-    if keys is not None:
-        kp = torch.zeros(m, dtype=torch.int64, device=dev)
-        kp[: keys.shape[0]] = keys
-        allkeys = torch.empty(world * m, dtype=torch.int64, device=dev)
-        dist.all_gather_into_tensor(allkeys, kp)
+    row_bufs = _gather_padded(local, m, dst, world, rank)
+    key_bufs = None if keys is None else _gather_padded(keys.to(torch.int64), m, dst, world, rank)
     if rank != dst:
         return None
-    rows = torch.cat([allrows[r * m: r * m + counts_l[r]] for r in range(world)])
-    ks = None if allkeys is None else torch.cat([allkeys[r * m: r * m + counts_l[r]] for r in range(world)])
+    rows = torch.cat([row_bufs[r][: counts_l[r]] for r in range(world)])
+    ks = None if key_bufs is None else torch.cat([key_bufs[r][: counts_l[r]] for r in range(world)])
     return rows, ks, counts_l
 
 

@@ -40,6 +40,33 @@ class CandidateOptions:
     indel_q_cutoff_in_lc: int = 10
 
 
+# candidate-finding scalars per platform preset, in CandidateOptions field order
+# (SetParameters.py:39-66 guppy5_sup, :93-121 guppy4_hac, :148-176 r10_q20, :202-230 hifi, :256-283 clr)
+CANDIDATE_PRESETS = {
+    "ont_r9_guppy5_sup": CandidateOptions(4, 0.1, 0.1, 0.1, 20, 15, 0, 0, 0.1, 0.15, 0.1, 20, 10),
+    "ont_r9_guppy4_hac": CandidateOptions(4, 0.10, 0.25, 0.25, 20, 15, 0, 0, 0.05, 0.01, 0.01, 20, 10),
+    "ont_r10_q20": CandidateOptions(4, 0.00001, 0.001, 0.001, 15, 30, 0, 0, 0.000001, 0.001, 0.001, 20, 35),
+    "hifi": CandidateOptions(4, 0, 0, 0, 15, 20, 0, 0, 0, 0, 0, 15, 20),
+    "clr": CandidateOptions(4, 0.1, 0.2, 0.2, 20, 20, 0, 0, 0.05, 0.05, 0.05, 20, 20),
+}
+
+
+def add_candidate_arguments(ap):
+    """the per-threshold overrides of FindCandidatesArguments / CallVariantsArguments (None = take the preset's value,
+    SetParameters.py `if options.X is None`)"""
+    import dataclasses
+    for f in dataclasses.fields(CandidateOptions):
+        ap.add_argument("--" + f.name, type=int if f.type in (int, "int") else float, default=None)
+
+
+def candidate_options_from_args(args, preset: str) -> CandidateOptions:
+    import dataclasses
+    base = CANDIDATE_PRESETS[preset]
+    over = {f.name: getattr(args, f.name) for f in dataclasses.fields(CandidateOptions)
+            if getattr(args, f.name, None) is not None}
+    return dataclasses.replace(base, **over)
+
+
 def repeat_annotation(sequence: str, kmer_size: int) -> List[int]:
     """CandidateFinder.py:277-297"""
     max_observed_repeats = [1] * len(sequence)
@@ -278,8 +305,14 @@ def main(argv=None):
     ap.add_argument("-f", "--fasta", required=True)
     ap.add_argument("-o", "--output_dir", required=True)
     ap.add_argument("-s", "--sample_name", default="SAMPLE")
+    g = ap.add_mutually_exclusive_group(required=True)
+    for name in CANDIDATE_PRESETS:
+        g.add_argument("--" + name, action="store_true")
+    add_candidate_arguments(ap)
     args = ap.parse_args(argv)
-    c = process_candidates(args.input_dir, args.fasta, args.sample_name, args.output_dir)
+    preset = next(n for n in CANDIDATE_PRESETS if getattr(args, n))
+    c = process_candidates(args.input_dir, args.fasta, args.sample_name, args.output_dir,
+                           candidate_options_from_args(args, preset))
     import sys
     sys.stderr.write("INFO: FINISHED PROCESSING, TOTAL CANDIDATES FOUND: %d (PEPPER %d, RE-GENOTYPING %d: SNP %d INDEL %d)\n" %
                      (c["total"], c["pepper"], c["variant_calling"], c["snp"], c["indel"]))

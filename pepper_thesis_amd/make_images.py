@@ -73,6 +73,27 @@ def parse_region(region: str):
     return contig, int(a), int(b)
 
 
+def list_intervals(fasta, bam, region: str = None, region_size: int = 100_000) -> List[Tuple[str, int, int]]:
+    """the interval list of generate_images (ImageGenerationUI.py:286-316): a whole contig is [0, length-1], a user region is
+    clamped to [max(0, start), min(end, length-1)], both cut into region_size pieces that share their boundary position"""
+    todo = []
+    if region:
+        for part in region.split(","):
+            contig, a, b = parse_region(part.strip())
+            last = fasta.get_chromosome_sequence_length(contig) - 1
+            if a is None:
+                a, b = 0, last
+            else:
+                a, b = max(0, a), min(b, last)
+            todo += split_intervals(contig, a, b, region_size)
+    else:
+        in_bam = set(bam.get_chromosome_sequence_names())
+        for n in fasta.get_chromosome_names():
+            if n in in_bam:
+                todo += split_intervals(n, 0, fasta.get_chromosome_sequence_length(n) - 1, region_size)
+    return todo
+
+
 def generate_images(ctx, bam_path: str, fasta_path: str, output_dir: str, params: Params, region: str = None,
                     region_size: int = 100_000, min_mapq: int = 5, include_supplementary: bool = False,
                     downsample_rate: float = 1.0, intervals_per_call: int = 8, rank: int = 0, world: int = 1) -> int:
@@ -83,16 +104,7 @@ def generate_images(ctx, bam_path: str, fasta_path: str, output_dir: str, params
     from .batch import pack_regions
     from .hdf5io import ImageStore
     bam, fasta = BamHandler(bam_path), FastaHandler(fasta_path)
-    if region:
-        todo = []
-        for part in region.split(","):
-            contig, a, b = parse_region(part)
-            if a is None:
-                a, b = 0, fasta.get_chromosome_sequence_length(contig)
-            todo += split_intervals(contig, a, b, region_size)
-    else:
-        names = [n for n in fasta.get_chromosome_names() if n in set(bam.get_chromosome_sequence_names())]
-        todo = [iv for n in names for iv in split_intervals(n, 0, fasta.get_chromosome_sequence_length(n), region_size)]
+    todo = list_intervals(fasta, bam, region, region_size)
     mine = [iv for i, iv in enumerate(todo) if i % world == rank]
     os.makedirs(output_dir, exist_ok=True)
     n_windows = 0
@@ -107,12 +119,39 @@ def generate_images(ctx, bam_path: str, fasta_path: str, output_dir: str, params
             for g, i in enumerate(keep):
                 contig, start, end = ivs[i]
                 sel = np.flatnonzero(out.region == g)
-                if sel.size == 0:
-                    continue
+                # an interval with reads but no candidate still gets its (empty) group, as the reference's write_summary
+                # of empty lists does (ImageGenerationUI.py:228-259)
                 store.write_summary("%s_%d_%d" % (contig, start, end), [contig] * sel.size, out.position[sel], out.depth[sel],
                                     [[out.candidates[j]] for j in sel], out.cand_freq[sel].reshape(-1, 1), out.images[sel])
             n_windows += len(out)
     return n_windows
+
+
+# CLI name -> Params field of the per-threshold overrides (CallVariantsArguments.py / MakeImagesArguments.py; None = preset)
+_IMAGE_OVERRIDES = (("min_snp_baseq", "min_snp_baseq", float), ("min_indel_baseq", "min_indel_baseq", float),
+                    ("snp_frequency", "snp_freq_threshold", float), ("insert_frequency", "insert_freq_threshold", float),
+                    ("delete_frequency", "delete_freq_threshold", float), ("min_coverage_threshold", "min_coverage_threshold", float),
+                    ("candidate_support_threshold", "candidate_support_threshold", float),
+                    ("snp_candidate_frequency_threshold", "snp_candidate_freq_threshold", float),
+                    ("indel_candidate_frequency_threshold", "indel_candidate_freq_threshold", float))
+
+
+def add_image_arguments(ap):
+    for cli, _, typ in _IMAGE_OVERRIDES:
+        ap.add_argument("--" + cli, type=typ, default=None)
+    ap.add_argument("--skip_indels", action="store_true", default=False)
+
+
+def image_options_from_args(args, preset: str):
+    """-> (Params, min_mapq): the preset's scalars with any explicit override applied (SetParameters.py `if X is None`)"""
+    import dataclasses
+    from .batch import PRESET_MIN_MAPQ, PRESETS
+    over = {field: getattr(args, cli) for cli, field, _ in _IMAGE_OVERRIDES if getattr(args, cli, None) is not None}
+    if getattr(args, "skip_indels", False):
+        over["skip_indels"] = True
+    params = dataclasses.replace(PRESETS[preset], **over)
+    mq = getattr(args, "min_mapq", None)
+    return params, (PRESET_MIN_MAPQ[preset] if mq is None else int(mq))
 
 
 def main(argv=None):
@@ -128,16 +167,18 @@ def main(argv=None):
     ap.add_argument("--region_size", type=int, default=100_000)
     ap.add_argument("-d", "--downsample_rate", type=float, default=1.0)
     ap.add_argument("--include_supplementary", action="store_true")
-    ap.add_argument("--min_mapq", type=int, default=5)
+    ap.add_argument("--min_mapq", type=int, default=None, help="default: the platform preset's value (SetParameters.py)")
     ap.add_argument("-t", "--threads", type=int, default=1)
     g = ap.add_mutually_exclusive_group(required=True)
     for name in PRESETS:
         g.add_argument("--" + name, action="store_true")
+    add_image_arguments(ap)
     args = ap.parse_args(argv)
     preset = next(n for n in PRESETS if getattr(args, n))
+    params, args.min_mapq = image_options_from_args(args, preset)
     rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
     ctx = Context(int(os.environ.get("LOCAL_RANK", "0")))
-    n = generate_images(ctx, args.bam, args.fasta, args.output_dir, PRESETS[preset], args.region, args.region_size,
+    n = generate_images(ctx, args.bam, args.fasta, args.output_dir, params, args.region, args.region_size,
                         args.min_mapq, args.include_supplementary, args.downsample_rate, rank=rank, world=world)
     ctx.close()
     import sys

@@ -26,7 +26,7 @@ class Predictor:
         else:
             raise ValueError(plan)
 
-    def predict(self, images: np.ndarray, batch_size: int = 512, callers: int = 8) -> np.ndarray:
+    def predict(self, images: np.ndarray, batch_size: int = 512, callers: int = 16) -> np.ndarray:
         """images [N,33,26] int8 -> [N,3] float32; `callers` batches are fused per device call"""
         assert self.plan == "p1"
         step = max(1, batch_size * callers)

@@ -6,7 +6,7 @@ directory is read (dataloader_predict.py:46-78), windows go through the P1 netwo
 results are written as `predictions/batch_<k>` groups (DataStorePredict.py:49-66) that the unmodified
 `find_candidates` consumes. Flags keep the reference's names (RunInferenceArguments.py:7-124).
 
-  python -m pepper_thesis_amd.run_inference -i IMAGE_DIR -m MODEL -o OUTPUT_DIR [-bs 512] [-per_gpu 8] [-d_ids 0]
+  python -m pepper_thesis_amd.run_inference -i IMAGE_DIR -m MODEL -o OUTPUT_DIR [-bs 512] [-per_gpu 16] [-d_ids 0]
 
 MODEL is the reference's checkpoint (torch.save dict with 'model_state_dict', ModelHander.py:18-44; loaded
 with weights_only=True) or an .npz of the same state dict. With several ranks (torchrun) files are dealt
@@ -37,7 +37,7 @@ def load_state_dict(model_path: str) -> dict:
     return {k: v.detach().cpu().numpy() for k, v in sd.items()}
 
 
-def predict_files(ctx, state_dict, input_files, output_file, batch_size=512, callers=8):
+def predict_files(ctx, state_dict, input_files, output_file, batch_size=512, callers=16):
     """predict() of predict_distributed_gpu.py:19-74 for a list of image files -> one prediction file"""
     from .hdf5io import ImageStore, PredictionStore
     from .predict import Predictor
@@ -47,6 +47,7 @@ def predict_files(ctx, state_dict, input_files, output_file, batch_size=512, cal
         for path in input_files:
             with ImageStore(path, "r") as store:
                 parts = [store.read_summary(name) for name in store.summaries()]
+            parts = [p for p in parts if len(p["positions"])]  # intervals with reads but no candidate leave empty groups
             if not parts:
                 continue
             cat = {k: np.concatenate([p[k] for p in parts]) for k in parts[0]}
@@ -66,7 +67,7 @@ def main(argv=None):
     ap.add_argument("-m", "--model_path", required=True)
     ap.add_argument("-o", "--output_dir", required=True)
     ap.add_argument("-bs", "--batch_size", type=int, default=512)
-    ap.add_argument("-per_gpu", "--callers_per_gpu", type=int, default=8)
+    ap.add_argument("-per_gpu", "--callers_per_gpu", type=int, default=16)
     ap.add_argument("-d_ids", "--device_ids", type=str, default=None)
     ap.add_argument("-g", "--gpu", action="store_true", default=True)
     ap.add_argument("-t", "--threads", type=int, default=8)
