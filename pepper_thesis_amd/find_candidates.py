@@ -6,9 +6,9 @@ predictions -> VCF runs end to end on this code base:
   find_candidates (dedupe)  CandidateFinder.py:532-581
   candidate_list_to_variant pepper_variant/modules/python/VcfWriter.py:48-138
   write_vcf_records         VcfWriter.py:140-218   (header fields :220-289)
-The reference writes bgzipped + tabix-indexed VCFs through pysam; pysam/htslib are not available here, so
-the five files are written as plain-text `.vcf` with the same records, FILTER/FORMAT fields and file split
-(FULL, PEPPER, VARIANT_CALLING, *_SNPs, *_INDEL).
+The reference writes bgzipped + tabix-indexed VCFs through pysam (VcfWriter.py:21-46); pysam/htslib are not available
+here, so the same five `.vcf.gz` files (FULL, PEPPER, VARIANT_CALLING, *_SNPs, *_INDEL) and their `.tbi` indexes are written
+by the native BGZF / tabix writer of csrc/pv_io.cpp (pvio_write_vcf_gz), with the same records and FILTER/FORMAT fields.
 Parity note: the reference module cannot be imported here (needs pysam/h5py/the pybind build) and ships no
 tests or fixtures for it: this restatement is pinned by nothing ("parity unpinned"); tests check its
 invariants and that GPU and oracle probabilities give identical records.
@@ -275,26 +275,25 @@ def process_candidates(prediction_dir: str, fasta_path: str, sample_name: str, o
     header = VCF_HEADER + "".join("##contig=<ID=%s,length=%d>\n" % (n, fasta.get_chromosome_sequence_length(n))
                                   for n in fasta.get_chromosome_names()) + \
         "#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\t%s\n" % sample_name
-    names = {"full": "PEPPER_VARIANT_FULL.vcf", "pepper": "PEPPER_VARIANT_OUTPUT_PEPPER.vcf",
-             "vc": "PEPPER_VARIANT_OUTPUT_VARIANT_CALLING.vcf", "snp": "PEPPER_VARIANT_OUTPUT_VARIANT_CALLING_SNPs.vcf",
-             "indel": "PEPPER_VARIANT_OUTPUT_VARIANT_CALLING_INDEL.vcf"}
-    files = {k: open(os.path.join(output_dir, v), "w") for k, v in names.items()}
-    for f in files.values():
-        f.write(header)
+    names = {"full": "PEPPER_VARIANT_FULL.vcf.gz", "pepper": "PEPPER_VARIANT_OUTPUT_PEPPER.vcf.gz",
+             "vc": "PEPPER_VARIANT_OUTPUT_VARIANT_CALLING.vcf.gz", "snp": "PEPPER_VARIANT_OUTPUT_VARIANT_CALLING_SNPs.vcf.gz",
+             "indel": "PEPPER_VARIANT_OUTPUT_VARIANT_CALLING_INDEL.vcf.gz"}
+    texts = {k: [header] for k in names}
     counts = dict(total=0, pepper=0, variant_calling=0, snp=0, indel=0)
     for line, selected_vc, is_snp in variant_records(variants, opt):
-        files["full"].write(line + "\n")
+        texts["full"].append(line + "\n")
         counts["total"] += 1
         if selected_vc:
-            files["snp" if is_snp else "indel"].write(line + "\n")
+            texts["snp" if is_snp else "indel"].append(line + "\n")
             counts["snp" if is_snp else "indel"] += 1
-            files["vc"].write(line + "\n")
+            texts["vc"].append(line + "\n")
             counts["variant_calling"] += 1
         else:
-            files["pepper"].write(line + "\n")
+            texts["pepper"].append(line + "\n")
             counts["pepper"] += 1
-    for f in files.values():
-        f.close()
+    from .bamio import write_vcf_gz
+    for k, fname in names.items():  # bgzip + tabix index, as VariantFile(..., 'w') + pysam.tabix_index (VcfWriter.py:21-46)
+        write_vcf_gz(os.path.join(output_dir, fname), "".join(texts[k]))
     return counts
 
 

@@ -291,6 +291,15 @@ class ImageStore:
             return
         self._written.add(summary_name)
         base = "%s/%s/" % (self._summary_path_, summary_name)
+        if len(positions) == 0:
+            # np.array([], dtype=...) of the reference's empty lists: one-dimensional empty datasets
+            self.f.write(base + "contigs", np.zeros(0, dtype="S1"))
+            self.f.write(base + "positions", np.zeros(0, dtype=np.int32))
+            self.f.write(base + "depths", np.zeros(0, dtype=np.uint8))
+            self.f.write(base + "candidates", np.zeros(0, dtype=object), vlen_str=True)
+            self.f.write(base + "candidate_frequency", np.zeros(0, dtype=np.uint8))
+            self.f.write(base + "images", np.zeros(0, dtype=np.int8))
+            return
         self.f.write(base + "contigs", np.array([c.encode() if isinstance(c, str) else c for c in contigs], dtype="S"))
         self.f.write(base + "positions", np.asarray(positions, dtype=np.int32))
         self.f.write(base + "depths", np.asarray(depths, dtype=np.uint8))

@@ -37,27 +37,42 @@ def load_state_dict(model_path: str) -> dict:
     return {k: v.detach().cpu().numpy() for k, v in sd.items()}
 
 
-def predict_files(ctx, state_dict, input_files, output_file, batch_size=512, callers=16):
-    """predict() of predict_distributed_gpu.py:19-74 for a list of image files -> one prediction file"""
+def predict_files(ctx, state_dict, input_files, output_file, batch_size=512, callers=16, timers=None):
+    """predict() of predict_distributed_gpu.py:19-74 for a list of image files -> one prediction file.
+    `timers` (optional dict) receives the stage times in seconds."""
+    import time
     from .hdf5io import ImageStore, PredictionStore
     from .predict import Predictor
+    T = dict(hdf5_read_s=0.0, predict_call_s=0.0, hdf5_write_s=0.0)
+    t_start = time.perf_counter()
     predictor = Predictor(ctx, state_dict, "p1")
+    T["load_weights_s"] = time.perf_counter() - t_start
     n_windows, batch_no = 0, 0
     with PredictionStore(output_file, "w") as out:
         for path in input_files:
+            t0 = time.perf_counter()
             with ImageStore(path, "r") as store:
                 parts = [store.read_summary(name) for name in store.summaries()]
             parts = [p for p in parts if len(p["positions"])]  # intervals with reads but no candidate leave empty groups
+            T["hdf5_read_s"] += time.perf_counter() - t0
             if not parts:
                 continue
             cat = {k: np.concatenate([p[k] for p in parts]) for k in parts[0]}
+            t0 = time.perf_counter()
             probs = predictor.predict(cat["images"], batch_size, callers)
+            T["predict_call_s"] += time.perf_counter() - t0
+            t0 = time.perf_counter()
             for i in range(0, len(probs), batch_size):
                 sl = slice(i, i + batch_size)
                 out.write_prediction(batch_no, cat["contigs"][sl], cat["positions"][sl], cat["depths"][sl],
                                      cat["candidates"][sl], cat["candidate_frequency"][sl], probs[sl].astype(np.float64))
                 batch_no += 1
+            T["hdf5_write_s"] += time.perf_counter() - t0
             n_windows += len(probs)
+    T["wall_s"] = time.perf_counter() - t_start
+    T["windows"] = n_windows
+    if timers is not None:
+        timers.update(T)
     return n_windows
 
 

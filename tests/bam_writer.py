@@ -63,7 +63,6 @@ def write_bam(path, refs, records, block_records=40):
         if n_in_block >= block_records:
             flush()
             n_in_block = 0
-        vbeg = (len(out) << 16) | len(cur)
         cig = rec["cigar"]
         seq = rec["seq"]
         end = rec["pos"] + max(ref_len(cig), 1)
@@ -76,15 +75,25 @@ def write_bam(path, refs, records, block_records=40):
         if rec.get("hp") is not None:
             aux += b"HPC" + struct.pack("<B", rec["hp"])
         aux += b"NMi" + struct.pack("<i", 3) + b"RGZgrp1\x00"
-        body = struct.pack("<iiBBHHHIiii", rec["tid"], rec["pos"], len(name), rec["mapq"], b, len(cig), rec["flag"], len(seq), -1, -1, 0)
-        body += name + b"".join(struct.pack("<I", (l << 4) | op) for op, l in cig) + bytes(packed) + bytes(rec["qual"]) + aux
-        cur += struct.pack("<I", len(body)) + body
-        n_in_block += 1
-        vend = (len(out) << 16) | len(cur)
-        if len(cur) >= 0xFF00:  # keep uoffset representable
+        cig_rec = cig
+        if rec.get("cg"):
+            # SAMv1 4.2.2: a CIGAR too long for the 16-bit count lives in the CG:B,I tag behind a <l_seq>S<rlen>N placeholder
+            cig_rec = [(4, len(seq)), (3, ref_len(cig))]
+            aux += b"CGBI" + struct.pack("<I", len(cig)) + b"".join(struct.pack("<I", (l << 4) | op) for op, l in cig)
+        body = struct.pack("<iiBBHHHIiii", rec["tid"], rec["pos"], len(name), rec["mapq"], b, len(cig_rec), rec["flag"], len(seq), -1, -1, 0)
+        body += name + b"".join(struct.pack("<I", (l << 4) | op) for op, l in cig_rec) + bytes(packed) + bytes(rec["qual"]) + aux
+        data = struct.pack("<I", len(body)) + body
+        if cur and len(cur) + len(data) > 0xFF00:  # a BGZF block holds at most 64 KiB: start the record in a fresh block
             flush()
             n_in_block = 0
-            vend = (len(out) << 16)
+        vbeg = (len(out) << 16) | len(cur)
+        cur += data
+        while len(cur) > 0xFF00:                   # a record longer than a block spans blocks
+            head, rest = bytes(cur[:0xFF00]), cur[0xFF00:]
+            out.extend(_bgzf_block(head))
+            cur = bytearray(rest)
+        n_in_block += 1
+        vend = (len(out) << 16) | len(cur)
         ix = index[rec["tid"]]
         ix["bins"].setdefault(b, []).append([vbeg, vend])
         for w in range(rec["pos"] >> 14, ((end - 1) >> 14) + 1):

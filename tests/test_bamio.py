@@ -81,3 +81,165 @@ def test_region_from_files_feeds_the_builder(files, oracle_lib):
 
 def bw_pack(cig):
     return np.asarray([(l << 4) | op for op, l in cig], dtype=np.uint32)
+
+
+# ---- hardening: sizes taken from the file are validated; long CIGARs come from the CG tag ----------------------------------
+
+def _small_files(tmp_path, recs, n=4000, name="h"):
+    rng = np.random.default_rng(1)
+    seq = "".join(rng.choice(list("ACGT"), size=n))
+    fa, bam = str(tmp_path / (name + ".fa")), str(tmp_path / (name + ".bam"))
+    bw.write_fasta(fa, [("c1", seq)])
+    bw.write_bam(bam, [("c1", n)], recs)
+    return fa, bam, seq
+
+
+def test_cg_tag_long_cigar(tmp_path):
+    """a read whose real CIGAR sits in CG:B,I behind the <l_seq>S<rlen>N placeholder is returned exactly like the same read
+    with an inline CIGAR (htslib resolves the tag in bam_read1, so the reference never sees the placeholder)"""
+    build.build_io()
+    rng = np.random.default_rng(2)
+    recs = bw.random_records(rng, 30, 4000, tid=0, mean_len=600, allow_skip=False)
+    for r in recs:
+        r["flag"], r["mapq"] = r["flag"] & 0x10, 60
+    import copy
+    tagged = copy.deepcopy(recs)
+    for r in tagged[::2]:
+        r["cg"] = True
+    fa, bam1, _ = _small_files(tmp_path, recs, name="inline")
+    _, bam2, _ = _small_files(tmp_path, tagged, name="cgtag")
+    a = bamio.BamHandler(bam1).get_reads("c1", 500, 3500, False, 0, 0)
+    b = bamio.BamHandler(bam2).get_reads("c1", 500, 3500, False, 0, 0)
+    assert len(a) == len(b) > 10
+    for x, y in zip(a, b):
+        assert (x.pos, x.pos_end, x.bases, x.quals.tolist(), x.cigar.tolist()) == (y.pos, y.pos_end, y.bases, y.quals.tolist(), y.cigar.tolist())
+    exp = bw.expected_reads(recs, 0, 500, 3500, False, 0)
+    assert [e["seq"] for e in exp] == [y.bases.decode() for y in b]
+
+
+def test_truncated_and_corrupt_inputs_fail_cleanly(tmp_path):
+    build.build_io()
+    rng = np.random.default_rng(4)
+    recs = bw.random_records(rng, 200, 4000, tid=0, mean_len=500, allow_skip=False)
+    fa, bam, _ = _small_files(tmp_path, recs)
+    raw = open(bam, "rb").read()
+    bai = open(bam + ".bai", "rb").read()
+    # truncated BAI: every prefix either loads or is refused with a message, never crashes
+    for cut in (6, 9, 13, 21, 40, len(bai) // 2, len(bai) - 3):
+        p = str(tmp_path / ("t%d.bam" % cut))
+        open(p, "wb").write(raw)
+        open(p + ".bai", "wb").write(bai[:cut])
+        with pytest.raises(IOError):
+            bamio.BamHandler(p)
+    # truncated BAM body: reads up to the cut come back or a clean error is raised
+    p = str(tmp_path / "cut.bam")
+    open(p, "wb").write(raw[: len(raw) * 2 // 3])
+    open(p + ".bai", "wb").write(bai)
+    try:
+        bamio.BamHandler(p).get_reads("c1", 0, 4000, True, 0, 0)
+    except IOError as e:
+        assert "BGZF" in str(e) or "BAM" in str(e) or "truncated" in str(e)
+    # a record whose l_seq / n_cigar claim more bytes than block_size holds is refused (no read past the record)
+    bad = [dict(r) for r in recs[:5]]
+    p2 = str(tmp_path / "bad.bam")
+    bw.write_bam(p2, [("c1", 4000)], bad)
+    body = bytearray(bgzf_plain(open(p2, "rb").read()))
+    # first alignment record starts after the header: find it through the BAI-independent layout
+    import struct
+    l_text = struct.unpack_from("<I", body, 4)[0]
+    off = 8 + l_text
+    n_ref = struct.unpack_from("<I", body, off)[0]
+    off += 4
+    for _ in range(n_ref):
+        ln = struct.unpack_from("<I", body, off)[0]
+        off += 4 + ln + 4
+    struct.pack_into("<I", body, off + 4 + 16, 0x00FFFFFF)   # l_seq far beyond block_size
+    p3 = str(tmp_path / "bad2.bam")
+    # same block layout as the writer's (header block, then the records), so that the index offsets still apply
+    open(p3, "wb").write(bw._bgzf_block(bytes(body[:off])) + bw._bgzf_block(bytes(body[off:])) + bw.BGZF_EOF)
+    open(p3 + ".bai", "wb").write(open(p2 + ".bai", "rb").read())
+    with pytest.raises(IOError) as ei:
+        bamio.BamHandler(p3).get_reads("c1", 0, 4000, True, 0, 0)
+    assert "corrupt BAM record" in str(ei.value)
+
+
+def bgzf_plain(raw: bytes) -> bytes:
+    import zlib
+    out, p = bytearray(), 0
+    while p < len(raw):
+        bsize = int.from_bytes(raw[p + 16:p + 18], "little") + 1
+        out += zlib.decompress(raw[p + 18:p + bsize - 8], -15)
+        p += bsize
+    return bytes(out)
+
+
+def test_full_64k_blocks_and_native_writer_roundtrip(tmp_path):
+    """the native writer's BAM (blocks filled to the limit) read back by the native reader equals the restated clipping"""
+    build.build_io()
+    from pepper_thesis_amd.batch import Read, Region, pack_regions
+    rng = np.random.default_rng(8)
+    recs = bw.random_records(rng, 400, 50_000, tid=0, mean_len=3000, allow_skip=False)
+    for r in recs:
+        r["flag"], r["mapq"], r["hp"] = r["flag"] & 0x10, 60, None
+        r["seq"] = r["seq"].replace("N", "A")
+    reads = [Read.make(r["pos"], bw_pack(r["cigar"]), r["seq"], r["qual"], bool(r["flag"] & 0x10), r["mapq"]) for r in recs]
+    b = pack_regions([Region(0, 49_999, b"A" * 50_000, reads)])
+    path = str(tmp_path / "native.bam")
+    bamio.write_bam(path, [("c1", 50_000)], np.zeros(len(reads), np.int32), b, level=1)
+    got = bamio.BamHandler(path).get_reads("c1", 10_000, 40_000, False, 0, 0)
+    exp = bw.expected_reads(recs, 0, 10_000, 40_000, False, 0)
+    assert len(got) == len(exp) > 50
+    for g, e in zip(got, exp):
+        assert (g.pos, g.pos_end, g.bases.decode(), g.quals.tolist()) == (e["pos"], e["pos_end"], e["seq"], e["qual"])
+
+
+def test_fill_batch_equals_per_read_path_and_reservoir(files):
+    """pvio_fill_batch (flat arrays for a list of intervals in one native call) == region_from_files per interval; the native
+    reservoir indices equal NumPy's legacy RandomState stream"""
+    from pepper_thesis_amd.batch import RegionBatch, pack_regions
+    from pepper_thesis_amd.make_images import downsample_indices
+    for n, rate in ((6000, 1.0), (100, 0.5), (5001, 1.0), (7, 0.0), (12000, 0.8), (10, 1.0)):
+        np.testing.assert_array_equal(bamio.reservoir_indices(n, rate), downsample_indices(n, rate))
+    b, f = bamio.BamHandler(files["dna_bam"]), bamio.FastaHandler(files["fa"])
+    ivs = [("chr20", 20_000, 30_000), ("chr20", 30_000, 40_000), ("chrM", 0, 5000), ("chr20", 120_000, 129_999)]
+    for rate in (1.0, 0.3):
+        fb = bamio.fill_batch(b, f, ivs, 5, False, rate)
+        regs = [bamio.region_from_files(b, f, c, a, e, 5, False, rate) for c, a, e in ivs]
+        keep = [i for i, r in enumerate(regs) if r.reads]
+        ref = pack_regions([regs[i] for i in keep])
+        assert fb.interval_index.tolist() == keep
+        for fld in RegionBatch.FIELDS:
+            np.testing.assert_array_equal(getattr(ref, fld), getattr(fb.batch, fld), err_msg=fld)
+        fb.close()
+
+
+def test_vcf_gz_and_tabix_roundtrip(tmp_path):
+    build.build_io()
+    lines = ["##fileformat=VCFv4.2", "#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO"]
+    for c in ("chr1", "chr2"):
+        for p in range(100, 400_000, 37):
+            lines.append("%s\t%d\t.\tAC\tA\t30\tPASS\t." % (c, p))
+    text = "\n".join(lines) + "\n"
+    path = str(tmp_path / "x.vcf.gz")
+    bamio.write_vcf_gz(path, text)
+    import gzip
+    assert gzip.open(path, "rb").read().decode() == text          # a BGZF file is a valid multi-member gzip file
+    assert bamio.bgzf_read_all(path).decode() == text
+    tbi = bamio.bgzf_read_all(path + ".tbi")
+    import struct
+    assert tbi[:4] == b"TBI\x01"
+    n_ref, fmt, col_seq, col_beg, col_end, meta, skip, l_nm = struct.unpack_from("<8i", tbi, 4)
+    assert (n_ref, fmt, col_seq, col_beg, col_end, meta, skip) == (2, 2, 1, 2, 0, ord("#"), 0)
+    assert tbi[36:36 + l_nm] == b"chr1\x00chr2\x00"
+    # walk the index: every chunk's virtual offsets point into the file and chunk starts are record starts
+    off = 36 + l_nm
+    raw = open(path, "rb").read()
+    for _ in range(n_ref):
+        n_bin = struct.unpack_from("<i", tbi, off)[0]; off += 4
+        for _ in range(n_bin):
+            _bin, n_chunk = struct.unpack_from("<Ii", tbi, off); off += 8
+            for _ in range(n_chunk):
+                beg, end = struct.unpack_from("<QQ", tbi, off); off += 16
+                assert (beg >> 16) < len(raw) and beg < end
+        n_intv = struct.unpack_from("<i", tbi, off)[0]; off += 4 + 8 * n_intv
+    assert off == len(tbi)

@@ -147,17 +147,21 @@ def test_call_variant_bam_to_vcf(hip_ctx, oracle_lib, tmp_path):
     counts = call_variant.main(["-b", str(tmp_path / "reads.bam"), "-f", str(tmp_path / "ref.fa"), "-m", str(tmp_path / "model.npz"),
                                 "-o", str(out), "-s", "HG003", "--ont_r9_guppy5_sup", "-r", "chr20:2000-38000", "--region_size", "12000"])
     assert counts["total"] > 20 and counts["total"] == counts["pepper"] + counts["variant_calling"]
-    full = [l for l in open(out / "PEPPER_VARIANT_FULL.vcf") if not l.startswith("#")]
+    import gzip
+    vcf_text = gzip.open(out / "PEPPER_VARIANT_FULL.vcf.gz", "rt").read()
+    assert os.path.exists(out / "PEPPER_VARIANT_FULL.vcf.gz.tbi") and os.path.exists(out / "PEPPER_VARIANT_OUTPUT_VARIANT_CALLING_SNPs.vcf.gz.tbi")
+    full = [l for l in vcf_text.splitlines(True) if not l.startswith("#")]
     assert len(full) == counts["total"]
     pos = [int(l.split("\t")[1]) for l in full]
     assert pos == sorted(pos) and len(set(pos)) == len(pos)
-    assert open(out / "PEPPER_VARIANT_FULL.vcf").read().startswith("##fileformat=VCF")
+    assert vcf_text.startswith("##fileformat=VCF")
     # the same prediction records with oracle probabilities -> identical VCF lines
     pred_dir = [p for p in os.listdir(out) if p.startswith("predictions_")][0]
     records = list(fc.read_prediction_records(str(out / pred_dir)))
     img_dir = [p for p in os.listdir(out) if p.startswith("images_")][0]
     with hdf5io.ImageStore(str(out / img_dir / "pepper_variants_images_thread_0.hdf5"), "r") as st:
         parts = [st.read_summary(n) for n in st.summaries()]
+    parts = [p for p in parts if len(p["positions"])]
     images = np.concatenate([p["images"] for p in parts])
     keys = [(p["positions"][i], p["candidates"][i, 0]) for p in parts for i in range(len(p["positions"]))]
     ref_probs = dict(zip(keys, rnn_oracle.p1_forward(w, images, np.float64)))

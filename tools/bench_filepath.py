@@ -1,0 +1,99 @@
+"""bench.py secondary leg: the REAL-FILE path — BAM + BAI / FASTA + FAI on disk -> make_images (native readers on a thread
+pool, HIP image builder, image HDF5) -> run_inference (image HDF5 -> HIP RNN -> prediction HDF5) — with stage timers.
+The BAM is synthetic (SURVEY 8(d) shape: one contig of >= 1 Mbp at 60x, 10 kb reads, planted sites) and is written here
+with the library's own BAM writer (pvio_write_bam); nothing under oracle/ is used. Not part of `value`.
+
+  python tools/bench_filepath.py [--mbp 1.0]
+"""
+import argparse
+import json
+import os
+import shutil
+import sys
+import tempfile
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def make_files(dirname, contig_len, depth=60, read_len=10_000, site_every=198, seed=77):
+    """synthetic contig + reads -> ref.fa(.fai), reads.bam(.bai)"""
+    from pepper_thesis_amd import bamio, synth
+    from pepper_thesis_amd.batch import pack_regions
+    t0 = time.perf_counter()
+    reg = synth.synth_region(seed, region_len=contig_len, depth=depth, read_len=read_len, site_every=site_every, ref_start=0,
+                             contig="chr20")
+    b = pack_regions([reg])
+    fa = os.path.join(dirname, "ref.fa")
+    width = 60
+    with open(fa, "wb") as f:
+        f.write(b">chr20 synthetic\n")
+        off = f.tell()
+        ref = np.frombuffer(reg.ref, dtype=np.uint8)
+        pad = (-len(ref)) % width
+        lines = np.concatenate([ref, np.zeros(pad, np.uint8)]).reshape(-1, width)
+        body = np.concatenate([lines, np.full((lines.shape[0], 1), 10, np.uint8)], axis=1).reshape(-1)
+        body = body[body != 0]
+        f.write(body.tobytes())
+        if body[-1] != 10:
+            f.write(b"\n")
+    with open(fa + ".fai", "w") as f:
+        f.write("chr20\t%d\t%d\t%d\t%d\n" % (len(ref), off, width, width + 1))
+    bam = os.path.join(dirname, "reads.bam")
+    bamio.write_bam(bam, [("chr20", contig_len)], np.zeros(b.n_reads, np.int32), b, level=1)
+    return bam, fa, dict(reads=b.n_reads, bases=b.n_bases, synth_and_write_s=time.perf_counter() - t0,
+                         bam_bytes=os.path.getsize(bam))
+
+
+def run(ctx, weights, dev=None, mbp=1.0, keep_dir=None):
+    from pepper_thesis_amd import make_images, run_inference
+    from pepper_thesis_amd.batch import PRESETS
+    d = keep_dir or tempfile.mkdtemp(prefix="pv_filepath_")
+    try:
+        contig_len = int(mbp * 1_000_000)
+        bam, fa, info = make_files(d, contig_len)
+        P = PRESETS["ont_r9_guppy5_sup"]
+        # warm the page cache and the workspaces with a small region (untimed)
+        make_images.generate_images(ctx, bam, fa, os.path.join(d, "warm"), P, region="chr20:0-50000", min_mapq=5)
+        t_img = {}
+        n = make_images.generate_images(ctx, bam, fa, os.path.join(d, "images"), P, min_mapq=5, timers=t_img)
+        t_inf = {}
+        files = [os.path.join(d, "images", f) for f in sorted(os.listdir(os.path.join(d, "images"))) if f.endswith(".hdf5")]
+        os.makedirs(os.path.join(d, "pred"), exist_ok=True)
+        n2 = run_inference.predict_files(ctx, weights, files, os.path.join(d, "pred", "pepper_prediction.hdf"), 512, 16, timers=t_inf)
+        assert n2 == n, (n, n2)
+        swept = contig_len / 1e6
+        wall = t_img["wall_s"] + t_inf["wall_s"]
+        gpu_calls = t_img["builder_call_s"] + t_inf["predict_call_s"]
+        return {
+            "workload": "synthetic chr20 of %.2f Mbp at 60x (10 kb reads): %d reads, %.1f M bases, BAM %.1f MB; %d intervals of 100 kb"
+                        % (swept, info["reads"], info["bases"] / 1e6, info["bam_bytes"] / 1e6, t_img["intervals"]),
+            "windows": n, "mbp_per_s": swept / wall, "windows_per_s": n / wall,
+            "make_images": {"wall_s": t_img["wall_s"], "mbp_per_s": swept / t_img["wall_s"], "reader_threads": t_img["reader_threads"],
+                            "bgzf_inflate_cpu_s": t_img["read_inflate_cpu_s"], "record_decode_clip_cpu_s": t_img["read_decode_cpu_s"],
+                            "inflate_MBps_per_thread": t_img["bytes_inflated"] / max(t_img["read_inflate_cpu_s"], 1e-9) / 1e6,
+                            "main_thread_waiting_for_readers_s": t_img["reader_stall_s"],
+                            "builder_call_s(h2d+kernels+d2h)": t_img["builder_call_s"], "hdf5_write_s": t_img["hdf5_write_s"]},
+            "run_inference": {"wall_s": t_inf["wall_s"], "windows_per_s": n / t_inf["wall_s"], "hdf5_read_s": t_inf["hdf5_read_s"],
+                              "predict_call_s(h2d+kernels+d2h)": t_inf["predict_call_s"], "hdf5_write_s": t_inf["hdf5_write_s"],
+                              "load_weights_s": t_inf["load_weights_s"]},
+            "host_share": 1.0 - gpu_calls / wall,
+            "note": "host share = 1 - (time inside the builder and RNN calls, PCIe copies included) / wall; the readers inflate BGZF on "
+                    "%d threads ahead of the GPU" % t_img["reader_threads"],
+        }
+    finally:
+        if keep_dir is None:
+            shutil.rmtree(d, ignore_errors=True)
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--mbp", type=float, default=1.0)
+    a = ap.parse_args()
+    from pepper_thesis_amd import runtime, synth
+    c = runtime.Context(0)
+    print(json.dumps(run(c, synth.make_weights_p1(1234), mbp=a.mbp), indent=1))
