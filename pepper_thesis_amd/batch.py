@@ -165,6 +165,32 @@ def pack_regions(regions: Sequence[Region]) -> RegionBatch:
                        read_mapq, base_off, bases, quals, cigar_off, cigar, [r.contig for r in regions])
 
 
+def merge_batches(batches: Sequence[RegionBatch]) -> RegionBatch:
+    """concatenate region batches (regions keep their order): array concatenation plus offset fix-ups, no per-read work"""
+    batches = [b for b in batches if b.n_regions]
+    if len(batches) == 1:
+        return batches[0]
+    if not batches:
+        return pack_regions([])
+
+    def cat(f):
+        return np.concatenate([getattr(b, f) for b in batches])
+
+    def cat_off(f, totals):
+        parts, base = [np.zeros(1, np.int64)], 0
+        for b, t in zip(batches, totals):
+            parts.append(getattr(b, f)[1:] + base)
+            base += t
+        return np.concatenate(parts)
+
+    return RegionBatch(
+        sum(b.n_regions for b in batches), cat("ref_start"), cat("ref_end"), cat("cand_start"), cat("cand_end"),
+        cat_off("ref_off", [int(b.ref.shape[0]) for b in batches]), cat("ref"),
+        cat_off("read_off", [b.n_reads for b in batches]), cat("read_pos"), cat("read_flags"), cat("read_mapq"),
+        cat_off("base_off", [b.n_bases for b in batches]), cat("bases"), cat("quals"),
+        cat_off("cigar_off", [b.n_cigar for b in batches]), cat("cigar"), [c for b in batches for c in b.contigs])
+
+
 @dataclass
 class Params:
     """The per-platform generate_summary scalars (SetParameters.py:12-283)."""

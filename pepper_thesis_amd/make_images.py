@@ -97,14 +97,15 @@ def list_intervals(fasta, bam, region: str = None, region_size: int = 100_000) -
 def generate_images(ctx, bam_path: str, fasta_path: str, output_dir: str, params: Params, region: str = None,
                     region_size: int = 100_000, min_mapq: int = 5, include_supplementary: bool = False,
                     downsample_rate: float = 1.0, intervals_per_call: int = 16, rank: int = 0, world: int = 1,
-                    reader_threads: int = None, timers: dict = None) -> int:
+                    reader_threads: int = None, timers: dict = None, intervals_per_read: int = 1) -> int:
     """generate_images (ImageGenerationUI.py:277-345) on the MI355X path: intervals of region_size, interval i handled
     by rank i % world (:211), `intervals_per_call` intervals per builder launch chain, one HDF5 file per rank.
 
     The reference gives every worker PROCESS its own BAM/FASTA handles and lets it fetch, summarise and write one interval
     at a time (:222-260). Here `reader_threads` threads (default: the CPU share, at most 16) each own a handle pair and fill
-    whole batches of intervals straight into the flat pv_batch_in arrays in native code (bamio.fill_batch, GIL released),
-    running ahead of the GPU; the calling thread only hands finished batches to the builder and writes the HDF5 groups.
+    `intervals_per_read` intervals at a time straight into the flat pv_batch_in arrays in native code (bamio.fill_batch, GIL
+    released), running ahead of the GPU; the calling thread merges `intervals_per_call` of them per builder launch chain
+    (array concatenation), hands them to the builder and writes the HDF5 groups.
     `timers` (optional dict) receives the stage times in seconds."""
     import os
     import threading
@@ -112,12 +113,15 @@ def generate_images(ctx, bam_path: str, fasta_path: str, output_dir: str, params
     from collections import deque
     from concurrent.futures import ThreadPoolExecutor
     from .bamio import BamHandler, FastaHandler, fill_batch
+    from .batch import merge_batches
     from .hdf5io import ImageStore
     t_start = time.perf_counter()
     bam, fasta = BamHandler(bam_path), FastaHandler(fasta_path)
     todo = list_intervals(fasta, bam, region, region_size)
     mine = [iv for i, iv in enumerate(todo) if i % world == rank]
-    groups = [mine[k:k + intervals_per_call] for k in range(0, len(mine), intervals_per_call)]
+    ipr = max(1, min(int(intervals_per_read), int(intervals_per_call)))
+    groups = [mine[k:k + ipr] for k in range(0, len(mine), ipr)]
+    reads_per_call = max(1, int(intervals_per_call) // ipr)
     n_thr = max(1, min(int(reader_threads or min(16, len(os.sched_getaffinity(0)))), max(len(groups), 1)))
     tls = threading.local()
 
@@ -127,37 +131,46 @@ def generate_images(ctx, bam_path: str, fasta_path: str, output_dir: str, params
         return fill_batch(tls.h[0], tls.h[1], ivs, min_mapq, include_supplementary, downsample_rate, REGION_SAFE_BASES)
 
     os.makedirs(output_dir, exist_ok=True)
-    T = dict(read_inflate_cpu_s=0.0, read_decode_cpu_s=0.0, reader_stall_s=0.0, builder_call_s=0.0, hdf5_write_s=0.0,
+    T = dict(read_inflate_cpu_s=0.0, read_decode_cpu_s=0.0, reader_stall_s=0.0, merge_s=0.0, builder_call_s=0.0, hdf5_write_s=0.0,
              bytes_inflated=0, reader_threads=n_thr, intervals=len(mine), bases=0, reads=0)
     n_windows = 0
     with ImageStore(os.path.join(output_dir, "pepper_variants_images_thread_%d.hdf5" % rank), "w") as store, \
             ThreadPoolExecutor(n_thr) as pool:
         pending = deque()
         nxt = 0
-        while nxt < len(groups) and len(pending) < n_thr + 2:      # readers run this many batches ahead of the GPU
+        ahead = reads_per_call + n_thr + 2                           # reads in flight: one builder call's worth + the pool
+        while nxt < len(groups) and len(pending) < ahead:
             pending.append(pool.submit(read_group, groups[nxt]))
             nxt += 1
         while pending:
+            fbs = []
             t0 = time.perf_counter()
-            fb = pending.popleft().result()
+            while pending and len(fbs) < reads_per_call:
+                fbs.append(pending.popleft().result())
+                if nxt < len(groups):
+                    pending.append(pool.submit(read_group, groups[nxt]))
+                    nxt += 1
             T["reader_stall_s"] += time.perf_counter() - t0
-            if nxt < len(groups):
-                pending.append(pool.submit(read_group, groups[nxt]))
-                nxt += 1
-            T["read_inflate_cpu_s"] += fb.t_inflate
-            T["read_decode_cpu_s"] += fb.t_total - fb.t_inflate
-            T["bytes_inflated"] += fb.bytes_inflated
-            if fb.batch.n_regions == 0:                              # "no group when no reads" (AlignmentSummarizer.py:212-213)
-                fb.close()
-                continue
-            T["bases"] += fb.batch.n_bases
-            T["reads"] += fb.batch.n_reads
+            names = []                                               # interval of every batch region, in batch order
+            for fb in fbs:
+                T["read_inflate_cpu_s"] += fb.t_inflate
+                T["read_decode_cpu_s"] += fb.t_total - fb.t_inflate
+                T["bytes_inflated"] += fb.bytes_inflated
+                names += [fb.intervals[int(i)] for i in fb.interval_index]
             t0 = time.perf_counter()
-            out = ctx.summarize(fb.batch, params)
+            batch = merge_batches([fb.batch for fb in fbs])
+            T["merge_s"] += time.perf_counter() - t0
+            if batch.n_regions == 0:                                 # "no group when no reads" (AlignmentSummarizer.py:212-213)
+                for fb in fbs:
+                    fb.close()
+                continue
+            T["bases"] += batch.n_bases
+            T["reads"] += batch.n_reads
+            t0 = time.perf_counter()
+            out = ctx.summarize(batch, params)
             T["builder_call_s"] += time.perf_counter() - t0
             t0 = time.perf_counter()
-            for g in range(fb.batch.n_regions):
-                contig, start, end = fb.intervals[int(fb.interval_index[g])]
+            for g, (contig, start, end) in enumerate(names):
                 sel = np.flatnonzero(out.region == g)
                 # an interval with reads but no candidate still gets its (empty) group, as the reference's write_summary
                 # of empty lists does (ImageGenerationUI.py:228-259)
@@ -165,7 +178,9 @@ def generate_images(ctx, bam_path: str, fasta_path: str, output_dir: str, params
                                     [[out.candidates[j]] for j in sel], out.cand_freq[sel].reshape(-1, 1), out.images[sel])
             T["hdf5_write_s"] += time.perf_counter() - t0
             n_windows += len(out)
-            fb.close()
+            del batch
+            for fb in fbs:
+                fb.close()
     T["wall_s"] = time.perf_counter() - t_start
     T["windows"] = n_windows
     if timers is not None:

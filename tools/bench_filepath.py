@@ -77,7 +77,7 @@ def run(ctx, weights, dev=None, mbp=1.0, keep_dir=None):
                             "bgzf_inflate_cpu_s": t_img["read_inflate_cpu_s"], "record_decode_clip_cpu_s": t_img["read_decode_cpu_s"],
                             "inflate_MBps_per_thread": t_img["bytes_inflated"] / max(t_img["read_inflate_cpu_s"], 1e-9) / 1e6,
                             "main_thread_waiting_for_readers_s": t_img["reader_stall_s"],
-                            "builder_call_s(h2d+kernels+d2h)": t_img["builder_call_s"], "hdf5_write_s": t_img["hdf5_write_s"]},
+                            "merge_s": t_img["merge_s"], "builder_call_s(h2d+kernels+d2h)": t_img["builder_call_s"], "hdf5_write_s": t_img["hdf5_write_s"]},
             "run_inference": {"wall_s": t_inf["wall_s"], "windows_per_s": n / t_inf["wall_s"], "hdf5_read_s": t_inf["hdf5_read_s"],
                               "predict_call_s(h2d+kernels+d2h)": t_inf["predict_call_s"], "hdf5_write_s": t_inf["hdf5_write_s"],
                               "load_weights_s": t_inf["load_weights_s"]},
