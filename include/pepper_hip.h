@@ -249,6 +249,13 @@ int pv_rnn_forward_p2_dev(pv_ctx* ctx, const uint8_t* d_images, int64_t B, uint8
 int pv_rnn_forward_p2_window(pv_ctx* ctx, const uint8_t* images, const float* hidden_in, int64_t B, float* logits,
                              float* hidden_out);
 
+/* Diagnostic (tests, tuning): C = A . W^T + bias through the 3-term split-bf16 MFMA GEMM of PV_DTYPE_BF16_INPUT_GEMM alone.
+ * HOST pointers, fp32 row-major A [M,K], W [N,K], bias [N] or NULL; C [splits][M][N] row-major (quads = 0) or [M/4][N][4]
+ * (quads = 1: four consecutive rows of a column adjacent, splits = 1). M % 4 == 0, N % 256 == 0, K % (32 * splits) == 0.
+ * *ms (optional) receives the kernel's duration. Has no counterpart in the reference. */
+int pv_debug_gemm_bf16x3(pv_ctx* ctx, const float* A, const float* W, const float* bias, int64_t M, int N, int K,
+                         int splits, int quads, float* C, float* ms);
+
 /* Per-kernel timing for the benchmark's roofline leg: between pv_profile_begin and pv_profile_end every
  * kernel the context launches is bracketed by HIP events on its launch stream. pv_profile_end
  * synchronises the device and returns the number of distinct kernels; names_buf receives their names

@@ -134,7 +134,36 @@ struct GruArgs {
     const float* hidden_in; // [B,2,128] or NULL (zeros)
     float* hidden_out;      // [B,2,128] or NULL
     float* logits;          // [B,100,5] raw dense1 output of the LAST window, or NULL
+    int* pair_flags;        // split form only: [n_tiles][2] hand-off counters of the two direction workgroups of a tile (zeroed per launch)
 };
+
+// ---- the two directions of a tile on two CUs (small batches) -----------------------------------------------------------
+// A launch is a chain of 3800 dependent steps whose duration is the per-step time of ONE workgroup. With both directions
+// in one workgroup every SIMD carries a forward and a reverse wave, i.e. twice the MFMA cycles per step. In the SPLIT
+// form a workgroup is (tile, direction), 4 waves, one per SIMD; the directions meet only where the model joins them: the
+// decoder reads both halves of the encoder output of its window, and dense1 + softmax read both halves of the decoder
+// output - two hand-offs per 100-column window (38 per launch), each a release/acquire pair at agent scope through a
+// monotonic counter per workgroup (MI355X_MICROARCH.md, inter-workgroup visibility): every wave drains its stores, the
+// workgroup's barrier, one lane publishes (release fence, drained, then the relaxed counter store) and polls the partner's
+// counter with relaxed loads, one acquire fence, barrier. Used only while both workgroups of every tile are resident at
+// once (grid <= CUs, one workgroup per CU), so a poll can never wait for a workgroup that has not been dispatched.
+__device__ __forceinline__ void pair_handoff(int* mine, const int* theirs, int value, int tid) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's stores have left
+    __syncthreads();
+    if (tid == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // ROCm 7.2 can drop the fence's own wait: keep this one, before the flag
+        __hip_atomic_store(mine, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        int spins = 0;
+        while (__hip_atomic_load(theirs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < value) {
+            __builtin_amdgcn_s_sleep(2);
+            if (++spins > (1 << 26)) break;   // bounded: a lost partner ends in wrong results, never in a hung device
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __syncthreads();
+}
 
 // one GRU layer over one 100-column window for this wave's direction.
 // Addressing: every global access is a raw buffer access (wave-uniform resource + 32-bit lane offset computed once +
@@ -236,16 +265,20 @@ __device__ __forceinline__ void gru_window(const GruArgs& a, int win_start, int 
     }
 }
 
-template <int TR>
-__global__ __launch_bounds__(512, 2) void k_gru_p2(GruArgs a) {
+template <int TR, bool SPLIT>
+__global__ __launch_bounds__(SPLIT ? 256 : 512, SPLIT ? 1 : 2) void k_gru_p2(GruArgs a) {
     extern __shared__ float smem[];
     // per direction: hbuf [2][TR][LDH], xbuf [TR][LDXD]
+    constexpr int NTHR = SPLIT ? 256 : 512;
     const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);  // SGPR: bases derived from it stay scalar
-    const int dir = wv >> 2, wq = wv & 3, tid_dir = tid & 255;
+    const int dir = SPLIT ? (int)(blockIdx.x & 1) : (wv >> 2), wq = wv & 3, tid_dir = tid & 255;
     constexpr int NE = TR / 2;
-    float* hbuf = smem + dir * (2 * TR * LDH + TR * LDXD);
+    float* hbuf = smem + (SPLIT ? 0 : dir) * (2 * TR * LDH + TR * LDXD);
     float* xbuf = hbuf + 2 * TR * LDH;
-    const int tile = blockIdx.x;
+    const int tile = SPLIT ? (int)(blockIdx.x >> 1) : (int)blockIdx.x;
+    int* my_flag = SPLIT ? a.pair_flags + 2 * tile + dir : nullptr;
+    const int* their_flag = SPLIT ? a.pair_flags + 2 * tile + (dir ^ 1) : nullptr;
+    int handoffs = 0;
     const int64_t b0 = (int64_t)tile * TR;
     float* enc_out = a.enc_out + (size_t)tile * WIN * TR * KPD;
     float* dec_out = a.dec_out + (size_t)tile * WIN * TR * KPD;
@@ -277,13 +310,17 @@ __global__ __launch_bounds__(512, 2) void k_gru_p2(GruArgs a) {
     for (int w = 0; w < a.nwin; w++) {
         const int ws = w * JUMP;
         gru_window<TR, KPE, true>(a, ws, dir, wq, lane, tid_dir, b0, xbuf, hbuf, cur, hst, enc_wp, enc_bias, nullptr, enc_out);
+        if constexpr (SPLIT) pair_handoff(my_flag, their_flag, ++handoffs, tid);   // both halves of the encoder output are there
         // decoder h0 = encoder final state of the same direction: hst / hbuf[cur] simply carry over
         gru_window<TR, KPD, false>(a, ws, dir, wq, lane, tid_dir, b0, xbuf, hbuf, cur, hst, dec_wp, dec_bias, enc_out, dec_out);
-        // dense1 + softmax + accumulate over the window (predict.py:70-89); TR*100 (row, t) pairs
-        for (int p = tid; p < TR * WIN; p += 512) {
+        if constexpr (SPLIT) pair_handoff(my_flag, their_flag, ++handoffs, tid);   // both halves of the decoder output; the partner is
+                                                                                    // done reading the encoder output as well
+        // dense1 + softmax + accumulate over the window (predict.py:70-89); TR*100 (row, t) pairs. Split form: the workgroup of
+        // direction d owns the columns of parity d (ws is even), for acc, logits and labels alike, so no column is shared.
+        for (int p = tid; p < TR * WIN; p += NTHR) {
             const int t = p / TR, row = p - t * TR;
             const int64_t b = b0 + row;
-            if (b >= a.B) continue;
+            if (b >= a.B || (SPLIT && (t & 1) != dir)) continue;
             const float* d = dec_out + ((size_t)t * TR + row) * KPD;
             float lg[NCLS];
 #pragma unroll
@@ -321,10 +358,10 @@ __global__ __launch_bounds__(512, 2) void k_gru_p2(GruArgs a) {
         }
     }
     // labels = argmax over the 5 classes, first maximum wins (torch.max, predict.py:91)
-    for (int p = tid; a.labels && p < TR * a.seq; p += 512) {
+    for (int p = tid; a.labels && p < TR * a.seq; p += NTHR) {
         const int row = p / a.seq, pos = p - row * a.seq;
         const int64_t b = b0 + row;
-        if (b >= a.B) continue;
+        if (b >= a.B || (SPLIT && (pos & 1) != dir)) continue;
         const float* ac = a.acc + ((size_t)b * a.seq + pos) * NCLS;
         int best = 0;
         float bv = ac[0];
@@ -370,7 +407,7 @@ void pack_gru(const pv_rnn_dir* dirs, int K, int KP, int TR, std::vector<float>&
     }
 }
 
-template <int TR> constexpr size_t lds_p2() { return (size_t)2 * (2 * TR * LDH + TR * LDXD) * sizeof(float); }
+template <int TR, bool SPLIT> constexpr size_t lds_p2() { return (size_t)(SPLIT ? 1 : 2) * (2 * TR * LDH + TR * LDXD) * sizeof(float); }
 
 }  // namespace
 
@@ -423,8 +460,9 @@ extern "C" int pv_rnn_load_p2(pv_ctx* ctx, const pv_weights_p2* w, int dtype) {
         if (!f && (rc = up2(bias.data(), bias.size(), &m->dec_bias, m->owned))) return rc;
     }
     if ((rc = up2(w->dense_w, (size_t)NCLS * KPD, &m->dense_w, m->owned)) || (rc = up2(w->dense_b, NCLS, &m->dense_b, m->owned))) return rc;
-    PV_HIP(hipFuncSetAttribute((const void*)k_gru_p2<32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_p2<32>()));
-    PV_HIP(hipFuncSetAttribute((const void*)k_gru_p2<16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_p2<16>()));
+    PV_HIP(hipFuncSetAttribute((const void*)k_gru_p2<32, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_p2<32, false>()));
+    PV_HIP(hipFuncSetAttribute((const void*)k_gru_p2<16, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_p2<16, false>()));
+    PV_HIP(hipFuncSetAttribute((const void*)k_gru_p2<16, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_p2<16, true>()));
     return PV_OK;
 }
 
@@ -451,10 +489,20 @@ static int p2_launch(pv_ctx* ctx, const uint8_t* d_images, int64_t B, uint8_t* d
     g.B = B;
     g.seq = seq; g.nwin = nwin; g.hidden_in = d_hidden_in; g.hidden_out = d_hidden_out; g.logits = d_logits;
     PV_HIP(hipMemsetAsync(g.acc, 0, (size_t)B * seq * NCLS * sizeof(float), st));
+    // the two directions of a tile on two CUs while every (tile, direction) workgroup has a CU of its own: the launch is a
+    // chain of dependent steps, and a step then carries one direction's MFMAs per SIMD instead of two
+    bool split = tr == 16 && 2 * n_tiles <= ctx->num_cu;
+    if (const char* e = getenv("PV_GRU_SPLIT")) split = split && atoi(e) != 0;
+    g.pair_flags = nullptr;
+    if (split) {
+        if ((rc = pv_get(ctx, "p2.pair_flags", (size_t)2 * n_tiles, &g.pair_flags))) return rc;
+        PV_HIP(hipMemsetAsync(g.pair_flags, 0, (size_t)2 * n_tiles * sizeof(int), st));
+    }
     {
         pv_prof_scope ps(ctx, "k_gru_p2", st);
-        if (tr == 32) k_gru_p2<32><<<(unsigned)n_tiles, 512, lds_p2<32>(), st>>>(g);
-        else k_gru_p2<16><<<(unsigned)n_tiles, 512, lds_p2<16>(), st>>>(g);
+        if (tr == 32) k_gru_p2<32, false><<<(unsigned)n_tiles, 512, lds_p2<32, false>(), st>>>(g);
+        else if (split) k_gru_p2<16, true><<<(unsigned)(2 * n_tiles), 256, lds_p2<16, true>(), st>>>(g);
+        else k_gru_p2<16, false><<<(unsigned)n_tiles, 512, lds_p2<16, false>(), st>>>(g);
     }
     PV_HIP(hipGetLastError());
     return PV_OK;

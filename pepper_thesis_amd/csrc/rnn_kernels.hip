@@ -22,6 +22,7 @@
 #include "pv_common.hpp"
 #include "mfma_tiles.hpp"
 
+#include <algorithm>
 #include <cmath>
 #include <cstdlib>
 
@@ -51,6 +52,19 @@ __device__ __forceinline__ float tanhf_(float x) {
 __device__ __forceinline__ float seluf_(float x) {
     return 1.0507009873554805f * (x > 0.0f ? x : 1.6732632423543772f * (__expf(x) - 1.0f));
 }
+
+// Operand format of the bf16x3 GEMMs ("split8"): every 8 consecutive K elements of a row are stored as 32 bytes,
+// 8 x bf16 hi followed by 8 x bf16 lo, with x ~= hi + lo, hi = bf16(x), lo = bf16(x - hi) (round to nearest even twice).
+// One 16-byte half of a group is exactly one MFMA A/B fragment of v_mfma_f32_32x32x16_bf16, so the GEMM moves operands
+// from HBM to LDS by LDS-DMA without touching a register. Byte offset of element k inside a row: (k >> 3) * 32 + (k & 7) * 2
+// (+16 for lo).
+__device__ __forceinline__ void split8_store(float x, __amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+    const __bf16 hi = (__bf16)x;
+    const __bf16 lo = (__bf16)(x - (float)hi);
+    __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(unsigned short, hi), r, voff, soff, 0);
+    __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(unsigned short, lo), r, voff, soff + 16u, 0);
+}
+__device__ __forceinline__ unsigned split8_off(unsigned k) { return (k >> 3) * 32u + (k & 7u) * 2u; }
 
 // ---- weight-fragment rings ------------------------------------------------------------------------------------------
 // The B operand (packed weights, one f32x4 per lane per gate tile per k-block of 8) comes from L2, ~1 us away, while a
@@ -153,9 +167,9 @@ struct LstmArgs {
     const float* x_f32;   // [Bp,33,512]  (decoder; padded to whole 32-row tiles)
     const float* wp;      // packed [2 dirs][8 waves][nkb][4 gates][64][4] in the tile form of the launch
     const float* bias;    // [2][1024] b_ih + b_hh
-    float* out;           // [Bp,33,512]
-    float* out_cm;        // optional chunk-major copy [512/32][Bp*33][32] (A operand of the bf16x3 decoder GEMM)
-    int64_t cm_rows;      // Bp*33
+    float* out;           // [Bp,33,512] fp32 (may be NULL when out_split is given)
+    unsigned char* out_split;  // optional split8 rows, TIME-MAJOR [33][Bp][512]: A operand of the bf16x3 decoder GEMM
+    int64_t Bp;           // rows of a time slab of out_split
     int64_t B;
     int n_tiles;          // tiles of TR rows
 };
@@ -212,6 +226,7 @@ __global__ __launch_bounds__(512, 2) void k_lstm_layer(LstmArgs a) {
     // (tile resource) + (lane offset, computed once) + (scalar offset of row group u and step t)
     const __amdgpu_buffer_rsrc_t xsr = make_rsrc(INT8 ? (const void*)a.wp : (const void*)(a.x_f32 + (size_t)b0 * T_STEPS * KP));
     const __amdgpu_buffer_rsrc_t osr = make_rsrc(a.out + (size_t)b0 * T_STEPS * 2 * H);
+    const __amdgpu_buffer_rsrc_t ssr = make_rsrc(a.out_split + (size_t)b0 * 2 * H * 4);
     const unsigned xg_l = (unsigned)(((tid / V4) * T_STEPS * KP + (tid % V4) * 4) * 4);
     const unsigned xl_l = (unsigned)((tid / V4) * LDX + (tid % V4) * 4);
     const unsigned xe_l = (unsigned)((tid >> 5) * LDX + (tid & 31));
@@ -247,6 +262,7 @@ __global__ __launch_bounds__(512, 2) void k_lstm_layer(LstmArgs a) {
     };
     const unsigned h_l = (unsigned)(lane_row<TR>(lane) * LDH + unit0);                      // lane part of the h tile offset
     const unsigned og_l = (unsigned)((lane_row<TR>(lane) * T_STEPS * 2 * H + unit0) * 4);   // lane part of the output byte offset
+    const unsigned sg_l = (unsigned)(lane_row<TR>(lane) * 2 * H * 4) + split8_off((unsigned)unit0);  // same for the split8 rows (unit0 + 16 adds two groups)
     x_load(dir ? T_STEPS - 1 : 0);
     x_store();
     __syncthreads();
@@ -277,12 +293,10 @@ __global__ __launch_bounds__(512, 2) void k_lstm_layer(LstmArgs a) {
             const float h = og * tanhf_(c);
             (hn + elem_row<TR>(e) * LDH + elem_unit<TR>(e))[h_l] = h;
             // outputs are padded to whole tiles: unconditional stores, tile resource + lane offset + scalar offset
-            PV_OSTORE(h, osr, og_l, (unsigned)((t * 2 * H + dir * H + elem_row<TR>(e) * T_STEPS * 2 * H + elem_unit<TR>(e)) * 4));
-            if (a.out_cm) {
-                const int row = lane_row<TR>(lane) + elem_row<TR>(e);
-                const unsigned col = dir * H + unit0 + elem_unit<TR>(e);
-                a.out_cm[((size_t)(col >> 5) * a.cm_rows + (size_t)(b0 + row) * T_STEPS + t) * 32 + (col & 31)] = h;
-            }
+            const unsigned o_s = (unsigned)((t * 2 * H + dir * H + elem_row<TR>(e) * T_STEPS * 2 * H + elem_unit<TR>(e)) * 4);
+            if (a.out) PV_OSTORE(h, osr, og_l, o_s);
+            if (a.out_split)   // row (t, b), element dir*H + unit
+                split8_store(h, ssr, sg_l, (unsigned)(((size_t)t * a.Bp + elem_row<TR>(e)) * 2 * H * 4 + split8_off(dir * H + elem_unit<TR>(e))));
         }
         __syncthreads();  // everyone is done reading xbuf / hbuf[cur]; hbuf[nxt] is complete
         if (s + 1 < T_STEPS) {
@@ -466,124 +480,218 @@ __global__ __launch_bounds__(256, 1) void k_head_tail(TailArgs a) {
 // G[b,t,:] = W_ih . enc_out[b,t,:] + b (both directions, N = 2048, K = 512) and for linear_1 (N = 512, K = 16896);
 // the recurrent h-part, the cell update and linear_2..5 stay fp32.
 struct GemmArgs {
-    const float* Ac;      // activations fp32, CHUNK-MAJOR [K/32][M][32]: one BK slice of a row tile is 16 KB contiguous
-    const __bf16* Wh;     // weights bf16 hi, chunk-major [K/32][N][32]
-    const __bf16* Wl;     // weights bf16 lo, chunk-major
+    const unsigned char* A;  // activations, split8 rows of K*4 bytes, [M][K]
+    const unsigned char* W;  // weights, split8 rows, [N][K]
     const float* bias;    // [N] or NULL
-    float* C;             // [splits][M, N]
+    float* C;             // [splits][M][N] row-major, or (c_quads) [M/4][N][4]: four consecutive rows of a column adjacent
     int64_t M;
     int N, K, splits;
+    int tiles_m, tiles_n; // 256 x 256 output tiles
+    int items;            // tiles_m * tiles_n * splits work items, walked by persistent workgroups
+    int c_quads;
 };
 
-// C tile 128 x 128 per workgroup (4 waves as 2 x 2, 64 x 64 each), BK = 32, double-buffered LDS, register staging.
-__global__ __launch_bounds__(256, 2) void k_gemm_bf16x3(GemmArgs g) {
-    constexpr int BM = 128, BN = 128, BK = 32, LD = 40;  // LD: bf16 elements per LDS row (80 B: conflict-free b128 reads)
-    extern __shared__ __bf16 sm16[];
-    __bf16* sAh = sm16;                    // [2][BM*LD]
-    __bf16* sAl = sAh + 2 * BM * LD;
-    __bf16* sBh = sAl + 2 * BM * LD;       // [2][BN*LD]
-    __bf16* sBl = sBh + 2 * BN * LD;
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, wr = wv >> 1, wc = wv & 1;
-    const int n_tiles_n = g.N / BN;
-    const int64_t mt = blockIdx.x / n_tiles_n;
-    const int nt_ = blockIdx.x - (int)(mt * n_tiles_n);
-    const int64_t m0 = mt * BM;
-    const int n0 = nt_ * BN;
-    const int kslice = g.K / g.splits;
-    const int kbeg = blockIdx.y * kslice;
-    f32x16 acc[2][2];
+// C = A . W^T (+ bias) with 3-term split-bf16 products (a_hi.w_hi + a_hi.w_lo + a_lo.w_hi) on v_mfma_f32_32x32x16_bf16.
+// Persistent workgroups (one per CU, 8 waves as 2 x 4, 128 x 64 outputs per wave = 8 accumulator tiles of 32 x 32) walk
+// 256 x 256 output tiles; K in steps of 32. Per K step a workgroup moves 64 KB ({A,W} x {hi,lo} x 256 rows x 64 B) from
+// L2/HBM straight into LDS with 64 LDS-DMA wave-instructions (buffer_load_dwordx4 ... lds, 8 per wave, no registers, no
+// ds_write): the transfers of step k+1 run during step k's MFMAs into the other half of a double-buffered image. An LDS-DMA
+// lands lane-linear (wave base + 16 B per lane), so the XOR swizzle that makes the fragment ds_read_b128 conflict-free
+// (16-byte chunk index ^ ((row >> 2) & 3) inside each 64-byte row) is applied on the SOURCE address of every lane. One
+// barrier per K step; per step and wave 24 ds_read_b128 feed 48 MFMAs. Work items are ordered n-tile fastest and dealt to the
+// XCDs in groups of one XCD's workgroups, so the CUs of an XCD work on the same few A row tiles at the same time. The next
+// item's first K step is requested BEFORE the epilogue stores (32 dwordx4 stores per wave in the quad layout): its DMAs are
+// older than the stores in the in-order vmcnt queue, a counted wait retires them and the stores drain behind the next
+// tile's first MFMAs.
+__global__ __launch_bounds__(512, 2) void k_gemm_bf16x3(GemmArgs g) {
+    constexpr int BM = 256, BN = 256, BK = 32;
+    constexpr int ARR = BM * BK * 2;          // bytes of one bf16 operand image (16 KB); buffer = [A_hi | A_lo | W_hi | W_lo]
+    extern __shared__ __attribute__((aligned(16))) unsigned char smg[];
+    const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wv >> 2, wc = wv & 3;
+    // DMA role: piece p (0, 1) of this wave covers rows 16 * (8p + wv) .. + 15 of an operand image; lane -> row lane >> 2,
+    // destination chunk lane & 3, source chunk (lane & 3) ^ ((lane >> 4) & 3) (= ((row >> 2) & 3) swizzle)
+    const int d_row = lane >> 2;
+    const unsigned d_chunk = (unsigned)((lane & 3) ^ ((lane >> 4) & 3));
+    // fragment role
+    const unsigned f_swz = (unsigned)(((lane & 31) >> 2) & 3);
+    const unsigned fa_l = (unsigned)((128 * wr + (lane & 31)) * 64);
+    const unsigned fb_l = (unsigned)(2 * ARR + (64 * wc + (lane & 31)) * 64);
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, per_xcd = gridDim.x >> 3;
+    const int kslice = g.K / g.splits, nk = kslice / BK;
+    const unsigned row_bytes = (unsigned)g.K * 4u;
+
+    __amdgpu_buffer_rsrc_t ra, rw;
+    unsigned la[2], lw[2];
+    auto item_coords = [&](int it, int& mt, int& nt, int& sp) {
+        nt = it % g.tiles_n;
+        const int r = it / g.tiles_n;
+        sp = r % g.splits;
+        mt = r / g.splits;
+    };
+    auto item_setup = [&](int mt, int nt, int sp) {
+        const int64_t m0 = (int64_t)mt * BM;
+        const int n0 = nt * BN;
+        ra = make_rsrc(g.A + ((size_t)m0 * g.K + (size_t)sp * kslice) * 4);
+        rw = make_rsrc(g.W + ((size_t)n0 * g.K + (size_t)sp * kslice) * 4);
 #pragma unroll
-    for (int a = 0; a < 2; a++)
-#pragma unroll
-        for (int b = 0; b < 2; b++)
-#pragma unroll
-            for (int r = 0; r < 16; r++) acc[a][b][r] = 0.0f;
-    f32x4 ra[4];  // 16 fp32 activations
-    f32x4 rb[4];  // 4 x 8 bf16 weights (hi, hi, lo, lo segments)
-    auto g_load = [&](int k0) {
-        const int kc = k0 >> 5;
-#pragma unroll
-        for (int u = 0; u < 4; u++) {
-            const int idx = tid + u * 256, row = idx >> 3, c4 = idx & 7;
-            int64_t m = m0 + row;
-            if (m >= g.M) m = g.M - 1;
-            ra[u] = *reinterpret_cast<const f32x4*>(g.Ac + ((size_t)kc * g.M + m) * 32 + c4 * 4);
-            const int arr = idx >> 9, sidx = idx & 511, brow = sidx >> 2, c8 = sidx & 3;
-            rb[u] = *reinterpret_cast<const f32x4*>((arr ? g.Wl : g.Wh) + ((size_t)kc * g.N + n0 + brow) * 32 + c8 * 8);
+        for (int p = 0; p < 2; p++) {
+            int64_t r = 16 * (8 * p + wv) + d_row;
+            if (m0 + r >= g.M) r = g.M - 1 - m0;             // rows beyond M replicate the last row (never stored)
+            la[p] = (unsigned)r * row_bytes + d_chunk * 32u;
+            int rn = 16 * (8 * p + wv) + d_row;
+            if (n0 + rn >= g.N) rn = g.N - 1 - n0;
+            lw[p] = (unsigned)rn * row_bytes + d_chunk * 32u;
         }
     };
-    auto s_store = [&](int buf) {
+    // 8 LDS-DMA pieces of this wave for K step kt into buffer buf
+    auto dma = [&](int kt, int buf) {
+        typedef __attribute__((address_space(3))) void* lds_ptr;
+        unsigned char* base = smg + buf * 4 * ARR + wv * 1024;
+        const unsigned so = (unsigned)(kt * BK * 4);
 #pragma unroll
-        for (int u = 0; u < 4; u++) {
-            const int idx = tid + u * 256, row = idx >> 3, c4 = idx & 7;
-            bf16x4 hi, lo;
-#pragma unroll
-            for (int j = 0; j < 4; j++) {
-                hi[j] = (__bf16)ra[u][j];
-                lo[j] = (__bf16)(ra[u][j] - (float)hi[j]);
-            }
-            *reinterpret_cast<bf16x4*>(sAh + buf * BM * LD + row * LD + c4 * 4) = hi;
-            *reinterpret_cast<bf16x4*>(sAl + buf * BM * LD + row * LD + c4 * 4) = lo;
-            const int arr = idx >> 9, sidx = idx & 511, brow = sidx >> 2, c8 = sidx & 3;
-            *reinterpret_cast<f32x4*>((arr ? sBl : sBh) + buf * BN * LD + brow * LD + c8 * 8) = rb[u];
+        for (int p = 0; p < 2; p++) {
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_ptr)(base + p * 8192), 16, la[p], so, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_ptr)(base + ARR + p * 8192), 16, la[p], so + 16u, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_ptr)(base + 2 * ARR + p * 8192), 16, lw[p], so, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_ptr)(base + 3 * ARR + p * 8192), 16, lw[p], so + 16u, 0, 0);
         }
     };
-    const int nk = kslice / BK;
-    g_load(kbeg);
-    s_store(0);
-    __syncthreads();
-    for (int kt = 0; kt < nk; kt++) {
-        const int buf = kt & 1;
-        if (kt + 1 < nk) g_load(kbeg + (kt + 1) * BK);
-        const __bf16* pAh = sAh + buf * BM * LD + (wr * 64 + (lane & 31)) * LD + 8 * (lane >> 5);
-        const __bf16* pAl = sAl + buf * BM * LD + (wr * 64 + (lane & 31)) * LD + 8 * (lane >> 5);
-        const __bf16* pBh = sBh + buf * BN * LD + (wc * 64 + (lane & 31)) * LD + 8 * (lane >> 5);
-        const __bf16* pBl = sBl + buf * BN * LD + (wc * 64 + (lane & 31)) * LD + 8 * (lane >> 5);
-#pragma unroll
-        for (int ks = 0; ks < 2; ks++) {
-            bf16x8 ah[2], al[2], bh[2], bl[2];
-#pragma unroll
-            for (int q = 0; q < 2; q++) {
-                ah[q] = *reinterpret_cast<const bf16x8*>(pAh + q * 32 * LD + ks * 16);
-                al[q] = *reinterpret_cast<const bf16x8*>(pAl + q * 32 * LD + ks * 16);
-                bh[q] = *reinterpret_cast<const bf16x8*>(pBh + q * 32 * LD + ks * 16);
-                bl[q] = *reinterpret_cast<const bf16x8*>(pBl + q * 32 * LD + ks * 16);
-            }
-#pragma unroll
-            for (int a = 0; a < 2; a++)
-#pragma unroll
-                for (int b = 0; b < 2; b++) {
-                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[a], bh[b], acc[a][b], 0, 0, 0);
-                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[a], bl[b], acc[a][b], 0, 0, 0);
-                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[a], bh[b], acc[a][b], 0, 0, 0);
-                }
-        }
-        if (kt + 1 < nk) s_store(buf ^ 1);
-        __syncthreads();
+
+    // the bias of an item's 256 columns also arrives by LDS-DMA (one 1 KB piece, wave 0) into a slot behind the two operand
+    // buffers: the kernel holds no register-destination load at all (one consumed while LDS-DMAs are in flight makes hipcc
+    // drain the whole vmcnt queue at that point)
+    float* sbias = reinterpret_cast<float*>(smg + 2 * 4 * ARR);
+    auto dma_bias = [&](int nt_) {
+        typedef __attribute__((address_space(3))) void* lds_ptr;
+        if (g.bias && wv == 0)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(make_rsrc(g.bias + nt_ * BN), (lds_ptr)sbias, 16, (unsigned)lane * 16u, 0, 0, 0);
+    };
+    int q = 0;                                    // group q of per_xcd consecutive items goes to the XCD class q % 8
+    int it = (xcd + 8 * q) * per_xcd + slot;
+    int mt = 0, nt = 0, sp = 0;
+    if (it < g.items) {
+        item_coords(it, mt, nt, sp);
+        item_setup(mt, nt, sp);
+        dma(0, 0);
+        dma_bias(nt);
     }
-    float* C = g.C + (size_t)blockIdx.y * g.M * g.N;
+    bool first = true;
+    while (it < g.items) {
+        f32x16 acc[4][2];
 #pragma unroll
-    for (int a = 0; a < 2; a++)
+        for (int mi = 0; mi < 4; mi++)
 #pragma unroll
-        for (int b = 0; b < 2; b++) {
-            const int n = n0 + wc * 64 + b * 32 + (lane & 31);
-            const float bv = g.bias ? g.bias[n] : 0.0f;
+            for (int ni = 0; ni < 2; ni++)
 #pragma unroll
-            for (int r = 0; r < 16; r++) {
-                const int64_t m = m0 + wr * 64 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                if (m < g.M) C[m * g.N + n] = acc[a][b][r] + bv;
+                for (int r = 0; r < 16; r++) acc[mi][ni][r] = 0.0f;
+        for (int kt = 0; kt < nk; kt++) {
+            const int buf = kt & 1;
+            // this step's operands have landed (every wave waits for its own DMAs, then the barrier); the other buffer is free
+            if (kt == 0 && !first) asm volatile("s_waitcnt vmcnt(32)" ::: "memory");   // the previous item's 32 stores may stay in flight
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            if (kt + 1 < nk) dma(kt + 1, buf ^ 1);
+            const unsigned char* base = smg + buf * 4 * ARR;
+#pragma unroll
+            for (int ks = 0; ks < 2; ks++) {
+                const unsigned ch = (unsigned)(((2 * ks + (lane >> 5)) ^ f_swz) * 16);
+                bf16x8 bh[2], bl[2];
+#pragma unroll
+                for (int ni = 0; ni < 2; ni++) {
+                    bh[ni] = *reinterpret_cast<const bf16x8*>(base + fb_l + ni * 32 * 64 + ch);
+                    bl[ni] = *reinterpret_cast<const bf16x8*>(base + ARR + fb_l + ni * 32 * 64 + ch);
+                }
+#pragma unroll
+                for (int mi = 0; mi < 4; mi++) {
+                    const bf16x8 ah = *reinterpret_cast<const bf16x8*>(base + fa_l + mi * 32 * 64 + ch);
+                    const bf16x8 al = *reinterpret_cast<const bf16x8*>(base + ARR + fa_l + mi * 32 * 64 + ch);
+#pragma unroll
+                    for (int ni = 0; ni < 2; ni++) {
+                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh[ni], acc[mi][ni], 0, 0, 0);
+                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl[ni], acc[mi][ni], 0, 0, 0);
+                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh[ni], acc[mi][ni], 0, 0, 0);
+                    }
+                }
             }
         }
+        first = false;
+        // C tile as a sized buffer resource: rows beyond M fall outside it and are dropped by the bounds check; the
+        // address of every store is (tile resource) + (lane offset) + (scalar offset of (wave, mi, ni, r))
+        const int64_t m0 = (int64_t)mt * BM;
+        const int n0 = nt * BN;
+        const int64_t rows_left = g.M - m0 < BM ? g.M - m0 : BM;
+        float* cbase = g.C + (size_t)sp * g.M * g.N;
+        float bv[2];
+#pragma unroll
+        for (int ni = 0; ni < 2; ni++) bv[ni] = g.bias ? sbias[64 * wc + 32 * ni + (lane & 31)] : 0.0f;
+        // every wave is done reading the operand buffers and the bias slot of this item before the next item's first DMAs
+        // overwrite them
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        q++;
+        it = (xcd + 8 * q) * per_xcd + slot;
+        if (it < g.items) {
+            item_coords(it, mt, nt, sp);
+            item_setup(mt, nt, sp);
+            dma(0, 0);
+            dma_bias(nt);
+        }
+        if (g.c_quads) {
+            // [M/4][N][4]: accumulator registers 4g..4g+3 of a lane are four consecutive rows of one column: one 16-byte store
+            // the same descriptor make_rsrc_sized builds, as four words for the inline-asm store below
+            const uint64_t cptr = (uint64_t)(cbase + ((size_t)(m0 >> 2) * g.N + n0) * 4);
+            u32x4 rcw;
+            rcw[0] = __builtin_amdgcn_readfirstlane((unsigned)cptr);
+            rcw[1] = __builtin_amdgcn_readfirstlane((unsigned)(cptr >> 32) & 0xffffu);
+            rcw[2] = __builtin_amdgcn_readfirstlane((unsigned)((((rows_left + 3) / 4 - 1) * g.N + BN) * 16));
+            rcw[3] = 0x00020000u;
+            const unsigned c_l = (unsigned)((((lane >> 5)) * g.N + (lane & 31)) * 16);
+#pragma unroll
+            for (int mi = 0; mi < 4; mi++)
+#pragma unroll
+                for (int ni = 0; ni < 2; ni++)
+#pragma unroll
+                    for (int gq = 0; gq < 4; gq++) {
+                        f32x4 v;
+#pragma unroll
+                        for (int j = 0; j < 4; j++) v[j] = acc[mi][ni][4 * gq + j] + bv[ni];
+                        // gfx950 reads the data registers of a 16-byte buffer store late: a VALU write to them in the next
+                        // wait states corrupts part of the lanes (measured: dword 1 of lanes 12-15 of every 16), and hipcc
+                        // (ROCm 7.2) pads that hazard only for stores WITHOUT an SGPR soffset. The store is issued from inline asm
+                        // with its own wait states, after which the registers are free (and with the 5 wait states a VALU-written
+                        // SGPR operand needs before a VMEM instruction reads it: hipcc pads nothing around asm statements, and the
+                        // scalar offset may just have come out of a v_readlane spill reload).
+                        const unsigned so = (unsigned)(((32 * wr + 8 * mi + 2 * gq) * g.N + 64 * wc + 32 * ni) * 16);
+                        asm volatile("s_nop 4\n\tbuffer_store_dwordx4 %0, %1, %2, %3 offen nt\n\ts_nop 2"
+                                     :: "v"(v), "v"(c_l), "s"(rcw), "s"(so) : "memory");
+                    }
+        } else {
+            const __amdgpu_buffer_rsrc_t rc = make_rsrc_sized(cbase + (size_t)m0 * g.N + n0, (unsigned)(((rows_left - 1) * g.N + BN) * 4));
+            const unsigned c_l = (unsigned)(((4 * (lane >> 5)) * g.N + (lane & 31)) * 4);
+#pragma unroll
+            for (int mi = 0; mi < 4; mi++)
+#pragma unroll
+                for (int ni = 0; ni < 2; ni++)
+#pragma unroll
+                    for (int r = 0; r < 16; r++)
+                        buf_store1_nt(acc[mi][ni][r] + bv[ni], rc, c_l,
+                                      (unsigned)(((128 * wr + 32 * mi + (r & 3) + 8 * (r >> 2)) * g.N + 64 * wc + 32 * ni) * 4));
+        }
+    }
 }
 
 // decoder recurrence on pre-computed input projections G (fp32 [Bp*33, 2048], bias included): per step only the
 // h part runs on the f32 MFMA; G is fetched into registers at the start of the step and added in the cell update.
 struct RecArgs {
-    const float* G;       // [Bp, 33, 2][1024]  (row (b,t), columns dir*1024 + gate*256 + unit)
+    const float* G;       // quads [33*Bp/4][2048][4]: row m = t*Bp + b (time-major), columns dir*1024 + gate*256 + unit, four
+                          // consecutive rows of a column adjacent (k_gemm_bf16x3, c_quads)
+    int64_t Bp;
     const float* wp;      // packed decoder weights [2 dirs][8 waves][96 kb][4][64][4] (the h part starts at k-block 64)
-    float* out;           // [Bp, 33, 512]
-    float* out_cm;        // chunk-major copy [16896/32][Bp][32] (A operand of the linear_1 GEMM)
-    int64_t cm_rows;      // Bp
+    float* out;           // [Bp, 33, 512] fp32, or NULL (only the debug taps read it)
+    unsigned char* out_split;  // [Bp] split8 rows of 33*512 elements (A operand of the linear_1 GEMM)
     int n_tiles;
 };
 
@@ -607,24 +715,24 @@ __global__ __launch_bounds__(512, 2) void k_lstm_rec_g(RecArgs a) {
     ring_prime<NT>(bq, wr, 0, lane);
     const int unit = UW * wv + (lane & 31);
     // raw buffer accesses (tile resource + lane offset + scalar offset): no per-lane 64-bit addresses next to the 64 gx values
-    const __amdgpu_buffer_rsrc_t gsr = make_rsrc(a.G + (size_t)b0 * T_STEPS * 2048);
+    const __amdgpu_buffer_rsrc_t gsr = make_rsrc(a.G + (size_t)b0 * 2048);     // quad (b0 / 4) of time slab 0
     const __amdgpu_buffer_rsrc_t osr = make_rsrc(a.out + (size_t)b0 * T_STEPS * 2 * H);
-    const unsigned gl_l = (unsigned)((4 * (lane >> 5) * T_STEPS * 2048 + (lane & 31)) * 4);
+    const unsigned gl_l = (unsigned)(((lane >> 5) * 2048 + (lane & 31)) * 16);  // quad h of a group of 8 rows, this lane's column
     const unsigned og_l = (unsigned)((4 * (lane >> 5) * T_STEPS * 2 * H + (lane & 31)) * 4);
-    const unsigned cm_l = (unsigned)((4 * (lane >> 5) * 32 + (lane & 31)) * 4);
+    const __amdgpu_buffer_rsrc_t ssr = make_rsrc(a.out_split + (size_t)b0 * T_STEPS * 2 * H * 4);
+    const unsigned sg_l = (unsigned)(4 * (lane >> 5) * T_STEPS * 2 * H * 4) + split8_off((unsigned)(lane & 31));
     __syncthreads();
     for (int s = 0; s < T_STEPS; s++) {
         const int t = dir ? (T_STEPS - 1 - s) : s;
         const int cur = s & 1, nxt = cur ^ 1;
         // input projections of this step: 64 values per lane, in flight during the h-part MFMAs
-        float gx[NT][16];
+        // (accumulator registers 4g..4g+3 = rows 8g + 4*(lane>>5) + 0..3 of this lane's column = one 16-byte quad of G)
+        f32x4 gx[NT][4];
 #pragma unroll
         for (int nt = 0; nt < NT; nt++)
 #pragma unroll
-            for (int r = 0; r < 16; r++) {
-                const int rr = (r & 3) + 8 * (r >> 2);  // compile-time part of the row; the lane part is in gl_l
-                gx[nt][r] = buf_load1(gsr, gl_l, (unsigned)((t * 2048 + dir * 1024 + UW * wv + rr * T_STEPS * 2048 + nt * H) * 4));
-            }
+            for (int gq = 0; gq < 4; gq++)
+                gx[nt][gq] = buf_load4_nt(gsr, gl_l, (unsigned)((((size_t)t * a.Bp / 4 + 2 * gq) * 2048 + dir * 1024 + nt * H + UW * wv) * 16));
         Gate<32> acc[NT];
 #pragma unroll
         for (int nt = 0; nt < NT; nt++)
@@ -632,22 +740,22 @@ __global__ __launch_bounds__(512, 2) void k_lstm_rec_g(RecArgs a) {
             for (int r = 0; r < 16; r++) acc[nt].v[r] = 0.0f;
         mma_dual_ringb<32, NT>(acc, hbuf + cur * ROWS * LDH, LDH, s == 0 ? 0 : NKB_H, hbuf, LDH, 0, wr, bq, lane);  // h_0 = 0
         float* hn = hbuf + nxt * ROWS * LDH;
-        const __amdgpu_buffer_rsrc_t cmr = make_rsrc(a.out_cm + ((size_t)(t * 16 + dir * 8 + wv) * a.cm_rows + (size_t)b0) * 32);
 #pragma unroll
         for (int r = 0; r < 16; r++) {
-            const float ig = sigmoidf_(acc[0].v[r] + gx[0][r]);
-            const float fg = sigmoidf_(acc[1].v[r] + gx[1][r]);
-            const float gg = tanhf_(acc[2].v[r] + gx[2][r]);
-            const float og = sigmoidf_(acc[3].v[r] + gx[3][r]);
+            const float ig = sigmoidf_(acc[0].v[r] + gx[0][r >> 2][r & 3]);
+            const float fg = sigmoidf_(acc[1].v[r] + gx[1][r >> 2][r & 3]);
+            const float gg = tanhf_(acc[2].v[r] + gx[2][r >> 2][r & 3]);
+            const float og = sigmoidf_(acc[3].v[r] + gx[3][r >> 2][r & 3]);
             const float c = fg * cst[r] + ig * gg;
             cst[r] = c;
             const float h = og * tanhf_(c);
             const int rr = (r & 3) + 8 * (r >> 2);
             const int row = rr + 4 * (lane >> 5);
             hn[row * LDH + unit] = h;
-            buf_store1(h, osr, og_l, (unsigned)((t * 2 * H + dir * H + UW * wv + rr * T_STEPS * 2 * H) * 4));
-            // chunk-major copy: flattened [t][512] column = K index of linear_1; this wave's 32 units are one 32-wide chunk
-            buf_store1(h, cmr, cm_l, (unsigned)(rr * 32 * 4));
+            const unsigned o_s = (unsigned)((t * 2 * H + dir * H + UW * wv + rr * T_STEPS * 2 * H) * 4);
+            if (a.out) buf_store1_nt(h, osr, og_l, o_s);
+            // row b, element k = t*512 + dir*256 + unit: flattened [t][512] = K index of linear_1
+            split8_store(h, ssr, sg_l, (unsigned)(rr * T_STEPS * 2 * H * 4) + split8_off((unsigned)(t * 2 * H + dir * H + UW * wv)));
         }
         __syncthreads();
     }
@@ -706,9 +814,10 @@ static void pack_linear(const float* W, int K, int TR, std::vector<float>& wp) {
 
 }  // namespace
 
+static constexpr int64_t P1_BF16_MAX_BATCH = 16384;
 template <int KP, int TR> constexpr size_t lds_lstm() { return (size_t)(TR * (KP + 4) + 2 * TR * (H + 4)) * sizeof(float); }
 static constexpr size_t LDS_REC = (size_t)(2 * ROWS * (H + 4)) * sizeof(float);
-static constexpr size_t LDS_GEMM = (size_t)4 * 2 * 128 * 40 * 2;  // 4 operand arrays x 2 buffers x 128 rows x 40 bf16
+static constexpr size_t LDS_GEMM = (size_t)2 * 4 * 256 * 32 * 2 + 1024;   // 2 buffers x {A_hi, A_lo, W_hi, W_lo} x 256 rows x 32 bf16 = 128 KB, + bias slot
 static constexpr size_t LDS_SPLITK = (size_t)ROWS * (2 * H + 4) * sizeof(float);
 template <int TR> constexpr size_t lds_tail() { return (size_t)2 * TR * (HEAD_N + 4) * sizeof(float); }
 
@@ -722,8 +831,8 @@ struct pv_rnn_p1 {
     float* wo = nullptr; float* bo = nullptr;
     int dtype = PV_DTYPE_F32;
     // PV_DTYPE_BF16_INPUT_GEMM: bf16 hi/lo splits of the decoder W_ih (both directions, [2048,512]) and linear_1 ([512,16896])
-    __bf16* dec_wih_h = nullptr; __bf16* dec_wih_l = nullptr; float* dec_bias_cat = nullptr;
-    __bf16* w1_h = nullptr; __bf16* w1_l = nullptr;
+    unsigned char* dec_wih_s = nullptr; float* dec_bias_cat = nullptr;   // split8 rows
+    unsigned char* w1_s = nullptr;
     std::vector<void*> owned;
 };
 
@@ -738,23 +847,22 @@ static inline float bf_bits2f(uint16_t h) {
     memcpy(&f, &u, 4);
     return f;
 }
-// w [N, K] row-major -> (hi, lo) bf16 with w ~= hi + lo, stored chunk-major [K/32][N][32]
-static int dev_upload_split(const float* w, size_t N, size_t K, __bf16** d_hi, __bf16** d_lo, std::vector<void*>& owned) {
+// w [N, K] row-major -> split8 rows (per 8 elements: 8 x bf16 hi, 8 x bf16 lo with w ~= hi + lo), K % 8 == 0
+static int dev_upload_split(const float* w, size_t N, size_t K, unsigned char** d_split, std::vector<void*>& owned) {
     const size_t n = N * K;
-    std::vector<uint16_t> hi(n), lo(n);
+    std::vector<uint16_t> sw(2 * n);
     for (size_t r = 0; r < N; r++)
         for (size_t k = 0; k < K; k++) {
             const float v = w[r * K + k];
-            const size_t o = ((k >> 5) * N + r) * 32 + (k & 31);
-            hi[o] = f2bf_bits(v);
-            lo[o] = f2bf_bits(v - bf_bits2f(hi[o]));
+            const uint16_t hi = f2bf_bits(v);
+            const uint16_t lo = f2bf_bits(v - bf_bits2f(hi));
+            const size_t o = r * K * 2 + (k >> 3) * 16 + (k & 7);   // in 2-byte units
+            sw[o] = hi;
+            sw[o + 8] = lo;
         }
-    PV_HIP(hipMalloc((void**)d_hi, n * 2));
-    owned.push_back(*d_hi);
-    PV_HIP(hipMalloc((void**)d_lo, n * 2));
-    owned.push_back(*d_lo);
-    PV_HIP(hipMemcpy(*d_hi, hi.data(), n * 2, hipMemcpyHostToDevice));
-    PV_HIP(hipMemcpy(*d_lo, lo.data(), n * 2, hipMemcpyHostToDevice));
+    PV_HIP(hipMalloc((void**)d_split, n * 4));
+    owned.push_back(*d_split);
+    PV_HIP(hipMemcpy(*d_split, sw.data(), n * 4, hipMemcpyHostToDevice));
     return PV_OK;
 }
 
@@ -826,9 +934,9 @@ extern "C" int pv_rnn_load_p1(pv_ctx* ctx, const pv_weights_p1* w, int dtype) {
             memcpy(&wcat[(size_t)d * 1024 * 512], w->decoder[d].w_ih, (size_t)1024 * 512 * sizeof(float));
             for (int n = 0; n < 1024; n++) bcat[d * 1024 + n] = w->decoder[d].b_ih[n] + w->decoder[d].b_hh[n];
         }
-        if ((rc = dev_upload_split(wcat.data(), 2048, 512, &m->dec_wih_h, &m->dec_wih_l, m->owned))) return rc;
+        if ((rc = dev_upload_split(wcat.data(), 2048, 512, &m->dec_wih_s, m->owned))) return rc;
         if ((rc = dev_upload(bcat, &m->dec_bias_cat, m->owned))) return rc;
-        if ((rc = dev_upload_split(w->linear_w[0], HEAD_N, HEAD_K, &m->w1_h, &m->w1_l, m->owned))) return rc;
+        if ((rc = dev_upload_split(w->linear_w[0], HEAD_N, HEAD_K, &m->w1_s, m->owned))) return rc;
         PV_HIP(hipFuncSetAttribute((const void*)k_gemm_bf16x3, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_GEMM));
         PV_HIP(hipFuncSetAttribute((const void*)k_lstm_rec_g, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_REC));
     }
@@ -854,7 +962,7 @@ static void launch_tail(pv_ctx* ctx, pv_rnn_p1* m, TailArgs& t, int n_tiles32, h
 }
 
 static int p1_forward_launch(pv_ctx* ctx, const int8_t* d_images, int64_t B, float* d_probs, float* enc_out,
-                             float* dec_out, float* part, hipStream_t st) {
+                             float* dec_out, float* part, hipStream_t st, bool taps = false) {
     pv_rnn_p1* m = ctx->p1;
     const int n_tiles = (int)((B + ROWS - 1) / ROWS);   // 32-row tiles: the granularity of every buffer and of the head
     // LSTM tile form: 32-row tiles once (tile, direction) workgroups fill the chip, else 16-row tiles: twice the workgroups,
@@ -867,13 +975,16 @@ static int p1_forward_launch(pv_ctx* ctx, const int8_t* d_images, int64_t B, flo
     const unsigned rec_grid = (unsigned)(((n_tiles + 3) / 4) * 8);
     LstmArgs e;
     e.x_i8 = d_images; e.x_f32 = nullptr; e.wp = m->enc_wp[f]; e.bias = m->enc_bias; e.out = enc_out; e.B = B; e.n_tiles = n_lt;
-    e.out_cm = nullptr; e.cm_rows = 0;
-    struct { float *enc_cm, *dec_cm; } bf = {nullptr, nullptr};
+    e.out_split = nullptr; e.Bp = 0;
+    unsigned char *enc_split = nullptr, *dec_split = nullptr;
     if (m->dtype == PV_DTYPE_BF16_INPUT_GEMM) {
+        // layer outputs leave the producers as split-bf16 words (hi | lo << 16), the operand form of the bf16x3 GEMMs; the
+        // fp32 copies are only written for the debug taps
         const size_t nel = (size_t)n_tiles * ROWS * T_STEPS * 2 * H;
         int rcb;
-        if ((rcb = pv_get(ctx, "p1.enc_cm", nel, &bf.enc_cm)) || (rcb = pv_get(ctx, "p1.dec_cm", nel, &bf.dec_cm))) return rcb;
-        e.out_cm = bf.enc_cm; e.cm_rows = (int64_t)n_tiles * ROWS * T_STEPS;
+        if ((rcb = pv_get(ctx, "p1.enc_split", nel * 4, &enc_split)) || (rcb = pv_get(ctx, "p1.dec_split", nel * 4, &dec_split))) return rcb;
+        e.out_split = enc_split; e.Bp = (int64_t)n_tiles * ROWS;
+        if (!taps) e.out = nullptr;
     }
     {
         pv_prof_scope ps(ctx, "k_lstm_layer_enc", st);
@@ -886,29 +997,34 @@ static int p1_forward_launch(pv_ctx* ctx, const int8_t* d_images, int64_t B, flo
         float* G = nullptr;
         int rc2 = pv_get(ctx, "p1.G", (size_t)M * 2048, &G);
         if (rc2) return rc2;
+        auto gemm_grid = [&](int items) { return (unsigned)(std::min((items + 7) / 8 * 8, (ctx->num_cu + 7) / 8 * 8)); };
         GemmArgs ga;
-        ga.Ac = bf.enc_cm; ga.Wh = m->dec_wih_h; ga.Wl = m->dec_wih_l; ga.bias = m->dec_bias_cat; ga.C = G;
+        ga.A = enc_split; ga.W = m->dec_wih_s; ga.bias = m->dec_bias_cat; ga.C = G;
         ga.M = M; ga.N = 2048; ga.K = 2 * H; ga.splits = 1;
+        ga.tiles_m = (int)((M + 255) / 256); ga.tiles_n = 2048 / 256; ga.items = ga.tiles_m * ga.tiles_n; ga.c_quads = 1;
         {
             pv_prof_scope ps(ctx, "k_gemm_bf16x3_dec", st);
-            k_gemm_bf16x3<<<dim3((unsigned)(((M + 127) / 128) * (2048 / 128)), 1), 256, LDS_GEMM, st>>>(ga);
+            k_gemm_bf16x3<<<gemm_grid(ga.items), 512, LDS_GEMM, st>>>(ga);
         }
         RecArgs ra;
-        ra.G = G; ra.wp = m->dec_wp[0]; ra.out = dec_out; ra.out_cm = bf.dec_cm; ra.cm_rows = Bp; ra.n_tiles = n_tiles;
+        ra.G = G; ra.Bp = Bp; ra.wp = m->dec_wp[0]; ra.out = taps ? dec_out : nullptr; ra.out_split = dec_split; ra.n_tiles = n_tiles;
         {
             pv_prof_scope ps(ctx, "k_lstm_rec_g", st);
             k_lstm_rec_g<<<rec_grid, 512, LDS_REC, st>>>(ra);
         }
-        // linear_1 as a split-K bf16x3 GEMM into slabs [splits][Bp][512]
-        const int64_t mtiles = (Bp + 127) / 128;
-        int gs = 1;
-        while (gs < 8 && mtiles * 4 * gs < ctx->num_cu && (HEAD_K / 32) % (gs * 2) == 0) gs *= 2;
+        // linear_1 as a split-K bf16x3 GEMM into slabs [splits][Bp][512]: the smallest split factor (a divisor of the 528
+        // K steps of 32) whose work items fill the chip
         GemmArgs gl;
-        gl.Ac = bf.dec_cm; gl.Wh = m->w1_h; gl.Wl = m->w1_l; gl.bias = nullptr; gl.C = part;
-        gl.M = Bp; gl.N = HEAD_N; gl.K = HEAD_K; gl.splits = gs;
+        gl.A = dec_split; gl.W = m->w1_s; gl.bias = nullptr; gl.C = part;
+        gl.M = Bp; gl.N = HEAD_N; gl.K = HEAD_K;
+        gl.tiles_m = (int)((Bp + 255) / 256); gl.tiles_n = HEAD_N / 256;
+        static const int divs[] = {1, 2, 3, 4, 6, 8, 11, 12, 16, 22, 24, 33};
+        int gs = 33;
+        for (int dv : divs) if (gl.tiles_m * gl.tiles_n * dv >= ctx->num_cu) { gs = dv; break; }
+        gl.splits = gs; gl.items = gl.tiles_m * gl.tiles_n * gs; gl.c_quads = 0;
         {
             pv_prof_scope ps(ctx, "k_gemm_bf16x3_lin1", st);
-            k_gemm_bf16x3<<<dim3((unsigned)(mtiles * 4), (unsigned)gs), 256, LDS_GEMM, st>>>(gl);
+            k_gemm_bf16x3<<<gemm_grid(gl.items), 512, LDS_GEMM, st>>>(gl);
         }
         TailArgs tb;
         tb.part = part; tb.b1 = m->b1; tb.splits = gs; tb.part_rows = Bp;
@@ -957,10 +1073,17 @@ extern "C" int pv_rnn_forward_p1_dev(pv_ctx* ctx, const int8_t* d_images, int64_
     PV_CHECK(B >= 0 && B < (1ll << 24), PV_ERR_INVALID, "batch %lld out of range", (long long)B);
     if (B == 0) return PV_OK;
     PV_HIP(hipSetDevice(ctx->device));
+    // the bf16x3 mode addresses its time-major split8 rows and the G quads with 32-bit scalar offsets (33 x Bp x 2 KB and
+    // 33 x Bp x 8 KB): larger batches run as chunks of P1_BF16_MAX_BATCH windows on the same stream
+    const int64_t chunk = ctx->p1->dtype == PV_DTYPE_BF16_INPUT_GEMM ? P1_BF16_MAX_BATCH : B;
     float *enc, *dec, *part;
-    int rc = p1_workspace(ctx, B, &enc, &dec, &part);
+    int rc = p1_workspace(ctx, std::min(B, chunk), &enc, &dec, &part);
     if (rc) return rc;
-    return p1_forward_launch(ctx, d_images, B, d_probs, enc, dec, part, pv_pick_stream(ctx, stream));
+    for (int64_t b0 = 0; b0 < B; b0 += chunk) {
+        const int64_t nb = std::min(chunk, B - b0);
+        if ((rc = p1_forward_launch(ctx, d_images + b0 * PV_WINDOW_BYTES, nb, d_probs + b0 * 3, enc, dec, part, pv_pick_stream(ctx, stream)))) return rc;
+    }
+    return PV_OK;
 }
 
 extern "C" int pv_rnn_forward_p1_debug(pv_ctx* ctx, const int8_t* images, int64_t B, float* probs, float* enc_out,
@@ -969,6 +1092,17 @@ extern "C" int pv_rnn_forward_p1_debug(pv_ctx* ctx, const int8_t* images, int64_
     PV_CHECK(ctx->p1, PV_ERR_STATE, "pv_rnn_load_p1 has not been called on this context");
     PV_CHECK(B >= 0 && B < (1ll << 24), PV_ERR_INVALID, "batch %lld out of range", (long long)B);
     if (B == 0) return PV_OK;
+    if (ctx->p1->dtype == PV_DTYPE_BF16_INPUT_GEMM && B > P1_BF16_MAX_BATCH) {
+        // host-buffer form in the bf16x3 mode: chunks (the taps are per-window, so chunking does not change them)
+        for (int64_t b0 = 0; b0 < B; b0 += P1_BF16_MAX_BATCH) {
+            const int64_t nb = std::min<int64_t>(P1_BF16_MAX_BATCH, B - b0);
+            const size_t tap = (size_t)b0 * T_STEPS * 2 * H;
+            int rcc = pv_rnn_forward_p1_debug(ctx, images + b0 * PV_WINDOW_BYTES, nb, probs + b0 * 3, enc_out ? enc_out + tap : nullptr,
+                                              dec_out ? dec_out + tap : nullptr);
+            if (rcc) return rcc;
+        }
+        return PV_OK;
+    }
     PV_HIP(hipSetDevice(ctx->device));
     hipStream_t st = ctx->stream;
     float *enc, *dec, *part, *d_probs;
@@ -978,7 +1112,7 @@ extern "C" int pv_rnn_forward_p1_debug(pv_ctx* ctx, const int8_t* images, int64_
     if ((rc = pv_get(ctx, "p1.images", (size_t)B * PV_WINDOW_BYTES, &d_img))) return rc;
     if ((rc = pv_get(ctx, "p1.probs", (size_t)B * 3, &d_probs))) return rc;
     PV_HIP(hipMemcpyAsync(d_img, images, (size_t)B * PV_WINDOW_BYTES, hipMemcpyHostToDevice, st));
-    if ((rc = p1_forward_launch(ctx, d_img, B, d_probs, enc, dec, part, st))) return rc;
+    if ((rc = p1_forward_launch(ctx, d_img, B, d_probs, enc, dec, part, st, enc_out || dec_out))) return rc;
     PV_HIP(hipMemcpyAsync(probs, d_probs, (size_t)B * 3 * sizeof(float), hipMemcpyDeviceToHost, st));
     const size_t nb = (size_t)B * T_STEPS * 2 * H * sizeof(float);
     if (enc_out) PV_HIP(hipMemcpyAsync(enc_out, enc, nb, hipMemcpyDeviceToHost, st));
@@ -989,6 +1123,47 @@ extern "C" int pv_rnn_forward_p1_debug(pv_ctx* ctx, const int8_t* images, int64_
 
 extern "C" int pv_rnn_forward_p1(pv_ctx* ctx, const int8_t* images, int64_t B, float* probs) {
     return pv_rnn_forward_p1_debug(ctx, images, B, probs, nullptr, nullptr);
+}
+
+// Diagnostic entry (tests, tuning): C = A . W^T + bias through k_gemm_bf16x3 alone. HOST pointers, fp32 row-major A [M,K],
+// W [N,K], bias [N] or NULL, C [splits][M][N] row-major (quads = 0) or [M/4][N][4] (quads = 1, splits must be 1).
+// M % 4 == 0, N % 256 == 0, K % (32 * splits) == 0. Returns the kernel time in ms through *ms when non-NULL.
+extern "C" int pv_debug_gemm_bf16x3(pv_ctx* ctx, const float* A, const float* W, const float* bias, int64_t M, int N, int K,
+                                    int splits, int quads, float* C, float* ms) {
+    PV_CHECK(ctx && A && W && C, PV_ERR_INVALID, "null argument");
+    PV_CHECK(M > 0 && M % 4 == 0 && N % 256 == 0 && splits >= 1 && K % (32 * splits) == 0 && (!quads || splits == 1), PV_ERR_INVALID, "bad GEMM shape");
+    PV_HIP(hipSetDevice(ctx->device));
+    std::vector<void*> owned;
+    unsigned char *dA = nullptr, *dW = nullptr;
+    float *dB = nullptr, *dC = nullptr;
+    int rc;
+    auto cleanup = [&]() { for (void* p : owned) (void)hipFree(p); };
+    if ((rc = dev_upload_split(A, (size_t)M, (size_t)K, &dA, owned)) || (rc = dev_upload_split(W, (size_t)N, (size_t)K, &dW, owned))) { cleanup(); return rc; }
+    if (bias && (rc = dev_upload(bias, (size_t)N, &dB, owned))) { cleanup(); return rc; }
+    const size_t nc = (size_t)splits * M * N;
+    if (hipMalloc((void**)&dC, nc * sizeof(float)) != hipSuccess) { cleanup(); pv_set_error("hipMalloc failed"); return PV_ERR_HIP; }
+    owned.push_back(dC);
+    (void)hipMemset(dC, 0xff, nc * sizeof(float));
+    (void)hipFuncSetAttribute((const void*)k_gemm_bf16x3, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_GEMM);
+    GemmArgs g;
+    g.A = dA; g.W = dW; g.bias = dB; g.C = dC; g.M = M; g.N = N; g.K = K; g.splits = splits;
+    g.tiles_m = (int)((M + 255) / 256); g.tiles_n = N / 256; g.items = g.tiles_m * g.tiles_n * splits; g.c_quads = quads;
+    const unsigned grid = (unsigned)(std::min((g.items + 7) / 8 * 8, (ctx->num_cu + 7) / 8 * 8));
+    hipEvent_t e0, e1;
+    (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+    k_gemm_bf16x3<<<grid, 512, LDS_GEMM, ctx->stream>>>(g);   // warm
+    (void)hipEventRecord(e0, ctx->stream);
+    k_gemm_bf16x3<<<grid, 512, LDS_GEMM, ctx->stream>>>(g);
+    (void)hipEventRecord(e1, ctx->stream);
+    hipError_t er = hipStreamSynchronize(ctx->stream);
+    float t = 0.f;
+    (void)hipEventElapsedTime(&t, e0, e1);
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    if (ms) *ms = t;
+    if (er == hipSuccess) er = hipMemcpy(C, dC, nc * sizeof(float), hipMemcpyDeviceToHost);
+    cleanup();
+    if (er != hipSuccess) { pv_set_error("GEMM failed: %s", hipGetErrorString(er)); return PV_ERR_HIP; }
+    return PV_OK;
 }
 
 // ---- P2 (bi-GRU polisher model): see rnn_gru.hip ----------------------------------------------------

@@ -196,3 +196,61 @@ def test_p1_full_batches_properties(hip_ctx, B):
         np.testing.assert_allclose(probs[lo:lo + 40], alone, atol=1e-6, rtol=0)
     ref = rnn_oracle.p1_forward(w, x[:16], np.float64)
     np.testing.assert_allclose(probs[:16], ref, atol=TOL_PROBS, rtol=0)
+
+
+@pytest.mark.parametrize("B", [4096, 4130])
+def test_p1_bf16_mode_full_batch_properties(B):
+    """configs[2] size (batch 4096, and a ragged size that leaves a partial 256-row GEMM tile): the bf16x3 mode agrees with the
+    fp32 mode on every window within the 1e-4 bar, rows are independent of the batch they run in, and the leading rows match
+    the float64 oracle."""
+    from pepper_thesis_amd import _ffi, runtime
+    w = synth.make_weights_p1(5, 2.0)
+    x = synth.synth_windows(3000 + B, B)
+    c32 = runtime.Context(0)
+    c32.load_p1(w)
+    p32 = c32.forward_p1(x)
+    c32.close()
+    ctx = runtime.Context(0)
+    ctx.load_p1(w, _ffi.PV_DTYPE_BF16_INPUT_GEMM)
+    probs = ctx.forward_p1(x)
+    assert np.isfinite(probs).all() and np.abs(probs.sum(1) - 1).max() < 1e-5
+    np.testing.assert_allclose(probs, p32, atol=TOL_PROBS, rtol=0)
+    for lo in (0, B // 2 - 17, B - 40):
+        alone = ctx.forward_p1(x[lo:lo + 40])
+        np.testing.assert_allclose(probs[lo:lo + 40], alone, atol=2e-6, rtol=0)
+    ref = rnn_oracle.p1_forward(w, x[:16], np.float64)
+    np.testing.assert_allclose(probs[:16], ref, atol=TOL_PROBS, rtol=0)
+    ctx.close()
+
+
+def test_bf16x3_gemm_alone(hip_ctx):
+    """the 3-term split-bf16 GEMM kernel by itself against float64 matmul: both output layouts, split-K, ragged M, bias"""
+    import ctypes as C
+    from pepper_thesis_amd import _ffi
+    lib = _ffi.load()
+    rng = np.random.default_rng(0)
+    for M, N, K, splits, quads, bias in ((64, 256, 64, 1, 0, True), (64, 256, 64, 1, 1, True), (1056, 2048, 512, 1, 1, True),
+                                         (320, 512, 1024, 2, 0, False), (2052, 512, 2112, 3, 0, False), (8448, 2048, 512, 1, 1, True)):
+        A = rng.standard_normal((M, K)).astype(np.float32)
+        W = (rng.standard_normal((N, K)) * 0.05).astype(np.float32)
+        b = rng.standard_normal(N).astype(np.float32) if bias else None
+        out = np.zeros((splits, M, N), np.float32)
+        _ffi.check(lib.pv_debug_gemm_bf16x3(hip_ctx.handle, A.ctypes.data, W.ctypes.data, None if b is None else b.ctypes.data,
+                                            M, N, K, splits, quads, out.ctypes.data, None))
+        if quads:
+            out = out.reshape(M // 4, N, 4).transpose(0, 2, 1).reshape(1, M, N)
+        ref = A.astype(np.float64) @ W.astype(np.float64).T + (0 if b is None else b)
+        # 3-term split: relative error ~2^-16 per product, fp32 accumulation over K
+        np.testing.assert_allclose(out.sum(0), ref, atol=2e-4, rtol=0, err_msg=str((M, N, K, splits, quads)))
+
+
+def test_p1_bf16_mode_chunks_large_batches():
+    """bf16x3 mode beyond its 16384-window addressing unit: the chunked launch equals the windows run in two separate calls"""
+    from pepper_thesis_amd import _ffi, runtime
+    ctx = runtime.Context(0)
+    ctx.load_p1(synth.make_weights_p1(5, 2.0), _ffi.PV_DTYPE_BF16_INPUT_GEMM)
+    x = synth.synth_windows(99, 16384 + 100)
+    whole = ctx.forward_p1(x)
+    parts = np.concatenate([ctx.forward_p1(x[:16384]), ctx.forward_p1(x[16384:])])
+    np.testing.assert_allclose(whole, parts, atol=2e-6, rtol=0)
+    ctx.close()
