@@ -213,13 +213,18 @@ __device__ __forceinline__ void gru_window(const GruArgs& a, int win_start, int 
             for (int u = 0; u < XR; u++) xr[u] = buf_load4(xsr, xd_g * 4u, (unsigned)((t * TR + u * 4) * KPD * 4));
         }
     };
-    auto x_store = [&]() {
+    // 16-row form: x_t tiles alternate between two LDS buffers (slot s & 1 holds step s): x_{s+1} is written right behind
+    // step s's MFMAs, so ONE barrier per step publishes both the new h and the next x. (Two 32-row x buffers of both
+    // directions do not fit the 160 KB: that form keeps one buffer and a second barrier.)
+    constexpr bool XDB = TR == 16;
+    auto x_store = [&](int slot) {
+        float* xb = xbuf + (XDB ? slot : 0) * TR * LDXD;
         if constexpr (ENC) {
 #pragma unroll
-            for (int u = 0; u < XE; u++) (xbuf + u * 8 * LDX)[xe_l] = xe[u];
+            for (int u = 0; u < XE; u++) (xb + u * 8 * LDX)[xe_l] = xe[u];
         } else {
 #pragma unroll
-            for (int u = 0; u < XR; u++) *reinterpret_cast<f32x4*>(xbuf + u * 4 * LDX + xd_l) = xr[u];
+            for (int u = 0; u < XR; u++) *reinterpret_cast<f32x4*>(xb + u * 4 * LDX + xd_l) = xr[u];
         }
     };
     f32x4 bq[4][3];  // weight-fragment ring of mma3_ring; slots 0..2 start with k-blocks 0..2
@@ -230,7 +235,7 @@ __device__ __forceinline__ void gru_window(const GruArgs& a, int win_start, int 
     const unsigned h_l = (unsigned)(lane_row<TR>(lane) * LDH + unit);   // lane part of the h tile offset
     const unsigned o_l = (unsigned)(lane_row<TR>(lane) * KPD + unit);   // lane part of the output offset
     x_load(dir ? WIN - 1 : 0);
-    x_store();
+    x_store(0);
     __syncthreads();
     for (int s = 0; s < WIN; s++) {
         const int t = dir ? (WIN - 1 - s) : s;
@@ -243,7 +248,8 @@ __device__ __forceinline__ void gru_window(const GruArgs& a, int win_start, int 
             gate_set<TR>(ar, e, b_r[t2]); gate_set<TR>(az, e, b_z[t2]); gate_set<TR>(anx, e, b_in[t2]); gate_set<TR>(anh, e, b_hn[t2]);
         }
         static_assert(NKB_X % 4 == 0 && NKB_H % 4 == 0, "mma3_ring works in groups of four k-blocks");
-        mma3_ring<TR>(ar, az, anx, anh, xbuf, LDX, NKB_X, hbuf + cur * TR * LDH, LDH, NKB_H, wr, bq, lane);
+        mma3_ring<TR>(ar, az, anx, anh, xbuf + (XDB ? (s & 1) : 0) * TR * LDXD, LDX, NKB_X, hbuf + cur * TR * LDH, LDH, NKB_H, wr, bq, lane);
+        if (XDB && s + 1 < WIN) x_store((s + 1) & 1);   // that buffer was last read in step s-1: every wave is past that step's barrier
         float* hn = hbuf + nxt * TR * LDH;
         const unsigned ob = (unsigned)((t * TR * KPD + dir * HG) * 4);  // uniform byte offset of (t, direction) in the scratch
 #pragma unroll
@@ -258,8 +264,8 @@ __device__ __forceinline__ void gru_window(const GruArgs& a, int win_start, int 
         }
         cur = nxt;
         __syncthreads();
-        if (s + 1 < WIN) {
-            x_store();
+        if (!XDB && s + 1 < WIN) {
+            x_store(0);
             __syncthreads();
         }
     }
@@ -268,12 +274,12 @@ __device__ __forceinline__ void gru_window(const GruArgs& a, int win_start, int 
 template <int TR, bool SPLIT>
 __global__ __launch_bounds__(SPLIT ? 256 : 512, SPLIT ? 1 : 2) void k_gru_p2(GruArgs a) {
     extern __shared__ float smem[];
-    // per direction: hbuf [2][TR][LDH], xbuf [TR][LDXD]
+    // per direction: hbuf [2][TR][LDH], xbuf [2 (16-row form) or 1][TR][LDXD]
     constexpr int NTHR = SPLIT ? 256 : 512;
     const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);  // SGPR: bases derived from it stay scalar
     const int dir = SPLIT ? (int)(blockIdx.x & 1) : (wv >> 2), wq = wv & 3, tid_dir = tid & 255;
     constexpr int NE = TR / 2;
-    float* hbuf = smem + (SPLIT ? 0 : dir) * (2 * TR * LDH + TR * LDXD);
+    float* hbuf = smem + (SPLIT ? 0 : dir) * (2 * TR * LDH + (TR == 16 ? 2 : 1) * TR * LDXD);
     float* xbuf = hbuf + 2 * TR * LDH;
     const int tile = SPLIT ? (int)(blockIdx.x >> 1) : (int)blockIdx.x;
     int* my_flag = SPLIT ? a.pair_flags + 2 * tile + dir : nullptr;
@@ -407,7 +413,7 @@ void pack_gru(const pv_rnn_dir* dirs, int K, int KP, int TR, std::vector<float>&
     }
 }
 
-template <int TR, bool SPLIT> constexpr size_t lds_p2() { return (size_t)(SPLIT ? 1 : 2) * (2 * TR * LDH + TR * LDXD) * sizeof(float); }
+template <int TR, bool SPLIT> constexpr size_t lds_p2() { return (size_t)(SPLIT ? 1 : 2) * (2 * TR * LDH + (TR == 16 ? 2 : 1) * TR * LDXD) * sizeof(float); }
 
 }  // namespace
 

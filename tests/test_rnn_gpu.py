@@ -254,3 +254,21 @@ def test_p1_bf16_mode_chunks_large_batches():
     parts = np.concatenate([ctx.forward_p1(x[:16384]), ctx.forward_p1(x[16384:])])
     np.testing.assert_allclose(whole, parts, atol=2e-6, rtol=0)
     ctx.close()
+
+
+@pytest.mark.parametrize("B", [5, 40, 200])
+def test_p2_split_direction_form_equals_fused_form(hip_ctx, B, monkeypatch):
+    """small batches run the two directions of a tile on two CUs (hand-offs through agent-scope counters): same bits as the
+    one-workgroup form, for the 19-window loop and for the single-window operator"""
+    hip_ctx.load_p2(synth.make_weights_p2(11, 2.0))
+    y = synth.synth_p2_images(500 + B, B)
+    l1, a1 = hip_ctx.forward_p2(y, want_acc=True)                       # split form (2 * tiles <= CUs)
+    lg1, h1 = hip_ctx.forward_p2_window(y[:, :100].copy())
+    monkeypatch.setenv("PV_GRU_SPLIT", "0")
+    l0, a0 = hip_ctx.forward_p2(y, want_acc=True)
+    lg0, h0 = hip_ctx.forward_p2_window(y[:, :100].copy())
+    assert np.array_equal(l1, l0) and np.array_equal(a1.view(np.uint32), a0.view(np.uint32))
+    assert np.array_equal(lg1.view(np.uint32), lg0.view(np.uint32)) and np.array_equal(h1.view(np.uint32), h0.view(np.uint32))
+    # and run to run (the hand-off protocol is a synchronisation, not a source of non-determinism)
+    l2, a2 = hip_ctx.forward_p2(y, want_acc=True)
+    assert np.array_equal(a2.view(np.uint32), a0.view(np.uint32))
