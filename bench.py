@@ -248,7 +248,7 @@ def p2_secondary(ctx, dev):
     return out
 
 
-def single_call_secondary(ctx, dev):
+def single_call_secondary(ctx, dev, weights):
     """secondary: ONE caller's batches through pv_rnn_forward_p1_dev alone (no caller fusion, no image builder), i.e. what
     a single `run_inference -bs 512` loop sees, and the same call at 2048 and 4096 windows. Not part of `value`."""
     import torch
@@ -274,6 +274,37 @@ def single_call_secondary(ctx, dev):
                           "tflops": FLOP_PER_WINDOW * B / wall_ms / 1e9,
                           "frac_of_f32_peak": FLOP_PER_WINDOW * B / wall_ms / 1e9 / PEAK_F32_TFLOPS}
         del x, probs
+    # the reference's own way to fill a GPU from 512-window batches: callers_per_gpu independent predict loops on one device
+    # (RunInferenceArguments.py:67-74, default 4). Here: N contexts = N HIP streams, each looping over its own 512-window
+    # batches with no fusion across callers; the (tile, direction) workgroups of the callers share the CUs.
+    from pepper_thesis_amd import runtime
+    for ncall in (4, 8):
+        try:
+            ctxs = [ctx] + [runtime.Context(ctx.device_id) for _ in range(ncall - 1)]
+            for c in ctxs[1:]:
+                c.load_p1(weights)
+            xs = [torch.from_numpy(synth.synth_windows(30 + i, 512)).to(dev) for i in range(ncall)]
+            ps = [torch.zeros((512, 3), dtype=torch.float32, device=dev) for _ in range(ncall)]
+            for c, x, p in zip(ctxs, xs, ps):
+                c.forward_p1_dev(x.data_ptr(), 512, p.data_ptr())
+            for c in ctxs:
+                c.synchronize()
+            reps = 20
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                for c, x, p in zip(ctxs, xs, ps):
+                    c.forward_p1_dev(x.data_ptr(), 512, p.data_ptr())
+            for c in ctxs:
+                c.synchronize()
+            dt = time.perf_counter() - t0
+            wps = reps * ncall * 512 / dt
+            out["callers%d_x_B512" % ncall] = {"windows_per_s": wps, "ms_per_round": dt / reps * 1e3, "tflops": FLOP_PER_WINDOW * wps / 1e12,
+                                               "frac_of_f32_peak": FLOP_PER_WINDOW * wps / 1e12 / PEAK_F32_TFLOPS,
+                                               "note": "%d independent callers (contexts / streams), 512 windows per call each, no fusion" % ncall}
+            for c in ctxs[1:]:
+                c.close()
+        except Exception as e:
+            out["callers%d_x_B512" % ncall] = {"error": repr(e)}
     return out
 
 
@@ -342,7 +373,7 @@ def main(argv=None):
     from pepper_thesis_amd import runtime, synth
     from pepper_thesis_amd.batch import PRESETS, pack_regions
     from pepper_thesis_amd.device import DeviceBatch, DeviceOut, PinnedBatch
-    from pepper_thesis_amd.dist import gather_predictions
+    from pepper_thesis_amd.dist import CabiGather, gather_predictions
 
     K, W = max(1, int(args.steps)), max(0, int(args.warmup))
 
@@ -481,10 +512,21 @@ def main(argv=None):
     drain()
 
     # ---- timed region ----------------------------------------------------------------------------------
+    cabi = None
     if dist is not None:
+        if os.environ.get("PV_BENCH_GATHER", "torch") == "cabi" and backend == "nccl":
+            cabi = CabiGather(ctx, rank, world)   # the exchange through the C-ABI (pv_gather) instead of torch.distributed
+
+        def exchange(t):
+            if cabi is None:
+                return gather_predictions(t, dst=0)
+            drain()
+            rows, counts = cabi.gather(t.contiguous(), dst=0, capacity_rows=world * t.shape[0])
+            return None if rows is None else (rows, None, counts)
+
         # untimed warm-up of the one exchange step as well: the first collective of a communicator sets up its channels
         # and loads its kernels (RCCL does that lazily), which must not land inside the timed region
-        gather_predictions(probs_holder["t"].view(-1, 3), dst=0)
+        exchange(probs_holder["t"].view(-1, 3))
         dist.barrier()
     torch.cuda.synchronize()
     ctx.profile_begin()
@@ -496,7 +538,7 @@ def main(argv=None):
     gathered = None
     if dist is not None:
         drain()
-        gathered = gather_predictions(probs_holder["t"].view(-1, 3), dst=0)
+        gathered = exchange(probs_holder["t"].view(-1, 3))
     drain()
     torch.cuda.synchronize()
     if dist is not None:
@@ -537,7 +579,8 @@ def main(argv=None):
                                    "1 region (R=100200, 60x, 10 kb reads) per step, %d steps fused per launch chain" % CALLERS,
                        "batch": BATCH, "callers": CALLERS, "region_len": REGION_LEN, "depth": DEPTH,
                        "windows_per_region": n_windows_region / CALLERS, "parallelism": "region-sharded x%d" % world,
-                       "backend": backend if world > 1 else None},
+                       "backend": backend if world > 1 else None,
+                       "gather": ("pv_gather (C-ABI, RCCL)" if cabi is not None else "torch.distributed gather to rank 0") if world > 1 else None},
             "mbp_per_s": total_steps * world * REGION_LEN / 1e6 / dt,
             "roofline": {"bound": "mfma", "kernel": "k_lstm_layer<512> (decoder bi-LSTM, fused input projection + recurrence)",
                          "achieved": achieved_tf, "peak": PEAK_F32_TFLOPS, "unit": "TFLOP/s",
@@ -588,7 +631,7 @@ def main(argv=None):
                 out["config2_bf16_input_gemm"] = {"error": repr(e)}
         if secondary and not args.no_p2:
             try:
-                out["p1_single_call"] = single_call_secondary(ctx, dev)
+                out["p1_single_call"] = single_call_secondary(ctx, dev, weights)
             except Exception as e:
                 out["p1_single_call"] = {"error": repr(e)}
             try:

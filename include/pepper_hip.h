@@ -249,6 +249,26 @@ int pv_rnn_forward_p2_dev(pv_ctx* ctx, const uint8_t* d_images, int64_t B, uint8
 int pv_rnn_forward_p2_window(pv_ctx* ctx, const uint8_t* images, const float* hidden_in, int64_t B, float* logits,
                              float* hidden_out);
 
+/* ---- multi-GPU: the one exchange step ------------------------------------------------------------------------------
+ * Regions shard across ranks (interval i -> rank i % world, pepper_variant/modules/python/ImageGenerationUI.py:211) with no
+ * data-path collective; pv_gather moves every rank's per-window rows (probabilities, and whatever keys the caller packs next
+ * to them) to ONE rank over RCCL: an all-gather of the row counts, then grouped point-to-point sends to `dst` (xGMI is
+ * point-to-point: the sends of the other ranks run on different links). The reference has no counterpart (each caller process
+ * writes its own prediction file, RunInference.py:101-106; its only process-group site is
+ * pepper/modules/python/models/predict_distributed_gpu.py:124-129). RCCL (librccl.so.1) is opened with dlopen on first use.
+ * One communicator per context; the 128-byte id is made by one rank (pv_comm_unique_id) and handed to the others by the
+ * launcher (environment, file, TCP store, torch.distributed broadcast). */
+typedef struct pv_comm pv_comm;
+#define PV_COMM_ID_BYTES 128
+int pv_comm_unique_id(pv_ctx* ctx, char* id128);
+int pv_comm_create(pv_ctx* ctx, const char* id128, int rank, int world, pv_comm** out);
+void pv_comm_destroy(pv_comm* comm);
+/* Every rank passes its n_rows rows of row_bytes bytes (DEVICE memory). counts_out [world] (host, optional) receives the
+ * per-rank row counts on every rank when the call returns; on `dst` the rows arrive rank-major in d_recv (DEVICE, capacity
+ * recv_capacity_rows rows) asynchronously on `stream`; other ranks may pass NULL for d_recv. */
+int pv_gather(pv_ctx* ctx, pv_comm* comm, const void* d_send, int64_t n_rows, int row_bytes, void* d_recv,
+              int64_t recv_capacity_rows, int64_t* counts_out, int dst, void* stream);
+
 /* Diagnostic (tests, tuning): C = A . W^T + bias through the 3-term split-bf16 MFMA GEMM of PV_DTYPE_BF16_INPUT_GEMM alone.
  * HOST pointers, fp32 row-major A [M,K], W [N,K], bias [N] or NULL; C [splits][M][N] row-major (quads = 0) or [M/4][N][4]
  * (quads = 1: four consecutive rows of a column adjacent, splits = 1). M % 4 == 0, N % 256 == 0, K % (32 * splits) == 0.

@@ -160,6 +160,10 @@ SYMBOLS = [
     ("pv_rnn_forward_p2", C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
     ("pv_rnn_forward_p2_dev", C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]),
     ("pv_rnn_forward_p2_window", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
+    ("pv_comm_unique_id", C.c_int, [C.c_void_p, C.c_char_p]),
+    ("pv_comm_create", C.c_int, [C.c_void_p, C.c_char_p, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
+    ("pv_comm_destroy", None, [C.c_void_p]),
+    ("pv_gather", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_int64, C.POINTER(C.c_int64), C.c_int, C.c_void_p]),
     ("pv_debug_gemm_bf16x3", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int,
                                         C.c_void_p, C.POINTER(C.c_float)]),
     ("pv_profile_begin", C.c_int, [C.c_void_p]),

@@ -10,7 +10,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(CSRC, "libpepper_hip.so")
-SOURCES = ["pv_api.hip", "summary_kernels.hip", "rnn_kernels.hip", "rnn_gru.hip"]
+SOURCES = ["pv_api.hip", "summary_kernels.hip", "rnn_kernels.hip", "rnn_gru.hip", "pv_comm.hip"]
 HEADERS = ["pv_common.hpp", "mfma_tiles.hpp", os.path.join("..", "..", "include", "pepper_hip.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
          "-fgpu-rdc" if False else "-fno-gpu-rdc"]
@@ -55,7 +55,7 @@ def build(force=False, verbose=False):
                 print(" ".join(cmd), file=sys.stderr)
             subprocess.check_call(cmd)
     if force or _stale(LIB, objs):
-        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs + ["-ldl"]
         if verbose:
             print(" ".join(cmd), file=sys.stderr)
         subprocess.check_call(cmd)
@@ -76,7 +76,7 @@ def build_variant(name, extra_flags):
         subprocess.check_call([hipcc] + FLAGS + list(extra_flags) + ["-c", os.path.join(CSRC, src), "-o", o])
         objs.append(o)
     lib = os.path.join(vdir, "libpepper_hip_%s.so" % name)
-    subprocess.check_call([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib] + objs)
+    subprocess.check_call([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib] + objs + ["-ldl"])
     return lib
 
 

@@ -63,3 +63,67 @@ def merge_sharded(rows_per_rank: Sequence[torch.Tensor], idx_per_rank: Sequence[
         for k, i in enumerate(idx):
             out[i] = rows[k]
     return out
+
+
+class CabiGather:
+    """The same exchange through the C-ABI (pv_comm_* / pv_gather, csrc/pv_comm.hip): RCCL driven from the library itself, for
+    hosts that do not carry torch.distributed. The 128-byte communicator id is created on rank 0 and distributed by
+    `exchange_id(bytes_or_None) -> bytes` (default: torch.distributed.broadcast_object_list when a process group exists)."""
+
+    def __init__(self, ctx, rank: int, world: int, exchange_id=None):
+        import ctypes as C
+        from . import _ffi
+        self.ctx, self.rank, self.world = ctx, int(rank), int(world)
+        self.lib = _ffi.load()
+        buf = C.create_string_buffer(128)
+        if self.rank == 0:
+            _ffi.check(self.lib.pv_comm_unique_id(ctx.handle, buf))
+        uid = buf.raw if self.rank == 0 else None
+        if exchange_id is not None:
+            uid = exchange_id(uid)
+        elif self.world > 1:
+            box = [uid]
+            dist.broadcast_object_list(box, src=0)
+            uid = box[0]
+        self.handle = C.c_void_p()
+        _ffi.check(self.lib.pv_comm_create(ctx.handle, uid, self.rank, self.world, C.byref(self.handle)))
+
+    def gather(self, local: torch.Tensor, dst: int = 0, capacity_rows: Optional[int] = None, stream: int = 0):
+        """local: contiguous DEVICE tensor [n_r, ...]; returns (rows [sum n_r, ...], counts) on dst, (None, counts) elsewhere.
+        capacity_rows: rows the destination provides room for (default world * n_local: right when the ranks hold equal row
+        counts, as the region-sharded benchmark does; ragged callers pass their bound)."""
+        import ctypes as C
+        from . import _ffi
+        assert local.is_cuda and local.is_contiguous()
+        n = int(local.shape[0])
+        row_bytes = int(local[0].numel() * local.element_size()) if n else int(np_prod(local.shape[1:]) * local.element_size())
+        cap = int(capacity_rows) if capacity_rows is not None else n * self.world
+        recv = None
+        if self.rank == dst:
+            recv = torch.empty((max(cap, 1),) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+        counts = (C.c_int64 * self.world)()
+        _ffi.check(self.lib.pv_gather(self.ctx.handle, self.handle, local.data_ptr() if n else None, n, row_bytes,
+                                      recv.data_ptr() if recv is not None else None, cap, counts, int(dst), stream or None))
+        cl = [int(c) for c in counts]
+        if self.rank != dst:
+            return None, cl
+        self.ctx.synchronize() if not stream else torch.cuda.synchronize()
+        return recv[: sum(cl)], cl
+
+    def close(self):
+        if getattr(self, "handle", None):
+            self.lib.pv_comm_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def np_prod(shape) -> int:
+    out = 1
+    for s in shape:
+        out *= int(s)
+    return out

@@ -55,3 +55,18 @@ def test_predictor_loop(hip_ctx):
     got = dict(p.predict_batches([x[:10], x[10:30]]))
     assert got[1].dtype == np.float64 and got[1].shape == (20, 3)
     np.testing.assert_allclose(got[1], probs[10:30], atol=1e-6)
+
+
+@pytest.mark.gpu
+def test_pv_gather_single_rank(hip_ctx):
+    """pv_comm_* / pv_gather through RCCL with a one-rank communicator (the multi-rank form needs one GPU per rank: it is
+    exercised by bench.py --gpus N on a multi-GPU node; here: library loading, id, communicator, count exchange, own-rows copy)"""
+    import torch
+    from pepper_thesis_amd.dist import CabiGather
+    g = CabiGather(hip_ctx, 0, 1)
+    x = torch.arange(21, dtype=torch.float32, device="cuda:0").reshape(7, 3)
+    rows, counts = g.gather(x, dst=0)
+    assert counts == [7] and torch.equal(rows, x)
+    rows, counts = g.gather(x[:0].contiguous(), dst=0)
+    assert counts == [0] and rows.shape[0] == 0
+    g.close()
