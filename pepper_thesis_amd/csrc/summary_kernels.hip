@@ -29,6 +29,7 @@
 #include "pv_common.hpp"
 
 #include <cmath>
+#include <cstdlib>
 
 namespace {
 
