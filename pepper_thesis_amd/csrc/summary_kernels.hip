@@ -28,6 +28,7 @@
 // bytewise exactly as std::string operator< would compare "<type digit><bytes>".
 #include "pv_common.hpp"
 
+#include <algorithm>
 #include <cmath>
 #include <cstdlib>
 
@@ -199,7 +200,7 @@ __global__ __launch_bounds__(256) void k_cigar_scan(SumArgs a) {
             if (active && (my_ref < -(1ll << 30) || my_rd > (1ll << 30))) set_status(a.diag, PV_ERR_LIMIT);
             a.op_ref[c] = active ? (int32_t)my_ref : OP_INACTIVE;
             a.op_rd[c] = (int32_t)my_rd;
-            a.op_read[c] = (int32_t)r;
+            if (a.polish) a.op_read[c] = (int32_t)r;   // only k_polish_insert walks op -> read
             a.op_flag[c] = 0;
         }
         ref_rel += __shfl(ir, 63, 64);
@@ -252,44 +253,6 @@ __global__ __launch_bounds__(256) void k_tile_fill(SumArgs a) {
 }
 
 // ---- K2 -------------------------------------------------------------------------------------------
-struct OpCtx {  // what a lane knows about "its" op
-    int32_t ref_rel, rd, len, op;
-    int32_t col_base, R;
-    int64_t base0, seq_end;  // global index of this read's first base / one past its last
-    int64_t ref_len;
-    bool rev, active, anchor_next;
-};
-
-__device__ __forceinline__ OpCtx load_op(const SumArgs& a, int64_t c) {
-    OpCtx o;
-    o.active = false;
-    o.len = 0; o.op = 15; o.ref_rel = 0; o.rd = 0; o.col_base = 0; o.R = 0; o.base0 = 0; o.seq_end = 0;
-    o.ref_len = 0; o.rev = false; o.anchor_next = false;
-    if (c >= a.n_cigar) return o;
-    const int32_t rr = a.op_ref[c];
-    if (rr == OP_INACTIVE) return o;
-    const uint32_t w = a.in.cigar[c];
-    const int32_t r = a.op_read[c];
-    const int g = a.read_region[r];
-    o.active = true;
-    o.op = w & 0xF;
-    o.len = (int32_t)(w >> 4);
-    o.ref_rel = rr;
-    o.rd = a.op_rd[c];
-    o.col_base = (int32_t)a.in.ref_off[g];
-    o.ref_len = a.in.ref_off[g + 1] - a.in.ref_off[g];
-    o.R = (int32_t)(a.in.ref_end[g] - a.in.ref_start[g] + 1);
-    o.base0 = a.in.base_off[r];
-    o.seq_end = a.in.base_off[r + 1];
-    o.rev = (a.in.read_flags[r] & 1) != 0;
-    const bool last = (c + 1 == a.in.cigar_off[r + 1]);
-    if (!last) {
-        const int nop = a.in.cigar[c + 1] & 0xF;
-        o.anchor_next = (nop == PV_CIGAR_IN || nop == PV_CIGAR_DEL);  // :381-391
-    }
-    return o;
-}
-
 // One workgroup per TILE of TILE_COLS columns. All 21 counters of the tile live in LDS for the whole
 // kernel (ds_add instead of global atomics) and are written out once with coalesced stores, so the
 // counter planes need no memset and see no global atomics.
@@ -646,57 +609,100 @@ __global__ __launch_bounds__(1024) void k_site_scan(SumArgs a) {
     if (threadIdx.x == 0) a.blk_cnt[blockIdx.x] = n;
 }
 
-// single-block exclusive scan of n (read from device if n_ptr) int32 values; total -> *total_out (int64)
-__global__ __launch_bounds__(1024) void k_scan_i32(const int32_t* in, int32_t* out, int64_t n_fixed,
-                                                   const int64_t* n_ptr, int64_t n_cap, int64_t* total_out) {
-    __shared__ int32_t s_w[16];
-    __shared__ int64_t s_carry;
-    int64_t n = n_ptr ? *n_ptr : n_fixed;
-    if (n > n_cap) n = n_cap;
+// Single-block exclusive scans of the pipeline's small arrays (tiles, 1024-column blocks, sites). A thread owns SCAN_V
+// consecutive values per pass (8192 per pass: one pass for every array of the benchmark's 16-region batches), three
+// barriers per pass. What used to be separate one-thread kernels behind a scan (limit checks, publishing the result
+// counters) runs in the scan's last thread.
+constexpr int SCAN_V = 8;
+template <typename T>
+__device__ __forceinline__ int64_t block_excl_scan(const T* in, T* out, int64_t n, int64_t* s_w, int64_t* s_carry) {
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    if (threadIdx.x == 0) s_carry = 0;
+    if (threadIdx.x == 0) *s_carry = 0;
     __syncthreads();
-    for (int64_t b = 0; b < n; b += 1024) {
-        const int64_t i = b + threadIdx.x;
-        const int32_t v = i < n ? in[i] : 0;
-        const int32_t inc = wave_incl_scan32(v, lane);
-        if (lane == 63) s_w[wv] = inc;
-        __syncthreads();
-        int32_t woff = 0;
-        for (int k = 0; k < wv; k++) woff += s_w[k];
-        const int64_t carry = s_carry;
-        if (i < n) out[i] = (int32_t)(carry + woff + inc - v);
-        __syncthreads();
-        if (threadIdx.x == 1023) s_carry = carry + woff + inc;
-        __syncthreads();
-    }
-    if (threadIdx.x == 0 && total_out) *total_out = s_carry;
-}
-
-__global__ __launch_bounds__(1024) void k_scan_i64(const int64_t* in, int64_t* out, const int64_t* n_ptr, int64_t n_cap,
-                                                   int64_t* total_out) {
-    __shared__ int64_t s_w[16];
-    __shared__ int64_t s_carry;
-    int64_t n = *n_ptr;
-    if (n > n_cap) n = n_cap;
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    if (threadIdx.x == 0) s_carry = 0;
-    __syncthreads();
-    for (int64_t b = 0; b < n; b += 1024) {
-        const int64_t i = b + threadIdx.x;
-        const int64_t v = i < n ? in[i] : 0;
-        const int64_t inc = wave_incl_scan(v, lane);
+    for (int64_t b = 0; b < n; b += 1024 * SCAN_V) {
+        const int64_t i0 = b + (int64_t)threadIdx.x * SCAN_V;
+        T v[SCAN_V];
+        int64_t sum = 0;
+#pragma unroll
+        for (int e = 0; e < SCAN_V; e++) { v[e] = i0 + e < n ? in[i0 + e] : (T)0; sum += (int64_t)v[e]; }
+        const int64_t inc = wave_incl_scan(sum, lane);
         if (lane == 63) s_w[wv] = inc;
         __syncthreads();
         int64_t woff = 0;
         for (int k = 0; k < wv; k++) woff += s_w[k];
-        const int64_t carry = s_carry;
-        if (i < n) out[i] = carry + woff + inc - v;
+        const int64_t carry = *s_carry;
+        int64_t run = carry + woff + inc - sum;
+#pragma unroll
+        for (int e = 0; e < SCAN_V; e++) { if (i0 + e < n) out[i0 + e] = (T)run; run += (int64_t)v[e]; }
         __syncthreads();
-        if (threadIdx.x == 1023) s_carry = carry + woff + inc;
+        if (threadIdx.x == 1023) *s_carry = carry + woff + inc;
         __syncthreads();
     }
-    if (threadIdx.x == 0 && total_out) *total_out = s_carry;
+    return *s_carry;
+}
+
+// tile pair counts -> offsets, total -> diag[D_NPAIRS]; over the pair workspace: nothing is filled or walked
+__global__ __launch_bounds__(1024) void k_scan_tiles(SumArgs a) {
+    __shared__ int64_t s_w[16];
+    __shared__ int64_t s_carry;
+    const int64_t total = block_excl_scan<int32_t>(a.tile_cnt, a.tile_off, a.n_tiles, s_w, &s_carry);
+    if (total > a.max_pairs) {
+        if (threadIdx.x == 0) set_status(a.diag, PV_ERR_LIMIT);
+        for (int64_t t = threadIdx.x; t < a.n_tiles; t += 1024) a.tile_cnt[t] = 0;
+    }
+    if (threadIdx.x == 0) a.diag[D_NPAIRS] = total;
+}
+
+// sites per 1024-column block -> offsets, total -> diag[D_NSITES]
+__global__ __launch_bounds__(1024) void k_scan_blocks(SumArgs a, int64_t n_blk) {
+    __shared__ int64_t s_w[16];
+    __shared__ int64_t s_carry;
+    const int64_t total = block_excl_scan<int32_t>(a.blk_cnt, a.blk_off, n_blk, s_w, &s_carry);
+    if (threadIdx.x == 0) a.diag[D_NSITES] = total;
+}
+
+// events per site -> offsets, total -> diag[D_NEVENTS]; site / event workspace limits
+__global__ __launch_bounds__(1024) void k_scan_events(SumArgs a) {
+    __shared__ int64_t s_w[16];
+    __shared__ int64_t s_carry;
+    int64_t n = a.diag[D_NSITES];
+    if (n > a.max_sites) n = a.max_sites;
+    const int64_t total = block_excl_scan<int32_t>(a.site_nev, a.site_evoff, n, s_w, &s_carry);
+    if (threadIdx.x == 0) {
+        a.diag[D_NEVENTS] = total;
+        if (a.diag[D_NSITES] > a.max_sites || total > a.max_events) set_status(a.diag, PV_ERR_LIMIT);
+    }
+}
+
+// windows and key bytes per site -> offsets, totals -> diag[D_NOUT], diag[D_STRBYTES]; result counters of the call
+__global__ __launch_bounds__(1024) void k_scan_outputs(SumArgs a) {
+    __shared__ int64_t s_w[16];
+    __shared__ int64_t s_carry;
+    int64_t n = a.diag[D_NSITES];
+    if (n > a.max_sites) n = a.max_sites;
+    const int64_t n_out = block_excl_scan<int32_t>(a.site_nemit, a.site_outoff, n, s_w, &s_carry);
+    __syncthreads();
+    const int64_t n_str = block_excl_scan<int64_t>(a.site_strbytes, a.site_stroff, n, s_w, &s_carry);
+    if (threadIdx.x == 0) {
+        a.diag[D_NOUT] = n_out;
+        a.diag[D_STRBYTES] = n_str;
+        // (k_write_windows, the only kernel behind this one, sets no status)
+        a.d_counts[0] = n_out;
+        a.d_counts[1] = n_str;
+        a.d_counts[2] = a.diag[D_STATUS];
+        a.d_counts[3] = a.diag[D_NSITES];
+    }
+}
+
+// single-block exclusive scan of n int32 values; total -> *total_out (int64) (polisher pipeline)
+__global__ __launch_bounds__(1024) void k_scan_i32(const int32_t* in, int32_t* out, int64_t n_fixed,
+                                                   const int64_t* n_ptr, int64_t n_cap, int64_t* total_out) {
+    __shared__ int64_t s_w[16];
+    __shared__ int64_t s_carry;
+    int64_t n = n_ptr ? *n_ptr : n_fixed;
+    if (n > n_cap) n = n_cap;
+    const int64_t total = block_excl_scan<int32_t>(in, out, n, s_w, &s_carry);
+    if (threadIdx.x == 0 && total_out) *total_out = total;
 }
 
 __global__ __launch_bounds__(1024) void k_site_rank(SumArgs a) {
@@ -722,17 +728,6 @@ __global__ __launch_bounds__(1024) void k_site_rank(SumArgs a) {
     }
 }
 
-__global__ void k_check_pairs(SumArgs a) {
-    if (a.diag[D_NPAIRS] > a.max_pairs) {
-        set_status(a.diag, PV_ERR_LIMIT);
-        for (int64_t t = 0; t < a.n_tiles; t++) a.tile_cnt[t] = 0;  // nothing is filled or walked
-    }
-}
-
-__global__ void k_check_limits(SumArgs a) {
-    if (a.diag[D_NSITES] > a.max_sites || a.diag[D_NEVENTS] > a.max_events) set_status(a.diag, PV_ERR_LIMIT);
-}
-
 // ---- K5 -------------------------------------------------------------------------------------------
 __device__ __forceinline__ void push_event(const SumArgs& a, int32_t s, int64_t src, int32_t len, int type, bool rev,
                                            int kind, int flags) {
@@ -743,44 +738,63 @@ __device__ __forceinline__ void push_event(const SumArgs& a, int32_t s, int64_t 
     a.ev[(int64_t)a.site_evoff[s] + slot] = e;
 }
 
+// One WORKGROUP per read: everything that is a property of the read (region, strand, base range) is read once per wave
+// from the same addresses, a thread needs three coalesced loads per op (CIGAR word, start column, read offset) instead
+// of the thirteen dependent ones a thread-per-op walk through op -> read -> region costs, and no per-op read index exists.
 __global__ __launch_bounds__(256) void k_collect(SumArgs a) {
-    const int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (a.diag[D_STATUS] != 0) return;
-    const OpCtx o = load_op(a, c);
-    if (!o.active) return;
-    if (o.op == PV_CIGAR_IN) {
-        if (!a.op_flag[c]) return;
-        const int64_t col = (int64_t)o.col_base + o.ref_rel - 1;
-        if (a.flags[col] & 1) push_event(a, a.site_rank[col], o.base0 + o.rd - 1, o.len + 1, 2, o.rev, 1, 1);
-    } else if (o.op == PV_CIGAR_DEL) {
-        if (!a.op_flag[c]) return;
-        const int64_t anchor = (int64_t)o.ref_rel - 1;
-        const int64_t col = o.col_base + anchor;
-        int64_t L = (int64_t)o.len + 1;
-        if (anchor + L > o.ref_len) L = o.ref_len - anchor;
-        if (a.flags[col] & 1) push_event(a, a.site_rank[col], col, (int32_t)L, 3, o.rev, 2, 1);
-    } else if (o.op == PV_CIGAR_MATCH || o.op == PV_CIGAR_EQUAL || o.op == PV_CIGAR_DIFF) {
-        int64_t lo = o.ref_rel < 0 ? -(int64_t)o.ref_rel : 0;
-        int64_t hi = (int64_t)o.R - o.ref_rel;
-        if (hi > o.len) hi = o.len;
-        if (hi <= lo) return;
-        const int64_t ca = (int64_t)o.col_base + o.ref_rel + lo;      // first column
-        const int64_t cb = (int64_t)o.col_base + o.ref_rel + hi - 1;  // last column
-        const int32_t s0 = a.site_rank[ca];
-        const int32_t s1 = a.site_rank[cb] + (a.flags[cb] & 1);
-        for (int32_t s = s0; s < s1; s++) {
-            const int64_t col = a.site_col[s];
-            if (a.cnt[C_RARE * a.n_cols + col] == 0) continue;
-            const int64_t i = col - ((int64_t)o.col_base + o.ref_rel);
-            const int64_t bi = o.base0 + o.rd + i;
-            if (bi >= o.seq_end) continue;  // already reported by k_pileup
-            const int base = a.in.bases[bi];
-            if (!((double)a.in.quals[bi] >= a.p.min_snp_baseq)) continue;
-            const int refb = a.in.ref[col];
-            const bool refvalid = is_acgt(up(refb));
-            const bool rare = (refb != base) && !(refvalid && is_acgt(base));
-            const bool corr = refvalid && base != up(base) && is_acgt(up(base));
-            if (rare || corr) push_event(a, s, bi, 1, 1, o.rev, 1, (rare ? 1 : 0) | (corr ? 2 : 0));
+    const int lane = threadIdx.x;
+    const int64_t r = blockIdx.x;
+    if (r >= a.n_reads || a.diag[D_STATUS] != 0) return;
+    if (a.read_t1[r] < a.read_t0[r]) return;   // mapq 0 or outside the region: every op is inactive
+    const int g = a.read_region[r];
+    const int64_t col_base = a.in.ref_off[g];
+    const int64_t ref_len = a.in.ref_off[g + 1] - col_base;
+    const int64_t R = a.in.ref_end[g] - a.in.ref_start[g] + 1;
+    const int64_t base0 = a.in.base_off[r], seq_end = a.in.base_off[r + 1];
+    const bool rev = (a.in.read_flags[r] & 1) != 0;
+    const int64_t c0 = a.in.cigar_off[r], c1 = a.in.cigar_off[r + 1];
+    for (int64_t c = c0 + lane; c < c1; c += 256) {
+        const int32_t ref_rel = a.op_ref[c];
+        if (ref_rel == OP_INACTIVE) continue;
+        const uint32_t w = a.in.cigar[c];
+        const int op = w & 0xF;
+        const int32_t len = (int32_t)(w >> 4);
+        if (op == PV_CIGAR_IN) {
+            if (!a.op_flag[c]) continue;
+            const int64_t col = col_base + ref_rel - 1;
+            if (a.flags[col] & 1) push_event(a, a.site_rank[col], base0 + a.op_rd[c] - 1, len + 1, 2, rev, 1, 1);
+        } else if (op == PV_CIGAR_DEL) {
+            if (!a.op_flag[c]) continue;
+            const int64_t anchor = (int64_t)ref_rel - 1;
+            const int64_t col = col_base + anchor;
+            int64_t L = (int64_t)len + 1;
+            if (anchor + L > ref_len) L = ref_len - anchor;
+            if (a.flags[col] & 1) push_event(a, a.site_rank[col], col, (int32_t)L, 3, rev, 2, 1);
+        } else if (op == PV_CIGAR_MATCH || op == PV_CIGAR_EQUAL || op == PV_CIGAR_DIFF) {
+            int64_t lo = ref_rel < 0 ? -(int64_t)ref_rel : 0;
+            int64_t hi = R - ref_rel;
+            if (hi > len) hi = len;
+            if (hi <= lo) continue;
+            const int64_t ca = col_base + ref_rel + lo;      // first column
+            const int64_t cb = col_base + ref_rel + hi - 1;  // last column
+            const int32_t s0 = a.site_rank[ca];
+            const int32_t s1 = a.site_rank[cb] + (a.flags[cb] & 1);
+            if (s1 <= s0) continue;
+            const int64_t rd = a.op_rd[c];
+            for (int32_t s = s0; s < s1; s++) {
+                const int64_t col = a.site_col[s];
+                if (a.cnt[C_RARE * a.n_cols + col] == 0) continue;
+                const int64_t i = col - (col_base + ref_rel);
+                const int64_t bi = base0 + rd + i;
+                if (bi >= seq_end) continue;  // already reported by k_pileup
+                const int base = a.in.bases[bi];
+                if (!((double)a.in.quals[bi] >= a.p.min_snp_baseq)) continue;
+                const int refb = a.in.ref[col];
+                const bool refvalid = is_acgt(up(refb));
+                const bool rare = (refb != base) && !(refvalid && is_acgt(base));
+                const bool corr = refvalid && base != up(base) && is_acgt(up(base));
+                if (rare || corr) push_event(a, s, bi, 1, 1, rev, 1, (rare ? 1 : 0) | (corr ? 2 : 0));
+            }
         }
     }
 }
@@ -945,13 +959,6 @@ __global__ __launch_bounds__(64) void k_site_alleles(SumArgs a) {
             a.site_strbytes[s] = sbytes;
         }
     }
-}
-
-__global__ void k_publish_counts(SumArgs a) {
-    a.d_counts[0] = a.diag[D_NOUT];
-    a.d_counts[1] = a.diag[D_STRBYTES];
-    a.d_counts[2] = a.diag[D_STATUS];
-    a.d_counts[3] = a.diag[D_NSITES];
 }
 
 // ---- K8 -------------------------------------------------------------------------------------------
@@ -1353,12 +1360,16 @@ __global__ __launch_bounds__(256) void k_polish_chunks(SumArgs a) {
     }
 }
 
-__global__ void k_zero_diag(int64_t* diag) {
+// start of a call: the diagnostics block and the per-tile pair counters / fill cursors (one launch instead of a kernel
+// and two memsets)
+__global__ __launch_bounds__(256) void k_init(SumArgs a) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
 #ifdef PV_PSTAMPS
-    if (threadIdx.x < D_NDIAG + 8) diag[threadIdx.x] = 0;
+    if (i < D_NDIAG + 8) a.diag[i] = 0;
 #else
-    if (threadIdx.x < D_NDIAG) diag[threadIdx.x] = 0;
+    if (i < D_NDIAG) a.diag[i] = 0;
 #endif
+    if (i < a.n_tiles) { a.tile_cnt[i] = 0; a.tile_fill[i] = 0; }
 }
 
 }  // namespace
@@ -1387,7 +1398,6 @@ static int summarize_launch(pv_ctx* ctx, const pv_batch_in* in, const pv_params*
     const int64_t nc1 = n_cigar > 0 ? n_cigar : 1, nr1 = n_reads > 0 ? n_reads : 1;
     if ((rc = pv_get(ctx, "sum.op_ref", nc1, &a.op_ref))) return rc;
     if ((rc = pv_get(ctx, "sum.op_rd", nc1, &a.op_rd))) return rc;
-    if ((rc = pv_get(ctx, "sum.op_read", nc1, &a.op_read))) return rc;
     if ((rc = pv_get(ctx, "sum.op_flag", nc1, &a.op_flag))) return rc;
     if ((rc = pv_get(ctx, "sum.read_region", nr1, &a.read_region))) return rc;
     a.n_tiles = (n_cols + TILE_COLS - 1) / TILE_COLS;
@@ -1423,26 +1433,20 @@ static int summarize_launch(pv_ctx* ctx, const pv_batch_in* in, const pv_params*
     if ((rc = pv_get(ctx, "sum.diag", (size_t)D_NDIAG + 8, &a.diag))) return rc;
 
     pv_prof_scope ps_all(ctx, "summary_pipeline", st);
-    k_zero_diag<<<1, 64, 0, st>>>(a.diag);
-    PV_HIP(hipMemsetAsync(a.tile_cnt, 0, (size_t)a.n_tiles * sizeof(int32_t), st));
-    PV_HIP(hipMemsetAsync(a.tile_fill, 0, (size_t)a.n_tiles * sizeof(int32_t), st));
+    k_init<<<grid_for(std::max<int64_t>(a.n_tiles, D_NDIAG + 8), 256), 256, 0, st>>>(a);
     if (n_reads > 0) { pv_prof_scope ps(ctx, "k_cigar_scan", st); k_cigar_scan<<<grid_for(n_reads, 4), 256, 0, st>>>(a); }
-    k_scan_i32<<<1, 1024, 0, st>>>(a.tile_cnt, a.tile_off, a.n_tiles, nullptr, a.n_tiles, &a.diag[D_NPAIRS]);
-    k_check_pairs<<<1, 1, 0, st>>>(a);
+    k_scan_tiles<<<1, 1024, 0, st>>>(a);
     if (n_reads > 0) { pv_prof_scope ps(ctx, "k_tile_fill", st); k_tile_fill<<<grid_for(n_reads, 4), 256, 0, st>>>(a); }
     { pv_prof_scope ps(ctx, "k_pileup", st); k_pileup_tiles<<<(unsigned)a.n_tiles, PT_THREADS, 0, st>>>(a); }
     k_site_scan<<<(unsigned)n_blk, 1024, 0, st>>>(a);
-    k_scan_i32<<<1, 1024, 0, st>>>(a.blk_cnt, a.blk_off, n_blk, nullptr, n_blk, &a.diag[D_NSITES]);
+    k_scan_blocks<<<1, 1024, 0, st>>>(a, n_blk);
     k_site_rank<<<(unsigned)n_blk, 1024, 0, st>>>(a);
-    k_scan_i32<<<1, 1024, 0, st>>>(a.site_nev, a.site_evoff, 0, &a.diag[D_NSITES], max_sites, &a.diag[D_NEVENTS]);
-    k_check_limits<<<1, 1, 0, st>>>(a);
-    if (n_cigar > 0) { pv_prof_scope ps(ctx, "k_collect", st); k_collect<<<grid_for(n_cigar, 256), 256, 0, st>>>(a); }
+    k_scan_events<<<1, 1024, 0, st>>>(a);
+    if (n_cigar > 0 && n_reads > 0) { pv_prof_scope ps(ctx, "k_collect", st); k_collect<<<(unsigned)n_reads, 256, 0, st>>>(a); }
     const unsigned site_grid = (unsigned)(max_sites < 4096 ? (max_sites > 0 ? max_sites : 1) : 4096);
     { pv_prof_scope ps(ctx, "k_site_alleles", st); k_site_alleles<<<site_grid, 64, 0, st>>>(a); }
-    k_scan_i32<<<1, 1024, 0, st>>>(a.site_nemit, a.site_outoff, 0, &a.diag[D_NSITES], max_sites, &a.diag[D_NOUT]);
-    k_scan_i64<<<1, 1024, 0, st>>>(a.site_strbytes, a.site_stroff, &a.diag[D_NSITES], max_sites, &a.diag[D_STRBYTES]);
+    k_scan_outputs<<<1, 1024, 0, st>>>(a);
     { pv_prof_scope ps(ctx, "k_write_windows", st); k_write_windows<<<site_grid, 64, 0, st>>>(a); }
-    k_publish_counts<<<1, 1, 0, st>>>(a);
     PV_HIP(hipGetLastError());
     return PV_OK;
 }
@@ -1637,13 +1641,10 @@ static int polish_launch(pv_ctx* ctx, const pv_batch_in* in, int64_t n_reads, in
     }
 
     pv_prof_scope ps_all(ctx, "polish_pipeline", st);
-    k_zero_diag<<<1, 64, 0, st>>>(a.diag);
-    PV_HIP(hipMemsetAsync(a.tile_cnt, 0, (size_t)a.n_tiles * sizeof(int32_t), st));
-    PV_HIP(hipMemsetAsync(a.tile_fill, 0, (size_t)a.n_tiles * sizeof(int32_t), st));
+    k_init<<<grid_for(std::max<int64_t>(a.n_tiles, D_NDIAG + 8), 256), 256, 0, st>>>(a);
     PV_HIP(hipMemsetAsync(a.ins_cnt, 0, (size_t)(max_ins_rows > 0 ? max_ins_rows : 1) * 10 * sizeof(int32_t), st));
     if (n_reads > 0) { pv_prof_scope ps(ctx, "k_cigar_scan", st); k_cigar_scan<<<grid_for(n_reads, 4), 256, 0, st>>>(a); }
-    k_scan_i32<<<1, 1024, 0, st>>>(a.tile_cnt, a.tile_off, a.n_tiles, nullptr, a.n_tiles, &a.diag[D_NPAIRS]);
-    k_check_pairs<<<1, 1, 0, st>>>(a);
+    k_scan_tiles<<<1, 1024, 0, st>>>(a);
     if (n_reads > 0) { pv_prof_scope ps(ctx, "k_tile_fill", st); k_tile_fill<<<grid_for(n_reads, 4), 256, 0, st>>>(a); }
     { pv_prof_scope ps(ctx, "k_polish_tiles", st); k_polish_tiles<<<(unsigned)a.n_tiles, PT_THREADS, 0, st>>>(a); }
     k_polish_blk<<<(unsigned)n_blk, 1024, 0, st>>>(a);
