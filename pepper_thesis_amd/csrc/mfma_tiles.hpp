@@ -43,6 +43,17 @@ __device__ __forceinline__ void buf_store1(float v, __amdgpu_buffer_rsrc_t r, un
     __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, voff, soff, 0);
 }
 
+// Workgroup barrier for LDS hand-offs only. `__syncthreads()` is a workgroup-scope fence + s_barrier, and for the fence hipcc
+// drains EVERYTHING the wave has in flight (`s_waitcnt vmcnt(0) lgkmcnt(0)`): the weight fragments requested several k-blocks
+// ahead and the step's output stores, i.e. an L2 round trip per recurrent step with no MFMA issued. The per-step barriers of
+// the recurrent kernels only publish LDS tiles (h, x), so they wait for this wave's LDS operations and nothing else; global
+// data is ordered where it is handed over (end of a layer / window: a full __syncthreads() or an agent-scope hand-off).
+__device__ __forceinline__ void lds_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
+
 template <int TR> struct Gate;
 template <> struct Gate<32> { f32x16 v; };      // lane -> unit lane&31, rows (e&3) + 8*(e>>2) + 4*(lane>>5), e = 0..15
 template <> struct Gate<16> { f32x4 v[2]; };    // lane -> unit 16*t + (lane&15), rows 4*(lane>>4) + i, e = 4t + i

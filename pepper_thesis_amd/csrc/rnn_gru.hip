@@ -187,7 +187,9 @@ __device__ __forceinline__ void gru_window(const GruArgs& a, int win_start, int 
     constexpr int XR = ENC ? 1 : TR / 4;   // decoder: float4 per thread, rows tid_dir/64 + 4u
     constexpr int XE = TR / 8;             // encoder: floats per thread, rows tid_dir/32 + 8u (KPE = 32 padded features)
     f32x4 xr[XR];
-    float xe[ENC ? XE : 1];
+    unsigned xe[ENC ? XE : 1];             // raw bytes: converted when they are written to LDS, so the load is not waited for
+                                           // at the top of the step (a conversion right behind the load makes hipcc drain the
+                                           // whole vmcnt queue there, weight-fragment ring included)
     unsigned xoff[ENC ? XE : 1];           // encoder: byte offset of (row's chunk, feature k) from the tile's first chunk
     const unsigned xd_g = (unsigned)((tid_dir >> 6) * KPD + (tid_dir & 63) * 4);   // decoder: float offset in x_src[t]
     const unsigned xd_l = (unsigned)((tid_dir >> 6) * LDX + (tid_dir & 63) * 4);   // ... and in xbuf
@@ -198,7 +200,7 @@ __device__ __forceinline__ void gru_window(const GruArgs& a, int win_start, int 
         for (int u = 0; u < XE; u++) {
             int64_t r = (tid_dir >> 5) + 8 * u;
             if (b0 + r >= a.B) r = a.B - 1 - b0;
-            xoff[u] = (unsigned)(r * a.seq * FEAT) + (unsigned)(tid_dir & 31);
+            xoff[u] = (unsigned)(r * a.seq * FEAT) + (unsigned)((tid_dir & 31) < FEAT ? (tid_dir & 31) : FEAT - 1);   // padding lanes re-read feature 9
         }
     }
     const uint8_t* img0 = a.images + ((size_t)b0 * a.seq + win_start) * FEAT;  // uniform
@@ -207,7 +209,7 @@ __device__ __forceinline__ void gru_window(const GruArgs& a, int win_start, int 
         if constexpr (ENC) {
             const uint8_t* src = img0 + t * FEAT;
 #pragma unroll
-            for (int u = 0; u < XE; u++) xe[u] = xe_valid ? (float)src[xoff[u]] : 0.0f;
+            for (int u = 0; u < XE; u++) xe[u] = src[xoff[u]];
         } else {
 #pragma unroll
             for (int u = 0; u < XR; u++) xr[u] = buf_load4(xsr, xd_g * 4u, (unsigned)((t * TR + u * 4) * KPD * 4));
@@ -221,7 +223,7 @@ __device__ __forceinline__ void gru_window(const GruArgs& a, int win_start, int 
         float* xb = xbuf + (XDB ? slot : 0) * TR * LDXD;
         if constexpr (ENC) {
 #pragma unroll
-            for (int u = 0; u < XE; u++) (xb + u * 8 * LDX)[xe_l] = xe[u];
+            for (int u = 0; u < XE; u++) (xb + u * 8 * LDX)[xe_l] = xe_valid ? (float)xe[u] : 0.0f;
         } else {
 #pragma unroll
             for (int u = 0; u < XR; u++) *reinterpret_cast<f32x4*>(xb + u * 4 * LDX + xd_l) = xr[u];
@@ -263,12 +265,199 @@ __device__ __forceinline__ void gru_window(const GruArgs& a, int win_start, int 
             buf_store1(h, osr, o_l * 4u, ob + (unsigned)((elem_row<TR>(e) * KPD + elem_unit<TR>(e)) * 4));
         }
         cur = nxt;
-        __syncthreads();
+        lds_barrier();
         if (!XDB && s + 1 < WIN) {
             x_store(0);
-            __syncthreads();
+            lds_barrier();
         }
     }
+    __syncthreads();   // the window's outputs (global scratch) are read by the next phase of this workgroup
+}
+
+// ---- overlapped window form (16-row tiles, one wave per SIMD: the split form) --------------------------------------------
+// With one wave per SIMD nothing hides the cell update, the h exchange and the barrier of a step. But two thirds of a
+// decoder step's MFMAs (W_ix x_t) do not depend on h at all: the x-part of step s+1 is issued right behind the h-part of
+// step s, and the cell update of step s runs in its shadow, one element per k-block group (VALU and LDS / global stores
+// issue between the MFMAs of the matrix pipe). The packed weight stream of this form is [h-part | x-part] per step and the
+// fragment ring wraps from the x-part into the next step's h-part.
+// K blocks [KB0, KB0 + NKB) of a stream of NTOT blocks (the requests wrap around), A from one LDS tile; hook(i) runs behind
+// the MFMAs of block i. On entry bq slots 0..2 hold blocks KB0..KB0+2, on exit the three blocks behind the range.
+// D = ring depth (register sets; requests run D-1 blocks ahead): one wave per SIMD has no partner wave to cover the L2
+// round trip of a fragment, so the decoder uses 8 sets (7 blocks = 2700 MFMA cycles ahead); NTOT % D == 0 keeps a block's
+// set (stream position % D) the same across the wrap.
+template <int KB0, int NKB, int NTOT, int D, typename Hook>
+__device__ __forceinline__ void ring16(Gate<16>& g0, Gate<16>& g1, Gate<16>& g2, const float* __restrict__ A, int lda,
+                                       __amdgpu_buffer_rsrc_t wr, f32x4 (&bq)[D][3], int lane, Hook&& hook) {
+    static_assert(NTOT % D == 0 && (D & (D - 1)) == 0, "ring depth must divide the stream length");
+    const float* ap = afrag_ptr<16>(A, lda, lane);
+    const unsigned lane16 = (unsigned)lane * 16u;
+    f32x2 aq[2];
+    aq[0] = *reinterpret_cast<const f32x2*>(ap);
+#pragma unroll
+    for (int i = 0; i < NKB; i++) {
+        {   // request block i + D - 1 of this call's range (wrapping into the stream's next blocks)
+            const int kbv = (KB0 + i + D - 1) % NTOT;
+            const int slot = (KB0 + i + D - 1) % D;
+#pragma unroll
+            for (int nt = 0; nt < 3; nt++) bq[slot][nt] = buf_load4(wr, lane16, (unsigned)((kbv * 3 + nt) * 1024));
+        }
+        if (i + 1 < NKB) aq[(i + 1) & 1] = *reinterpret_cast<const f32x2*>(ap + 8 * (i + 1));
+        __builtin_amdgcn_sched_barrier(0);   // keep hipcc from sinking the prefetches next to their uses
+        {
+            const int slot = (KB0 + i) % D;
+#pragma unroll
+            for (int j = 0; j < 2; j++) {
+                gate_mma<16>(g0, aq[i & 1], bq[slot][0], j);
+                gate_mma<16>(g1, aq[i & 1], bq[slot][1], j);
+                gate_mma<16>(g2, aq[i & 1], bq[slot][2], j);
+            }
+        }
+        hook(i);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+template <int KP, bool ENC>
+__device__ __forceinline__ void gru_window_ovl(const GruArgs& a, int win_start, int dir, int wq, int lane, int tid_dir,
+                                               int64_t b0, float* xbuf, float* hbuf, int& cur, float (&hst)[8],
+                                               const float* wp, const float* bias, const float* x_src, float* out_dst) {
+    constexpr int TR = 16;
+    constexpr int LDX = KP + 4;
+    constexpr int NKB_X = KP / 8, NKB_H = HG / 8, NTOT = NKB_X + NKB_H;
+    constexpr int NE = 8;
+    const int unit = 32 * wq + lane_unit<TR>(lane);
+    float b_r[2], b_z[2], b_in[2], b_hn[2];
+#pragma unroll
+    for (int t = 0; t < 2; t++) {
+        b_r[t] = bias[0 * HG + unit + 16 * t]; b_z[t] = bias[1 * HG + unit + 16 * t];
+        b_in[t] = bias[2 * HG + unit + 16 * t]; b_hn[t] = bias[3 * HG + unit + 16 * t];
+    }
+    constexpr int XR = ENC ? 1 : TR / 4;   // decoder: float4 per thread, rows tid_dir/64 + 4u
+    constexpr int XE = TR / 8;             // encoder: floats per thread, rows tid_dir/32 + 8u
+    f32x4 xr[XR];
+    unsigned xe[ENC ? XE : 1];             // raw bytes: converted when they are written to LDS, so the load is not waited for
+                                           // at the top of the step (a conversion right behind the load makes hipcc drain the
+                                           // whole vmcnt queue there, weight-fragment ring included)
+    unsigned xoff[ENC ? XE : 1];
+    const unsigned xd_g = (unsigned)((tid_dir >> 6) * KPD + (tid_dir & 63) * 4);
+    const unsigned xd_l = (unsigned)((tid_dir >> 6) * LDX + (tid_dir & 63) * 4);
+    const unsigned xe_l = (unsigned)((tid_dir >> 5) * LDX + (tid_dir & 31));
+    const bool xe_valid = (tid_dir & 31) < FEAT;
+    if constexpr (ENC) {
+#pragma unroll
+        for (int u = 0; u < XE; u++) {
+            int64_t r = (tid_dir >> 5) + 8 * u;
+            if (b0 + r >= a.B) r = a.B - 1 - b0;
+            xoff[u] = (unsigned)(r * a.seq * FEAT) + (unsigned)((tid_dir & 31) < FEAT ? (tid_dir & 31) : FEAT - 1);   // padding lanes re-read feature 9
+        }
+    }
+    const uint8_t* img0 = a.images + ((size_t)b0 * a.seq + win_start) * FEAT;  // uniform
+    const __amdgpu_buffer_rsrc_t wr = make_rsrc(wp), xsr = make_rsrc(ENC ? (const void*)wp : (const void*)x_src), osr = make_rsrc(out_dst);
+    auto x_load = [&](int s) {   // the input of step s (time index by direction)
+        const int t = dir ? (WIN - 1 - s) : s;
+        if constexpr (ENC) {
+            const uint8_t* src = img0 + t * FEAT;
+#pragma unroll
+            for (int u = 0; u < XE; u++) xe[u] = src[xoff[u]];
+        } else {
+#pragma unroll
+            for (int u = 0; u < XR; u++) xr[u] = buf_load4(xsr, xd_g * 4u, (unsigned)((t * TR + u * 4) * KPD * 4));
+        }
+    };
+    auto x_store = [&](int slot) {
+        float* xb = xbuf + slot * TR * LDXD;
+        if constexpr (ENC) {
+#pragma unroll
+            for (int u = 0; u < XE; u++) (xb + u * 8 * LDX)[xe_l] = xe_valid ? (float)xe[u] : 0.0f;
+        } else {
+#pragma unroll
+            for (int u = 0; u < XR; u++) *reinterpret_cast<f32x4*>(xb + u * 4 * LDX + xd_l) = xr[u];
+        }
+    };
+    constexpr int D = NTOT % 8 == 0 ? 8 : 4;   // decoder: 48 blocks per step, 8 register sets; encoder: 20 blocks, 4 sets
+    f32x4 bq[D][3];  // the ring starts with the first x-part blocks (the prologue runs the x-part of step 0)
+#pragma unroll
+    for (int q = 0; q < D - 1; q++)
+#pragma unroll
+        for (int nt = 0; nt < 3; nt++)
+            bq[(NKB_H + q) % D][nt] = buf_load4(wr, (unsigned)lane * 16u, (unsigned)((((NKB_H + q) % NTOT) * 3 + nt) * 1024));
+    const unsigned h_l = (unsigned)(lane_row<TR>(lane) * LDH + unit);
+    const unsigned o_l = (unsigned)(lane_row<TR>(lane) * KPD + unit);
+    auto nohook = [](int) {};
+    // prologue: x_0 and x_1 into the two slots, x-part of step 0
+    x_load(0);
+    x_store(0);
+    x_load(1);
+    x_store(1);
+    __syncthreads();
+    Gate<TR> xr_, xz_, xn_;   // x-part (+ biases) of the CURRENT step
+#pragma unroll
+    for (int e = 0; e < NE; e++) { gate_set<TR>(xr_, e, b_r[e >> 2]); gate_set<TR>(xz_, e, b_z[e >> 2]); gate_set<TR>(xn_, e, b_in[e >> 2]); }
+    ring16<NKB_H, NKB_X, NTOT, D>(xr_, xz_, xn_, xbuf, LDX, wr, bq, lane, nohook);
+#ifdef PV_GRU_STAMPS
+    unsigned long long st0, st1, acc_t[4] = {0, 0, 0, 0};
+#define GSTAMP(i) { asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st1) :: "memory"); acc_t[i] += st1 - st0; st0 = st1; }
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st0) :: "memory");
+#else
+#define GSTAMP(i)
+#endif
+    for (int s = 0; s < WIN; s++) {
+        const int t = dir ? (WIN - 1 - s) : s;
+        const int nxt = cur ^ 1;
+        if (s + 2 < WIN) x_load(s + 2);
+        GSTAMP(0)
+        Gate<TR> hr, hz, hn_;   // h-part of this step
+#pragma unroll
+        for (int e = 0; e < NE; e++) { gate_set<TR>(hr, e, 0.0f); gate_set<TR>(hz, e, 0.0f); gate_set<TR>(hn_, e, b_hn[e >> 2]); }
+        ring16<0, NKB_H, NTOT, D>(hr, hz, hn_, hbuf + cur * TR * LDH, LDH, wr, bq, lane, nohook);
+        GSTAMP(1)
+        float* hnx = hbuf + nxt * TR * LDH;
+        const unsigned ob = (unsigned)((t * TR * KPD + dir * HG) * 4);
+        auto cell = [&](int e) {
+            const float rg = sigmoidf_(gate_get<TR>(xr_, e) + gate_get<TR>(hr, e));
+            const float zg = sigmoidf_(gate_get<TR>(xz_, e) + gate_get<TR>(hz, e));
+            const float ng = tanhf_(gate_get<TR>(xn_, e) + rg * gate_get<TR>(hn_, e));
+            const float h = (1.0f - zg) * ng + zg * hst[e];
+            hst[e] = h;
+            (hnx + elem_row<TR>(e) * LDH + elem_unit<TR>(e))[h_l] = h;
+            buf_store1(h, osr, o_l * 4u, ob + (unsigned)((elem_row<TR>(e) * KPD + elem_unit<TR>(e)) * 4));
+        };
+        if (s + 1 < WIN) {
+            Gate<TR> nr, nz, nn;   // x-part of the NEXT step, issued now; the cell update of this step runs behind its MFMAs
+#pragma unroll
+            for (int e = 0; e < NE; e++) { gate_set<TR>(nr, e, b_r[e >> 2]); gate_set<TR>(nz, e, b_z[e >> 2]); gate_set<TR>(nn, e, b_in[e >> 2]); }
+            constexpr int EPB = NKB_X >= NE ? 1 : NE / NKB_X;   // elements per hooked block
+            constexpr int STRIDE = NKB_X >= NE ? NKB_X / NE : 1; // hooked block every STRIDE blocks
+            ring16<NKB_H, NKB_X, NTOT, D>(nr, nz, nn, xbuf + ((s + 1) & 1) * TR * LDXD, LDX, wr, bq, lane, [&](int i) {
+                if (i % STRIDE == 0) {
+#pragma unroll
+                    for (int q = 0; q < EPB; q++) cell((i / STRIDE) * EPB + q);
+                    // the slice's ~40 vector instructions per element go BETWEEN the block's 12 MFMAs (an MFMA occupies the matrix
+                    // pipe for 32 cycles and vector issue for 8 of them): one MFMA, then a few VALU, twelve times
+#pragma unroll
+                    for (int g = 0; g < 12; g++) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);            // 1 MFMA
+                        __builtin_amdgcn_sched_group_barrier(0x002, 4 * EPB, 0);      // VALU of the cell slice
+                    }
+                }
+            });
+            xr_ = nr; xz_ = nz; xn_ = nn;
+        } else {
+#pragma unroll
+            for (int e = 0; e < NE; e++) cell(e);
+        }
+        GSTAMP(2)
+        if (s + 2 < WIN) x_store(s & 1);   // x_{s+2} into the slot x_s left
+        cur = nxt;
+        lds_barrier();
+        GSTAMP(3)
+    }
+#ifdef PV_GRU_STAMPS
+    if (a.pair_flags && blockIdx.x == 0 && threadIdx.x == 0)
+        for (int i = 0; i < 4; i++) atomicAdd((unsigned long long*)(a.pair_flags + 64) + (ENC ? 0 : 4) + i, acc_t[i]);
+#endif
+#undef GSTAMP
+    __syncthreads();   // the window's outputs (global scratch) are read by the next phase (after the hand-off)
 }
 
 template <int TR, bool SPLIT>
@@ -315,10 +504,12 @@ __global__ __launch_bounds__(SPLIT ? 256 : 512, SPLIT ? 1 : 2) void k_gru_p2(Gru
 
     for (int w = 0; w < a.nwin; w++) {
         const int ws = w * JUMP;
-        gru_window<TR, KPE, true>(a, ws, dir, wq, lane, tid_dir, b0, xbuf, hbuf, cur, hst, enc_wp, enc_bias, nullptr, enc_out);
+        if constexpr (SPLIT) gru_window_ovl<KPE, true>(a, ws, dir, wq, lane, tid_dir, b0, xbuf, hbuf, cur, hst, enc_wp, enc_bias, nullptr, enc_out);
+        else gru_window<TR, KPE, true>(a, ws, dir, wq, lane, tid_dir, b0, xbuf, hbuf, cur, hst, enc_wp, enc_bias, nullptr, enc_out);
         if constexpr (SPLIT) pair_handoff(my_flag, their_flag, ++handoffs, tid);   // both halves of the encoder output are there
         // decoder h0 = encoder final state of the same direction: hst / hbuf[cur] simply carry over
-        gru_window<TR, KPD, false>(a, ws, dir, wq, lane, tid_dir, b0, xbuf, hbuf, cur, hst, dec_wp, dec_bias, enc_out, dec_out);
+        if constexpr (SPLIT) gru_window_ovl<KPD, false>(a, ws, dir, wq, lane, tid_dir, b0, xbuf, hbuf, cur, hst, dec_wp, dec_bias, enc_out, dec_out);
+        else gru_window<TR, KPD, false>(a, ws, dir, wq, lane, tid_dir, b0, xbuf, hbuf, cur, hst, dec_wp, dec_bias, enc_out, dec_out);
         if constexpr (SPLIT) pair_handoff(my_flag, their_flag, ++handoffs, tid);   // both halves of the decoder output; the partner is
                                                                                     // done reading the encoder output as well
         // dense1 + softmax + accumulate over the window (predict.py:70-89); TR*100 (row, t) pairs. Split form: the workgroup of
@@ -381,7 +572,8 @@ __global__ __launch_bounds__(SPLIT ? 256 : 512, SPLIT ? 1 : 2) void k_gru_p2(Gru
 //  32-row form: lane -> gate column 32w + (lane&31), the four values are k = 8kb + 4*(lane>>5) + j, j = 0..3
 //  16-row form: lane -> gate columns 32w + (lane&15) (tile 0) and 32w + 16 + (lane&15) (tile 1),
 //               the four values are {tile0 j0, tile0 j1, tile1 j0, tile1 j1} with k = 8kb + 2*(lane>>4) + j
-void pack_gru(const pv_rnn_dir* dirs, int K, int KP, int TR, std::vector<float>& wp, std::vector<float>& bias) {
+// hx_order: the stream starts with the h-part k-blocks ([h | x], the order of the overlapped window form) instead of [x | h]
+void pack_gru(const pv_rnn_dir* dirs, int K, int KP, int TR, std::vector<float>& wp, std::vector<float>& bias, bool hx_order = false) {
     const int nkb = (KP + HG) / 8;
     wp.assign((size_t)2 * 4 * nkb * 3 * 256, 0.0f);
     bias.assign((size_t)2 * 4 * HG, 0.0f);
@@ -393,6 +585,7 @@ void pack_gru(const pv_rnn_dir* dirs, int K, int KP, int TR, std::vector<float>&
             bias[(size_t)d * 4 * HG + 3 * HG + u] = dirs[d].b_hh[2 * HG + u];
         }
         auto wval = [&](int n, int k) -> float {
+            if (hx_order) k = k < HG ? KP + k : k - HG;   // stream position -> position in [x | h]
             if (k < KP) return k < K ? dirs[d].w_ih[(size_t)n * K + k] : 0.0f;
             return dirs[d].w_hh[(size_t)n * HG + (k - KP)];
         };
@@ -418,8 +611,8 @@ template <int TR, bool SPLIT> constexpr size_t lds_p2() { return (size_t)(SPLIT 
 }  // namespace
 
 struct pv_rnn_p2 {
-    float* enc_wp[2] = {nullptr, nullptr};  // [0] 32-row tile form, [1] 16-row tile form
-    float* dec_wp[2] = {nullptr, nullptr};
+    float* enc_wp[3] = {nullptr, nullptr, nullptr};  // [0] 32-row tile form, [1] 16-row tile form, [2] 16-row form in [h | x] order (split form)
+    float* dec_wp[3] = {nullptr, nullptr, nullptr};
     float* enc_bias = nullptr; float* dec_bias = nullptr;
     float* dense_w = nullptr; float* dense_b = nullptr;
     std::vector<void*> owned;
@@ -457,11 +650,11 @@ extern "C" int pv_rnn_load_p2(pv_ctx* ctx, const pv_weights_p2* w, int dtype) {
     ctx->p2 = m;
     std::vector<float> wp, bias;
     int rc;
-    for (int f = 0; f < 2; f++) {
-        pack_gru(w->encoder, FEAT, KPE, f ? 16 : 32, wp, bias);
+    for (int f = 0; f < 3; f++) {
+        pack_gru(w->encoder, FEAT, KPE, f ? 16 : 32, wp, bias, f == 2);
         if ((rc = up2(wp.data(), wp.size(), &m->enc_wp[f], m->owned))) return rc;
         if (!f && (rc = up2(bias.data(), bias.size(), &m->enc_bias, m->owned))) return rc;
-        pack_gru(w->decoder, KPD, KPD, f ? 16 : 32, wp, bias);
+        pack_gru(w->decoder, KPD, KPD, f ? 16 : 32, wp, bias, f == 2);
         if ((rc = up2(wp.data(), wp.size(), &m->dec_wp[f], m->owned))) return rc;
         if (!f && (rc = up2(bias.data(), bias.size(), &m->dec_bias, m->owned))) return rc;
     }
@@ -501,8 +694,9 @@ static int p2_launch(pv_ctx* ctx, const uint8_t* d_images, int64_t B, uint8_t* d
     if (const char* e = getenv("PV_GRU_SPLIT")) split = split && atoi(e) != 0;
     g.pair_flags = nullptr;
     if (split) {
-        if ((rc = pv_get(ctx, "p2.pair_flags", (size_t)2 * n_tiles, &g.pair_flags))) return rc;
-        PV_HIP(hipMemsetAsync(g.pair_flags, 0, (size_t)2 * n_tiles * sizeof(int), st));
+        g.enc_wp = m->enc_wp[2]; g.dec_wp = m->dec_wp[2];   // [h | x] stream order of the overlapped window form
+        if ((rc = pv_get(ctx, "p2.pair_flags", (size_t)2 * n_tiles + 96, &g.pair_flags))) return rc;
+        PV_HIP(hipMemsetAsync(g.pair_flags, 0, ((size_t)2 * n_tiles + 96) * sizeof(int), st));
     }
     {
         pv_prof_scope ps(ctx, "k_gru_p2", st);
@@ -574,3 +768,14 @@ extern "C" int pv_rnn_forward_p2_window(pv_ctx* ctx, const uint8_t* images, cons
     PV_HIP(hipStreamSynchronize(st));
     return PV_OK;
 }
+
+#ifdef PV_GRU_STAMPS
+// diagnostic build only: phase cycle sums of workgroup 0 / wave 0 of the last split-form launch (tools/bench_gru.py prints them)
+extern "C" int pv_debug_read_gru_stamps(pv_ctx* ctx, unsigned long long* out8) {
+    int* d = nullptr;
+    if (pv_get(ctx, "p2.pair_flags", 8, &d)) return PV_ERR_HIP;
+    PV_HIP(hipDeviceSynchronize());
+    PV_HIP(hipMemcpy(out8, d + 64, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    return PV_OK;
+}
+#endif

@@ -219,7 +219,8 @@ __global__ __launch_bounds__(512, 2) void k_lstm_layer(LstmArgs a) {
     constexpr int XR = INT8 ? 1 : TR * V4 / NTHR;         // decoder: float4 per thread, rows tid/128 + 4u
     constexpr int XI = INT8 ? TR * KP / NTHR : 1;         // encoder: floats per thread, rows tid/32 + 16u
     f32x4 xr[XR];
-    float xi[XI];
+    unsigned xi[XI];                                      // raw bytes: converted when written to LDS (a conversion right behind
+                                                          // the load would make hipcc drain the vmcnt queue, ring included, per step)
     int xoff[XI];                                         // encoder: offset of (row's window, feature k) from the tile's first window
                                                           // (negative when a 16-row half tile lies wholly beyond B)
     // the decoder input is padded to whole 32-row tiles (rows beyond B replicate row B-1): no clamp, and the address is
@@ -237,7 +238,7 @@ __global__ __launch_bounds__(512, 2) void k_lstm_layer(LstmArgs a) {
         for (int u = 0; u < XI; u++) {
             int64_t r = (tid >> 5) + 16 * u;
             if (b0 + r >= a.B) r = a.B - 1 - b0;   // rows beyond B replicate row B-1 (finite values; never stored to the caller)
-            xoff[u] = (int)(r * T_STEPS * F_IN) + (tid & 31);
+            xoff[u] = (int)(r * T_STEPS * F_IN) + ((tid & 31) < F_IN ? (tid & 31) : F_IN - 1);   // padding lanes re-read feature 25
         }
     }
     const int8_t* img0 = a.x_i8 + (size_t)b0 * T_STEPS * F_IN;  // uniform
@@ -245,7 +246,7 @@ __global__ __launch_bounds__(512, 2) void k_lstm_layer(LstmArgs a) {
         if constexpr (INT8) {
             const int8_t* src = img0 + t * F_IN;
 #pragma unroll
-            for (int u = 0; u < XI; u++) xi[u] = xe_valid ? (float)src[xoff[u]] : 0.0f;
+            for (int u = 0; u < XI; u++) xi[u] = (unsigned)(int)src[xoff[u]];
         } else {
 #pragma unroll
             for (int u = 0; u < XR; u++) xr[u] = PV_XLOAD(xsr, xg_l, (unsigned)(((u * (NTHR / V4)) * T_STEPS + t) * KP * 4));
@@ -254,7 +255,7 @@ __global__ __launch_bounds__(512, 2) void k_lstm_layer(LstmArgs a) {
     auto x_store = [&]() {
         if constexpr (INT8) {
 #pragma unroll
-            for (int u = 0; u < XI; u++) (xbuf + u * 16 * LDX)[xe_l] = xi[u];
+            for (int u = 0; u < XI; u++) (xbuf + u * 16 * LDX)[xe_l] = xe_valid ? (float)(int)xi[u] : 0.0f;
         } else {
 #pragma unroll
             for (int u = 0; u < XR; u++) *reinterpret_cast<f32x4*>(xbuf + u * (NTHR / V4) * LDX + xl_l) = xr[u];
@@ -298,10 +299,10 @@ __global__ __launch_bounds__(512, 2) void k_lstm_layer(LstmArgs a) {
             if (a.out_split)   // row (t, b), element dir*H + unit
                 split8_store(h, ssr, sg_l, (unsigned)(((size_t)t * a.Bp + elem_row<TR>(e)) * 2 * H * 4 + split8_off(dir * H + elem_unit<TR>(e))));
         }
-        __syncthreads();  // everyone is done reading xbuf / hbuf[cur]; hbuf[nxt] is complete
+        lds_barrier();  // everyone is done reading xbuf / hbuf[cur]; hbuf[nxt] is complete (LDS only: mfma_tiles.hpp)
         if (s + 1 < T_STEPS) {
             x_store();
-            __syncthreads();
+            lds_barrier();
         }
     }
 }
@@ -368,9 +369,9 @@ __global__ __launch_bounds__(256, 1) void k_head_splitk(HeadArgs a) {
         if (st + 1 < a.steps_per_split) a_load(t + 1);
         mma_stream_ringb<32, 4>(acc, abuf, LDA, KC / 8, wr, t * (KC / 8), bq, lane);
         if (st + 1 < a.steps_per_split) {
-            __syncthreads();  // every wave is done reading abuf
+            lds_barrier();  // every wave is done reading abuf
             a_store();
-            __syncthreads();
+            lds_barrier();
         }
     }
     float* dst = a.part + (size_t)split * a.B * HEAD_N;
@@ -757,7 +758,7 @@ __global__ __launch_bounds__(512, 2) void k_lstm_rec_g(RecArgs a) {
             // row b, element k = t*512 + dir*256 + unit: flattened [t][512] = K index of linear_1
             split8_store(h, ssr, sg_l, (unsigned)(rr * T_STEPS * 2 * H * 4) + split8_off((unsigned)(t * 2 * H + dir * H + UW * wv)));
         }
-        __syncthreads();
+        lds_barrier();
     }
 }
 

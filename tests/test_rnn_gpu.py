@@ -258,8 +258,10 @@ def test_p1_bf16_mode_chunks_large_batches():
 
 @pytest.mark.parametrize("B", [5, 40, 200])
 def test_p2_split_direction_form_equals_fused_form(hip_ctx, B, monkeypatch):
-    """small batches run the two directions of a tile on two CUs (hand-offs through agent-scope counters): same bits as the
-    one-workgroup form, for the 19-window loop and for the single-window operator"""
+    """small batches run the two directions of a tile on two CUs (hand-offs through agent-scope counters) with the x-part of
+    step s+1 issued behind step s (x- and h-products in separate accumulators, so sums round differently from the
+    one-workgroup form): agreement to 1e-5 on logits / accumulated softmax, equal labels away from ties, and bit-identical run
+    to run, for the 19-window loop and for the single-window operator"""
     hip_ctx.load_p2(synth.make_weights_p2(11, 2.0))
     y = synth.synth_p2_images(500 + B, B)
     l1, a1 = hip_ctx.forward_p2(y, want_acc=True)                       # split form (2 * tiles <= CUs)
@@ -267,8 +269,13 @@ def test_p2_split_direction_form_equals_fused_form(hip_ctx, B, monkeypatch):
     monkeypatch.setenv("PV_GRU_SPLIT", "0")
     l0, a0 = hip_ctx.forward_p2(y, want_acc=True)
     lg0, h0 = hip_ctx.forward_p2_window(y[:, :100].copy())
-    assert np.array_equal(l1, l0) and np.array_equal(a1.view(np.uint32), a0.view(np.uint32))
-    assert np.array_equal(lg1.view(np.uint32), lg0.view(np.uint32)) and np.array_equal(h1.view(np.uint32), h0.view(np.uint32))
+    np.testing.assert_allclose(a1, a0, atol=1e-5, rtol=0)
+    np.testing.assert_allclose(lg1, lg0, atol=1e-5, rtol=0)
+    np.testing.assert_allclose(h1, h0, atol=1e-5, rtol=0)
+    top2 = np.sort(a0, axis=2)
+    clear = (top2[..., -1] - top2[..., -2]) > 1e-4
+    assert np.array_equal(l1[clear], l0[clear])
     # and run to run (the hand-off protocol is a synchronisation, not a source of non-determinism)
+    monkeypatch.delenv("PV_GRU_SPLIT")
     l2, a2 = hip_ctx.forward_p2(y, want_acc=True)
-    assert np.array_equal(a2.view(np.uint32), a0.view(np.uint32))
+    assert np.array_equal(a2.view(np.uint32), a1.view(np.uint32)) and np.array_equal(l2, l1)

@@ -31,3 +31,15 @@ ms = prof["k_gru_p2"][0] / prof["k_gru_p2"][1]
 flop = 80_435_200 * 19 * B
 print("B=%d chunks: %.2f ms -> %.0f chunks/s, %.0f 100-col windows/s, %.2f TFLOP/s (fp32 peak 157.3)" %
       (B, ms, B / ms * 1e3, 19 * B / ms * 1e3, flop / ms / 1e9))
+
+if os.environ.get("PV_GRU_STAMPS"):
+    import ctypes as C
+    from pepper_thesis_amd import _ffi
+    lib = C.CDLL(_ffi.LIB_PATH)
+    out = (C.c_ulonglong * 8)()
+    lib.pv_debug_read_gru_stamps.argtypes = [C.c_void_p, C.c_void_p]
+    assert lib.pv_debug_read_gru_stamps(ctx.handle, out) == 0
+    names = ["x_load issue", "h-part", "x-part + cell", "x_store + barrier"]
+    for lay, off in (("encoder", 0), ("decoder", 4)):
+        tot = sum(out[off + i] for i in range(4))
+        print(lay, "cycles per step (last launch, wave 0 of workgroup 0):", {n: round(out[off + i] / 1900.0) for i, n in enumerate(names)}, "total", round(tot / 1900.0))
