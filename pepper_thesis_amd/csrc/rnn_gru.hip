@@ -303,17 +303,22 @@ __device__ __forceinline__ void ring16(Gate<16>& g0, Gate<16>& g1, Gate<16>& g2,
         }
         if (i + 1 < NKB) aq[(i + 1) & 1] = *reinterpret_cast<const f32x2*>(ap + 8 * (i + 1));
         __builtin_amdgcn_sched_barrier(0);   // keep hipcc from sinking the prefetches next to their uses
-        {
+        {   // gate by gate (4 MFMAs each); hook(i, third) places a third of a cell-update slice behind each group, so its
+            // vector instructions issue while the group's MFMAs occupy the matrix pipe
             const int slot = (KB0 + i) % D;
 #pragma unroll
-            for (int j = 0; j < 2; j++) {
-                gate_mma<16>(g0, aq[i & 1], bq[slot][0], j);
-                gate_mma<16>(g1, aq[i & 1], bq[slot][1], j);
-                gate_mma<16>(g2, aq[i & 1], bq[slot][2], j);
-            }
+            for (int j = 0; j < 2; j++) gate_mma<16>(g0, aq[i & 1], bq[slot][0], j);
+            hook(i, 0);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int j = 0; j < 2; j++) gate_mma<16>(g1, aq[i & 1], bq[slot][1], j);
+            hook(i, 1);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int j = 0; j < 2; j++) gate_mma<16>(g2, aq[i & 1], bq[slot][2], j);
+            hook(i, 2);
+            __builtin_amdgcn_sched_barrier(0);
         }
-        hook(i);
-        __builtin_amdgcn_sched_barrier(0);
     }
 }
 
@@ -383,7 +388,7 @@ __device__ __forceinline__ void gru_window_ovl(const GruArgs& a, int win_start, 
             bq[(NKB_H + q) % D][nt] = buf_load4(wr, (unsigned)lane * 16u, (unsigned)((((NKB_H + q) % NTOT) * 3 + nt) * 1024));
     const unsigned h_l = (unsigned)(lane_row<TR>(lane) * LDH + unit);
     const unsigned o_l = (unsigned)(lane_row<TR>(lane) * KPD + unit);
-    auto nohook = [](int) {};
+    auto nohook = [](int, int) {};
     // prologue: x_0 and x_1 into the two slots, x-part of step 0
     x_load(0);
     x_store(0);
@@ -413,31 +418,36 @@ __device__ __forceinline__ void gru_window_ovl(const GruArgs& a, int win_start, 
         GSTAMP(1)
         float* hnx = hbuf + nxt * TR * LDH;
         const unsigned ob = (unsigned)((t * TR * KPD + dir * HG) * 4);
-        auto cell = [&](int e) {
-            const float rg = sigmoidf_(gate_get<TR>(xr_, e) + gate_get<TR>(hr, e));
-            const float zg = sigmoidf_(gate_get<TR>(xz_, e) + gate_get<TR>(hz, e));
-            const float ng = tanhf_(gate_get<TR>(xn_, e) + rg * gate_get<TR>(hn_, e));
-            const float h = (1.0f - zg) * ng + zg * hst[e];
-            hst[e] = h;
-            (hnx + elem_row<TR>(e) * LDH + elem_unit<TR>(e))[h_l] = h;
-            buf_store1(h, osr, o_l * 4u, ob + (unsigned)((elem_row<TR>(e) * KPD + elem_unit<TR>(e)) * 4));
+        // the cell update of one element in three parts (state in c_r, c_z, c_n), so that each part fits behind one gate
+        // group of MFMAs
+        float c_r = 0.0f, c_z = 0.0f, c_n = 0.0f;
+        auto cell3 = [&](int e, int third) {
+            if (third == 0) {
+                c_r = sigmoidf_(gate_get<TR>(xr_, e) + gate_get<TR>(hr, e));
+                c_z = __expf(-(gate_get<TR>(xz_, e) + gate_get<TR>(hz, e)));
+            } else if (third == 1) {
+                c_z = rcpf_(1.0f + c_z);
+                c_n = tanhf_(gate_get<TR>(xn_, e) + c_r * gate_get<TR>(hn_, e));
+            } else {
+                const float h = (1.0f - c_z) * c_n + c_z * hst[e];
+                hst[e] = h;
+                (hnx + elem_row<TR>(e) * LDH + elem_unit<TR>(e))[h_l] = h;
+                buf_store1(h, osr, o_l * 4u, ob + (unsigned)((elem_row<TR>(e) * KPD + elem_unit<TR>(e)) * 4));
+            }
         };
+        auto cell = [&](int e) { cell3(e, 0); cell3(e, 1); cell3(e, 2); };
         if (s + 1 < WIN) {
             Gate<TR> nr, nz, nn;   // x-part of the NEXT step, issued now; the cell update of this step runs behind its MFMAs
 #pragma unroll
             for (int e = 0; e < NE; e++) { gate_set<TR>(nr, e, b_r[e >> 2]); gate_set<TR>(nz, e, b_z[e >> 2]); gate_set<TR>(nn, e, b_in[e >> 2]); }
             constexpr int EPB = NKB_X >= NE ? 1 : NE / NKB_X;   // elements per hooked block
             constexpr int STRIDE = NKB_X >= NE ? NKB_X / NE : 1; // hooked block every STRIDE blocks
-            ring16<NKB_H, NKB_X, NTOT, D>(nr, nz, nn, xbuf + ((s + 1) & 1) * TR * LDXD, LDX, wr, bq, lane, [&](int i) {
+            ring16<NKB_H, NKB_X, NTOT, D>(nr, nz, nn, xbuf + ((s + 1) & 1) * TR * LDXD, LDX, wr, bq, lane, [&](int i, int third) {
                 if (i % STRIDE == 0) {
-#pragma unroll
-                    for (int q = 0; q < EPB; q++) cell((i / STRIDE) * EPB + q);
-                    // the slice's ~40 vector instructions per element go BETWEEN the block's 12 MFMAs (an MFMA occupies the matrix
-                    // pipe for 32 cycles and vector issue for 8 of them): one MFMA, then a few VALU, twelve times
-#pragma unroll
-                    for (int g = 0; g < 12; g++) {
-                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);            // 1 MFMA
-                        __builtin_amdgcn_sched_group_barrier(0x002, 4 * EPB, 0);      // VALU of the cell slice
+                    if constexpr (EPB == 1) {
+                        cell3(i / STRIDE, third);
+                    } else {   // encoder: four blocks for eight elements, whole elements behind the gate groups
+                        if (third < EPB) cell((i / STRIDE) * EPB + third);
                     }
                 }
             });
