@@ -638,6 +638,12 @@ def main(argv=None):
                 out["p2_bigru"] = p2_secondary(ctx, dev)
             except Exception as e:
                 out["p2_bigru"] = {"error": repr(e)}
+        if secondary and not args.no_p2:
+            try:
+                from tools import bench_hp
+                out["hp_builder"] = bench_hp.run(ctx, dev, regions=[batch.region(g) for g in range(batch.n_regions)])
+            except Exception as e:  # noqa: BLE001
+                out["hp_builder"] = {"error": repr(e)}
         if secondary and not args.no_filepath:
             try:
                 from tools import bench_filepath

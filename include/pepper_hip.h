@@ -50,6 +50,11 @@ extern "C" {
 #define PV_FEATURES 26
 #define PV_WINDOW_BYTES (PV_WINDOW_ROWS * PV_FEATURES)
 #define PV_MAX_COLOR 125         /* region_summary.h:15-16 */
+/* haplotag-aware variant (`-hp`): ImageSizeOptionsHP (Options.py:17-22): 48 planes, window 20 -> 21 rows
+ * (region_summary_hp.cpp:946 "candidate_window_size + 1") */
+#define PV_HP_WINDOW_ROWS 21
+#define PV_HP_FEATURES 48
+#define PV_HP_WINDOW_BYTES (PV_HP_WINDOW_ROWS * PV_HP_FEATURES)
 #define PV_MAX_ALLELE_KEY 61     /* region_summary.cpp:461,511 "candidate_string.length() <= 61" */
 
 /* CIGAR op codes = BAM codes = CIGAR_OPERATIONS (pepper_variant/modules/cpp/cigar.h:15-27) */
@@ -153,6 +158,22 @@ int pv_summarize_regions(pv_ctx* ctx, const pv_batch_in* in, const pv_params* pa
 int pv_summarize_regions_dev(pv_ctx* ctx, const pv_batch_in* in, const pv_params* params,
                              int64_t n_reads, int64_t n_bases, int64_t n_cigar, int64_t n_ref_bytes,
                              int64_t max_region_len, pv_batch_out* out, int64_t* d_counts, void* stream);
+
+/* ---- haplotag-aware image builder (`make_images -hp`) --------------------------------------------
+ * Replaces PEPPER_VARIANT.RegionalSummaryGeneratorHP (pybind_api.h:64-71; region_summary_hp.cpp:350-663 populate_summary_matrix,
+ * :665-1012 generate_summary; call site AlignmentSummarizerHP.py:215-233). Same flat batch and scalar struct as
+ * pv_summarize_regions plus one int per read, `read_hp` = type_read::hp_tag (the HP aux tag, 0 when absent; NULL = all 0):
+ *   48 planes = {REF, SNP, INS, DEL overlays 0-3} + 4 x {REF count, A, C, G, T, I, D, *} for (HP1 fwd, HP1 rev, HP2 fwd,
+ *   HP2 rev) with 3 overlay planes in front of each group; an untagged read (hp 0) counts in both haplotypes;
+ *   params->candidate_window_size must be 20 and params->feature_size 48; out->images is [capacity][21][48]
+ *   (images_i32 likewise); every plane is clamped to +-125 (region_summary_hp.cpp:762-767).
+ * Results are bit-identical with the reference class on the same reads. */
+int pv_summarize_regions_hp(pv_ctx* ctx, const pv_batch_in* in, const int32_t* read_hp, const pv_params* params,
+                            pv_batch_out* out);
+/* device-resident, asynchronous form: see pv_summarize_regions_dev; read_hp is a DEVICE pointer (or NULL) */
+int pv_summarize_regions_hp_dev(pv_ctx* ctx, const pv_batch_in* in, const int32_t* read_hp, const pv_params* params,
+                                int64_t n_reads, int64_t n_bases, int64_t n_cigar, int64_t n_ref_bytes,
+                                pv_batch_out* out, int64_t* d_counts, void* stream);
 
 /* ---- P2 (polisher) summary images -------------------------------------------------------------
  * Replaces SummaryGenerator::generate_summary + generate_image

@@ -12,6 +12,7 @@ from pepper_thesis_amd.batch import Params, RegionBatch, run_flat_summarizer
 _HERE = os.path.dirname(os.path.abspath(__file__))
 ORACLE_SO = os.path.join(_HERE, "liboracle.so")
 REF_SO = os.path.join(_HERE, "_ref", "libref_region_summary.so")
+REF_HP_SO = os.path.join(_HERE, "_ref", "libref_region_summary_hp.so")
 
 _SIG = [C.POINTER(_ffi.pv_batch_in), C.POINTER(_ffi.pv_params), C.POINTER(_ffi.pv_batch_out)]
 _libs = {}
@@ -28,13 +29,16 @@ def build(force=False):
         _made = True
 
 
-def _load(path, sym):
+_SIG_HP = [_SIG[0], C.POINTER(C.c_int32), _SIG[1], _SIG[2]]
+
+
+def _load(path, sym, sig=None):
     key = (path, sym)
     if key not in _libs:
         lib = C.CDLL(path)
         fn = getattr(lib, sym)
         fn.restype = C.c_int
-        fn.argtypes = _SIG
+        fn.argtypes = sig or _SIG
         _libs[key] = fn
     return _libs[key]
 
@@ -57,6 +61,27 @@ def reference_summarize(batch: RegionBatch, params: Params, want_i32=False):
     rc, out = run_flat_summarizer(_load(REF_SO, "ref_summarize_regions"), batch, params, want_i32)
     if rc:
         raise RuntimeError("ref_summarize_regions failed: %d" % rc)
+    return out
+
+
+def have_reference_hp():
+    return os.path.exists(REF_HP_SO)
+
+
+def summarize_hp(batch: RegionBatch, params: Params, want_i32=False):
+    """CPU restatement of RegionalSummaryGeneratorHP.generate_summary (region_summary_hp_oracle.c)."""
+    build()
+    rc, out = run_flat_summarizer(_load(ORACLE_SO, "oracle_summarize_regions_hp", _SIG_HP), batch, params, want_i32, hp=True)
+    if rc:
+        raise RuntimeError("oracle_summarize_regions_hp failed: %d" % rc)
+    return out
+
+
+def reference_summarize_hp(batch: RegionBatch, params: Params, want_i32=False):
+    """The reference's own region_summary_hp.cpp (only where oracle/_ref was built)."""
+    rc, out = run_flat_summarizer(_load(REF_HP_SO, "ref_summarize_regions_hp", _SIG_HP), batch, params, want_i32, hp=True)
+    if rc:
+        raise RuntimeError("ref_summarize_regions_hp failed: %d" % rc)
     return out
 
 

@@ -31,6 +31,9 @@ PV_ERR_STATE = -6
 PV_WINDOW_ROWS = 33
 PV_FEATURES = 26
 PV_WINDOW_BYTES = PV_WINDOW_ROWS * PV_FEATURES
+PV_HP_WINDOW_ROWS = 21
+PV_HP_FEATURES = 48
+PV_HP_WINDOW_BYTES = PV_HP_WINDOW_ROWS * PV_HP_FEATURES
 
 PV_PLAN_P1_LSTM = 1
 PV_PLAN_P2_GRU = 2
@@ -147,6 +150,11 @@ SYMBOLS = [
     ("pv_summarize_regions", C.c_int, [C.c_void_p, C.POINTER(pv_batch_in), C.POINTER(pv_params), C.POINTER(pv_batch_out)]),
     ("pv_summarize_regions_dev", C.c_int,
      [C.c_void_p, C.POINTER(pv_batch_in), C.POINTER(pv_params), C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int64,
+      C.POINTER(pv_batch_out), C.c_void_p, C.c_void_p]),
+    ("pv_summarize_regions_hp", C.c_int,
+     [C.c_void_p, C.POINTER(pv_batch_in), C.POINTER(C.c_int32), C.POINTER(pv_params), C.POINTER(pv_batch_out)]),
+    ("pv_summarize_regions_hp_dev", C.c_int,
+     [C.c_void_p, C.POINTER(pv_batch_in), C.c_void_p, C.POINTER(pv_params), C.c_int64, C.c_int64, C.c_int64, C.c_int64,
       C.POINTER(pv_batch_out), C.c_void_p, C.c_void_p]),
     ("pv_polish_summarize_regions", C.c_int, [C.c_void_p, C.POINTER(pv_batch_in), C.c_int, C.c_int, C.POINTER(pv_polish_out)]),
     ("pv_polish_summarize_regions_dev", C.c_int,

@@ -38,9 +38,10 @@ class Read:
     quals: np.ndarray            # uint8
     is_reverse: bool = False
     mapq: int = 60
+    hp_tag: int = 0              # type_read::hp_tag (the HP aux tag; only the haplotag-aware builder reads it)
 
     @staticmethod
-    def make(pos, cigar, bases, quals=20, is_reverse=False, mapq=60):
+    def make(pos, cigar, bases, quals=20, is_reverse=False, mapq=60, hp_tag=0):
         cg = parse_cigar(cigar) if isinstance(cigar, str) else np.asarray(cigar, dtype=np.uint32)
         bs = bases.encode() if isinstance(bases, str) else bytes(bases)
         if np.isscalar(quals):
@@ -48,7 +49,7 @@ class Read:
         else:
             q = np.asarray(quals, dtype=np.uint8)
         assert len(q) == len(bs)
-        return Read(int(pos), cg, bs, q, bool(is_reverse), int(mapq))
+        return Read(int(pos), cg, bs, q, bool(is_reverse), int(mapq), int(hp_tag))
 
 
 @dataclass
@@ -83,6 +84,7 @@ class RegionBatch:
     cigar_off: np.ndarray
     cigar: np.ndarray
     contigs: List[str] = field(default_factory=list)
+    read_hp: Optional[np.ndarray] = None   # int32 [n_reads] hp_tag per read, passed NEXT to pv_batch_in (pv_summarize_regions_hp)
 
     FIELDS = ("ref_start", "ref_end", "cand_start", "cand_end", "ref_off", "ref", "read_off", "read_pos",
               "read_flags", "read_mapq", "base_off", "bases", "quals", "cigar_off", "cigar")
@@ -128,7 +130,8 @@ class RegionBatch:
             b0, b1 = int(self.base_off[r]), int(self.base_off[r + 1])
             c0, c1 = int(self.cigar_off[r]), int(self.cigar_off[r + 1])
             reads.append(Read(int(self.read_pos[r]), self.cigar[c0:c1].copy(), self.bases[b0:b1].tobytes(),
-                              self.quals[b0:b1].copy(), bool(self.read_flags[r] & 1), int(self.read_mapq[r])))
+                              self.quals[b0:b1].copy(), bool(self.read_flags[r] & 1), int(self.read_mapq[r]),
+                              0 if self.read_hp is None else int(self.read_hp[r])))
         return Region(int(self.ref_start[g]), int(self.ref_end[g]),
                       self.ref[int(self.ref_off[g]):int(self.ref_off[g + 1])].tobytes(), reads,
                       int(self.cand_start[g]), int(self.cand_end[g]),
@@ -161,8 +164,10 @@ def pack_regions(regions: Sequence[Region]) -> RegionBatch:
     bases = np.frombuffer(b"".join(rd.bases for rd in reads), dtype=np.uint8).copy() if m else np.zeros(0, np.uint8)
     quals = np.concatenate([rd.quals for rd in reads]).astype(np.uint8) if m else np.zeros(0, np.uint8)
     cigar = np.concatenate([rd.cigar for rd in reads]).astype(np.uint32) if m else np.zeros(0, np.uint32)
+    read_hp = np.asarray([rd.hp_tag for rd in reads], dtype=np.int32).reshape(m)
     return RegionBatch(n, ref_start, ref_end, cand_start, cand_end, ref_off, ref, read_off, read_pos, read_flags,
-                       read_mapq, base_off, bases, quals, cigar_off, cigar, [r.contig for r in regions])
+                       read_mapq, base_off, bases, quals, cigar_off, cigar, [r.contig for r in regions],
+                       read_hp if read_hp.any() else None)
 
 
 def merge_batches(batches: Sequence[RegionBatch]) -> RegionBatch:
@@ -188,7 +193,9 @@ def merge_batches(batches: Sequence[RegionBatch]) -> RegionBatch:
         cat_off("ref_off", [int(b.ref.shape[0]) for b in batches]), cat("ref"),
         cat_off("read_off", [b.n_reads for b in batches]), cat("read_pos"), cat("read_flags"), cat("read_mapq"),
         cat_off("base_off", [b.n_bases for b in batches]), cat("bases"), cat("quals"),
-        cat_off("cigar_off", [b.n_cigar for b in batches]), cat("cigar"), [c for b in batches for c in b.contigs])
+        cat_off("cigar_off", [b.n_cigar for b in batches]), cat("cigar"), [c for b in batches for c in b.contigs],
+        None if all(b.read_hp is None for b in batches) else np.concatenate(
+            [np.zeros(b.n_reads, np.int32) if b.read_hp is None else b.read_hp for b in batches]))
 
 
 @dataclass
@@ -231,6 +238,12 @@ PRESETS = {
 }
 
 
+def hp_params(p: Params) -> Params:
+    """the same platform scalars with the window geometry of the haplotag-aware builder (ImageSizeOptionsHP, Options.py:17-22)"""
+    from dataclasses import replace
+    return replace(p, candidate_window_size=_ffi.PV_HP_WINDOW_ROWS - 1, feature_size=_ffi.PV_HP_FEATURES)
+
+
 # options.min_mapq per platform preset (SetParameters.py:16-17,71-72,126-127,180-181,234-235): BAM_handler.get_reads drops
 # reads with MAPQ below it before the image builder sees them
 PRESET_MIN_MAPQ = {
@@ -249,7 +262,7 @@ class SummaryOut:
     position: np.ndarray
     depth: np.ndarray
     cand_freq: np.ndarray
-    images: np.ndarray           # int8 [N,33,26]
+    images: np.ndarray           # int8 [N,33,26] ([N,21,48] from the haplotag-aware builder)
     candidates: List[str]
     images_i32: Optional[np.ndarray] = None
 
@@ -260,7 +273,8 @@ class SummaryOut:
 class OutBuffers:
     """Caller-owned output arrays + the C struct pointing at them."""
 
-    def __init__(self, capacity: int, str_capacity: int, want_i32: bool = False):
+    def __init__(self, capacity: int, str_capacity: int, want_i32: bool = False, rows: int = _ffi.PV_WINDOW_ROWS,
+                 features: int = _ffi.PV_FEATURES):
         capacity = max(int(capacity), 1)
         str_capacity = max(int(str_capacity), 1)
         self.capacity, self.str_capacity = capacity, str_capacity
@@ -268,8 +282,8 @@ class OutBuffers:
         self.position = np.zeros(capacity, np.int64)
         self.depth = np.zeros(capacity, np.uint8)
         self.cand_freq = np.zeros(capacity, np.uint8)
-        self.images = np.zeros((capacity, _ffi.PV_WINDOW_ROWS, _ffi.PV_FEATURES), np.int8)
-        self.images_i32 = np.zeros((capacity, _ffi.PV_WINDOW_ROWS, _ffi.PV_FEATURES), np.int32) if want_i32 else None
+        self.images = np.zeros((capacity, rows, features), np.int8)
+        self.images_i32 = np.zeros((capacity, rows, features), np.int32) if want_i32 else None
         self.cand_str = np.zeros(str_capacity, np.uint8)
         self.cand_off = np.zeros(capacity + 1, np.int64)
         s = _ffi.pv_batch_out()
@@ -288,15 +302,28 @@ class OutBuffers:
                           None if self.images_i32 is None else self.images_i32[:n].copy())
 
 
+def hp_pointer(batch: RegionBatch):
+    """the `read_hp` argument of the *_hp entry points: int32 per read, NULL when no read carries a tag"""
+    if batch.read_hp is None:
+        return None
+    assert batch.read_hp.dtype == np.int32 and batch.read_hp.shape[0] == batch.n_reads
+    return batch.read_hp.ctypes.data_as(C.POINTER(C.c_int32))
+
+
 def run_flat_summarizer(fn, batch: RegionBatch, params: Params, want_i32: bool = False,
-                        capacity: int = 4096, str_capacity: int = 1 << 16, ctx=None) -> SummaryOut:
-    """Call any function with the (pv_batch_in*, pv_params*, pv_batch_out*) signature, growing the
-    caller-owned buffers on PV_ERR_CAPACITY (the 2-call size query of SURVEY 8b)."""
+                        capacity: int = 4096, str_capacity: int = 1 << 16, ctx=None, hp: bool = False) -> SummaryOut:
+    """Call any function with the (pv_batch_in*, pv_params*, pv_batch_out*) signature — or, with hp, the
+    (pv_batch_in*, const int32_t* read_hp, pv_params*, pv_batch_out*) one — growing the caller-owned buffers on
+    PV_ERR_CAPACITY (the 2-call size query of SURVEY 8b)."""
     cin = batch.as_c()
     cp = params.as_c()
     for _ in range(3):
-        ob = OutBuffers(capacity, str_capacity, want_i32)
-        args = (C.byref(cin), C.byref(cp), C.byref(ob.c))
+        if hp:
+            ob = OutBuffers(capacity, str_capacity, want_i32, _ffi.PV_HP_WINDOW_ROWS, _ffi.PV_HP_FEATURES)
+            args = (C.byref(cin), hp_pointer(batch), C.byref(cp), C.byref(ob.c))
+        else:
+            ob = OutBuffers(capacity, str_capacity, want_i32)
+            args = (C.byref(cin), C.byref(cp), C.byref(ob.c))
         rc = fn(ctx, *args) if ctx is not None else fn(*args)
         if rc == _ffi.PV_ERR_CAPACITY:
             capacity = max(int(ob.c.n_out), capacity)

@@ -36,6 +36,10 @@ namespace {
 
 constexpr int NCNT = 21;
 constexpr int C_COV = 0, C_SNP = 1, C_INS = 2, C_DEL = 3, C_RARE = 4, C_PLANE = 5;
+// haplotag-aware builder (region_summary_hp.cpp): the same four site counters, then 4 groups (set 1 fwd, set 1 rev,
+// set 2 fwd, set 2 rev) x {REF count, A, C, G, T, I, D, *} holding the FINAL signed plane values (window plane
+// 4 + 11*group for the REF count, 8 + 11*group + k for the symbols)
+constexpr int NCNT_HP = 36, HC_PLANE = 4;
 constexpr int32_t OP_INACTIVE = 0x7fffffff;
 constexpr int UMAX = 1024;  // distinct alleles per site held in LDS
 constexpr int TILE_COLS = 512;  // columns per pileup tile (one workgroup accumulates a tile in LDS)
@@ -48,7 +52,8 @@ struct Event {  // 16 B
     uint8_t type;   // 1 SNP 2 INS 3 DEL
     uint8_t rev;
     uint8_t kind;   // 1 bases, 2 ref
-    uint8_t flags;  // bit0: is an allele observation; bit1: plane correction (lower-case acgt counted in an ACGT plane)
+    uint8_t flags;  // bit0: is an allele observation; bit1: plane correction (lower-case acgt counted in an ACGT plane);
+                    // bits 2-3 (haplotag form): the haplotype sets whose per-strand allele counts the observation joins
 };
 
 struct AlleleRec {  // 32 B
@@ -66,7 +71,7 @@ struct AlleleRec {  // 32 B
 
 struct PairRec {  // 48 B: everything a tile workgroup needs to walk one (read, tile) pair
     int32_t read, op_lo, op_hi, col_base;
-    int32_t R, c_last, ref_len, rev;
+    int32_t R, c_last, ref_len, rev;   // rev: bit0 strand; haplotag builder: bits 1-2 count sets, bits 3-4 symbol sets
     int64_t base0, seq_end;
 };
 
@@ -109,6 +114,9 @@ struct SumArgs {
     int64_t max_events;
     pv_batch_out out;
     int64_t* d_counts;
+    // ---- haplotag-aware builder only ----
+    int32_t hp;               // 1: RegionalSummaryGeneratorHP semantics (48 planes, 21 rows)
+    const int32_t* read_hp;   // [n_reads] type_read::hp_tag, or null (all 0)
     // ---- P2 (polisher) summary only ----
     int32_t polish;       // 1: CIGAR semantics of SummaryGenerator::iterate_over_read (N and P consume the reference only)
     int32_t seq_len, seq_step;  // chunk length, chunk length - overlap
@@ -246,6 +254,14 @@ __global__ __launch_bounds__(256) void k_tile_fill(SumArgs a) {
         pr.c_last = c1 - 1;
         pr.ref_len = (int32_t)(a.in.ref_off[g + 1] - cb0);
         pr.rev = a.in.read_flags[r] & 1;
+        if (a.hp) {
+            // region_summary_hp.cpp: REF-count planes and the allele maps take "hp_tag == 0 || hp_tag == k" (:395-402, :415-422);
+            // the symbol planes take both sets for tag 0, set 1 for tag 1 and set 2 for ANY other tag (:454-462, get_feature_index :197)
+            const int32_t tag = a.read_hp ? a.read_hp[r] : 0;
+            const int cs = ((tag == 0 || tag == 1) ? 1 : 0) | ((tag == 0 || tag == 2) ? 2 : 0);
+            const int ss = tag == 0 ? 3 : (tag == 1 ? 1 : 2);
+            pr.rev |= (cs << 1) | (ss << 3);
+        }
         pr.base0 = a.in.base_off[r];
         pr.seq_end = a.in.base_off[r + 1];
         a.pairs[slot] = pr;
@@ -297,8 +313,20 @@ enum {
     L_SNP = 19, L_INS = 20, L_DEL = 21, L_RARE = 22, L_N = 23
 };
 
+// LDS counters of the haplotag-aware form (region_summary_hp.cpp:393-463): a counted base costs TWO ds_adds whatever the
+// read's tag is - one into its count-set class (coverage and the REF-count planes of both haplotypes are sums of classes),
+// one into either the SNP counter or its symbol-set class (a match can only land in the plane of the reference's own symbol).
+enum {
+    HL_REFC = 0,   // [4 count-set classes: none, set 1, set 2, both][2 strands]: quality-passing aligned bases
+    HL_M = 8,      // [3 symbol-set classes: set 1, set 2, both][2 strands]: bases equal to a valid reference base
+    HL_O = 14,     // [2 sets][2 strands][3]: planes I, D, *
+    HL_COVD = 26,  // coverage taken back by inserts that fail the quality bar (:487-488)
+    HL_SNP = 27, HL_INS = 28, HL_DEL = 29, HL_N = 30
+};
+
+template <bool HP>
 __global__ __launch_bounds__(PT_THREADS) void k_pileup_tiles(SumArgs a) {
-    __shared__ int32_t s_cnt[L_N][TILE_COLS];
+    __shared__ int32_t s_cnt[HP ? (int)HL_N : (int)L_N][TILE_COLS];
     __shared__ uint8_t s_ref[TILE_COLS + 4];  // the tile's reference bytes (+4: a padded group may look past the tile)
     __shared__ uint8_t s_lut[256];           // byte class: bits0-2 plane symbol 1..7, 8 = upper ACGT, 16 = lower acgt, 32 = valid reference
     __shared__ uint16_t s_blk[PT_THREADS * (TILE_COLS + 4) / 64 + 2];  // op that owns the first slot of every 64-slot block
@@ -326,7 +354,7 @@ __global__ __launch_bounds__(PT_THREADS) void k_pileup_tiles(SumArgs a) {
 #define PSTAMP(i)
 #endif
     const int64_t tlo = tile * TILE_COLS, thi = tlo + TILE_COLS - 1;  // global columns of this tile
-    for (int i = tid; i < L_N * TILE_COLS; i += PT_THREADS) (&s_cnt[0][0])[i] = 0;
+    for (int i = tid; i < (HP ? (int)HL_N : (int)L_N) * TILE_COLS; i += PT_THREADS) (&s_cnt[0][0])[i] = 0;
     for (int i = tid; i < TILE_COLS + 4; i += PT_THREADS) s_ref[i] = (i < TILE_COLS && tlo + i < a.n_cols) ? a.in.ref[tlo + i] : (uint8_t)'N';
     if (tid < 256) s_lut[tid] = (uint8_t)(sym_of(tid) | (is_acgt(tid) ? 8 : 0) | ((tid != up(tid) && is_acgt(up(tid))) ? 16 : 0) | (is_acgt(up(tid)) ? 32 : 0));
     const int32_t p0 = a.tile_off[tile];
@@ -353,7 +381,7 @@ __global__ __launch_bounds__(PT_THREADS) void k_pileup_tiles(SumArgs a) {
             const int k = ob + tid;
             int32_t ref_rel = 0, rd = 0, len = 0, op = 15, col_base = 0;
             bool active = false, anchor_next = false, rev = false;
-            int pslot = 0;
+            int pslot = 0, hpbits = 0;  // hpbits: bits 0-1 count sets, bits 2-3 symbol sets (haplotag form only)
             int32_t c = 0;
             int64_t clo = 0, chi = -1;
             if (k < total_ops) {
@@ -367,7 +395,8 @@ __global__ __launch_bounds__(PT_THREADS) void k_pileup_tiles(SumArgs a) {
                 const int32_t rdv = a.op_rd[c];
                 const uint32_t wn = a.in.cigar[c < c_last ? c + 1 : c];
                 col_base = p_colbase[pslot];
-                rev = p_rev[pslot] != 0;
+                rev = (p_rev[pslot] & 1) != 0;
+                hpbits = p_rev[pslot] >> 1;
                 active = rr != OP_INACTIVE;
                 if (active) {
                     ref_rel = rr; rd = rdv; op = w & 0xF; len = (int32_t)(w >> 4);
@@ -378,8 +407,58 @@ __global__ __launch_bounds__(PT_THREADS) void k_pileup_tiles(SumArgs a) {
                 if (clo < 0) clo = 0;
                 if (chi > p_R[pslot] - 1) chi = p_R[pslot] - 1;
             }
-            const int so = L_O + (rev ? 3 : 0);
+            [[maybe_unused]] const int so = L_O + (rev ? 3 : 0);
             // (1) indel ops; an op belongs to the tile that owns its anchor column
+            if constexpr (HP) {
+                const int st = rev ? 1 : 0, ss = hpbits >> 2;
+                if (active && op == PV_CIGAR_IN) {  // region_summary_hp.cpp:469-553
+                    const int64_t anchor = (int64_t)ref_rel - 1;
+                    if (anchor >= clo && anchor <= chi && rd >= 1) {
+                        const int lc = (int)(col_base + anchor - tlo);
+                        const int64_t start = p_base0[pslot] + rd;  // first inserted base; the allele starts one base earlier
+                        if (start + len > p_seqend[pslot]) {
+                            set_status(a.diag, PV_ERR_INVALID);
+                        } else {
+                            int64_t qs = 0;
+                            for (int64_t i = 0; i < len; i++) qs += a.in.quals[start + i];  // inserted bases only, :482-484
+                            const bool qok = (double)qs >= a.p.min_indel_baseq * (double)len;
+                            if (!qok && (double)a.in.quals[start - 1] >= a.p.min_snp_baseq) atomicAdd(&s_cnt[HL_COVD][SW(lc)], 1);
+                            if (2 + (int64_t)len <= PV_MAX_ALLELE_KEY && qok) {
+                                if (is_acgt(up(s_ref[lc]))) {
+                                    if (ss & 1) atomicAdd(&s_cnt[HL_O + (0 + st) * 3 + 0][SW(lc)], 1);
+                                    if (ss & 2) atomicAdd(&s_cnt[HL_O + (2 + st) * 3 + 0][SW(lc)], 1);
+                                }
+                                atomicAdd(&s_cnt[HL_INS][SW(lc)], 1);
+                                a.op_flag[c] = 1;
+                            }
+                        }
+                    }
+                } else if (active && op == PV_CIGAR_DEL) {  // :556-649
+                    const int64_t anchor = (int64_t)ref_rel - 1;
+                    if (anchor >= clo && anchor <= chi) {
+                        const int lc = (int)(col_base + anchor - tlo);
+                        if (is_acgt(up(s_ref[lc]))) {  // unconditional, :561-569
+                            if (ss & 1) atomicAdd(&s_cnt[HL_O + (0 + st) * 3 + 1][SW(lc)], 1);
+                            if (ss & 2) atomicAdd(&s_cnt[HL_O + (2 + st) * 3 + 1][SW(lc)], 1);
+                        }
+                        int64_t L = (int64_t)len + 1;
+                        if (anchor + L > p_reflen[pslot]) L = p_reflen[pslot] - anchor;
+                        if (1 + L <= PV_MAX_ALLELE_KEY) {
+                            atomicAdd(&s_cnt[HL_DEL][SW(lc)], 1);
+                            a.op_flag[c] = 1;
+                        }
+                    }
+                    int64_t i0 = clo - ref_rel; if (i0 < 0) i0 = 0;
+                    int64_t i1 = chi + 1 - ref_rel; if (i1 > len) i1 = len;
+                    for (int64_t i = i0; i < i1; i++) {  // :631-647
+                        const int lc2 = (int)((int64_t)col_base + ref_rel + i - tlo);
+                        if (is_acgt(up(s_ref[lc2]))) {
+                            if (ss & 1) atomicAdd(&s_cnt[HL_O + (0 + st) * 3 + 2][SW(lc2)], 1);
+                            if (ss & 2) atomicAdd(&s_cnt[HL_O + (2 + st) * 3 + 2][SW(lc2)], 1);
+                        }
+                    }
+                }
+            } else {
             if (active && op == PV_CIGAR_IN) {  // :431-490
                 const int64_t anchor = (int64_t)ref_rel - 1;
                 if (anchor >= clo && anchor <= chi && rd >= 1) {
@@ -430,6 +509,7 @@ __global__ __launch_bounds__(PT_THREADS) void k_pileup_tiles(SumArgs a) {
                     if (is_acgt(up(s_ref[lc2]))) atomicAdd(&s_cnt[so + 2][SW(lc2)], 1);
                 }
             }
+            }
             // (2) aligned bases of the batch's M/=/X ops, clipped to tile and region
             PSTAMP(1)  // op lookup + indel ops
             const bool is_m = active && (op == PV_CIGAR_MATCH || op == PV_CIGAR_EQUAL || op == PV_CIGAR_DIFF);
@@ -449,7 +529,7 @@ __global__ __launch_bounds__(PT_THREADS) void k_pileup_tiles(SumArgs a) {
             s_i0[tid] = i0 - (incl - effp);
             s_iend[tid] = i0 + eff;
             s_meta[tid] = len - 1;
-            s_opfl[tid] = (uint8_t)((rev ? 1 : 0) | (anchor_next ? 2 : 0));
+            s_opfl[tid] = (uint8_t)((rev ? 1 : 0) | (anchor_next ? 2 : 0) | (HP ? hpbits << 2 : 0));
             s_opair[tid] = (uint8_t)pslot;
             for (int32_t bb = (incl - effp + 63) >> 6; (bb << 6) < incl; bb++) s_blk[bb] = (uint16_t)tid;  // blocks starting inside this op
             __syncthreads();
@@ -476,7 +556,7 @@ __global__ __launch_bounds__(PT_THREADS) void k_pileup_tiles(SumArgs a) {
                     g[u].lc = lc;
                     g[u].nv = nv;
                     const int f = s_opfl[owc];
-                    g[u].fl = f & 1;
+                    g[u].fl = HP ? f : (f & 1);
                     g[u].last = (f & 2) ? s_meta[owc] - i : -1;  // group position of the op's last base, if that base anchors an indel
                     uint32_t b4 = 0, q4 = 0;
                     if (nv > 0) {
@@ -504,6 +584,12 @@ __global__ __launch_bounds__(PT_THREADS) void k_pileup_tiles(SumArgs a) {
                         const int q = (g[u].qw >> (8 * e)) & 0xFF;
                         if (e >= g[u].nv || q < a.qmin_snp) continue;
                         const int lc = g[u].lc + e;
+                        if constexpr (HP) {  // region_summary_hp.cpp:393-463
+                            const int st = g[u].fl & 1, cs = (g[u].fl >> 2) & 3, ss = (g[u].fl >> 4) & 3;
+                            atomicAdd(&s_cnt[HL_REFC + 2 * cs + st][SW(lc)], 1);
+                            if (refb != base) atomicAdd(&s_cnt[HL_SNP][SW(lc)], 1);                       // raw bytes, :406
+                            else if (s_lut[refb] & 32) atomicAdd(&s_cnt[HL_M + 2 * (ss - 1) + st][SW(lc)], 1);
+                        } else {
                         const int st = g[u].fl;
                         const int cb = s_lut[base];
                         const bool refvalid = (s_lut[refb] & 32) != 0;
@@ -520,6 +606,7 @@ __global__ __launch_bounds__(PT_THREADS) void k_pileup_tiles(SumArgs a) {
                         const bool rare = mism && !(refvalid && (cb & 8));
                         const bool corr = refvalid && (cb & 16);
                         if (rare || corr) atomicAdd(&s_cnt[L_RARE][SW(lc)], 1);
+                        }
                     }
                 }
             };
@@ -546,6 +633,33 @@ __global__ __launch_bounds__(PT_THREADS) void k_pileup_tiles(SumArgs a) {
     const int64_t NC = a.n_cols;
     int64_t ncol = NC - tlo;
     if (ncol > TILE_COLS) ncol = TILE_COLS;
+    if constexpr (HP) {
+        for (int lc = tid; lc < ncol; lc += PT_THREADS) {
+            const int64_t g = tlo + lc;
+            int cov = -s_cnt[HL_COVD][SW(lc)];
+#pragma unroll
+            for (int k = 0; k < 8; k++) cov += s_cnt[HL_REFC + k][SW(lc)];
+            const int rsym = s_lut[s_ref[lc]];  // bits0-2: plane symbol of the reference byte, bit 5: valid reference
+#pragma unroll
+            for (int set = 0; set < 2; set++) {
+#pragma unroll
+                for (int st = 0; st < 2; st++) {
+                    const int grp = 2 * set + st;
+                    int32_t* dst = a.cnt + (int64_t)(HC_PLANE + 8 * grp) * NC + g;
+                    dst[0] = -(s_cnt[HL_REFC + 2 * (1 + set) + st][SW(lc)] + s_cnt[HL_REFC + 2 * 3 + st][SW(lc)]);
+                    const int m = s_cnt[HL_M + 2 * set + st][SW(lc)] + s_cnt[HL_M + 2 * 2 + st][SW(lc)];
+#pragma unroll
+                    for (int k = 0; k < 4; k++) dst[(int64_t)(1 + k) * NC] = ((rsym & 32) && (rsym & 7) == k + 1) ? -m : 0;
+#pragma unroll
+                    for (int k = 0; k < 3; k++) dst[(int64_t)(5 + k) * NC] = s_cnt[HL_O + grp * 3 + k][SW(lc)];
+                }
+            }
+            a.cnt[(int64_t)C_COV * NC + g] = cov;
+            a.cnt[(int64_t)C_SNP * NC + g] = s_cnt[HL_SNP][SW(lc)];
+            a.cnt[(int64_t)C_INS * NC + g] = s_cnt[HL_INS][SW(lc)];
+            a.cnt[(int64_t)C_DEL * NC + g] = s_cnt[HL_DEL][SW(lc)];
+        }
+    } else {
     for (int lc = tid; lc < ncol; lc += PT_THREADS) {
         const int64_t g = tlo + lc;
         int cov = s_cnt[L_COVI][SW(lc)];
@@ -569,6 +683,7 @@ __global__ __launch_bounds__(PT_THREADS) void k_pileup_tiles(SumArgs a) {
         a.cnt[(int64_t)C_INS * NC + g] = s_cnt[L_INS][SW(lc)];
         a.cnt[(int64_t)C_DEL * NC + g] = s_cnt[L_DEL][SW(lc)];
         a.cnt[(int64_t)C_RARE * NC + g] = s_cnt[L_RARE][SW(lc)];
+    }
     }
 #ifdef PV_PSTAMPS
     PSTAMP(5)  // flush
@@ -723,7 +838,9 @@ __global__ __launch_bounds__(1024) void k_site_rank(SumArgs a) {
         const int64_t NC = a.n_cols;
         a.site_col[rank] = (int32_t)col;
         a.site_region[rank] = upper_bound_i64(a.in.ref_off, a.in.n_regions + 1, col) - 1;
-        a.site_nev[rank] = a.cnt[C_INS * NC + col] + a.cnt[C_DEL * NC + col] + a.cnt[C_RARE * NC + col];
+        // events a site will receive: every insert / delete observation, and either the rare SNP observations (the
+        // common ones are read off the symbol planes) or, in the haplotag form, every SNP observation
+        a.site_nev[rank] = a.cnt[C_INS * NC + col] + a.cnt[C_DEL * NC + col] + a.cnt[(a.hp ? C_SNP : C_RARE) * NC + col];
         a.site_fill[rank] = 0;
     }
 }
@@ -752,6 +869,11 @@ __global__ __launch_bounds__(256) void k_collect(SumArgs a) {
     const int64_t R = a.in.ref_end[g] - a.in.ref_start[g] + 1;
     const int64_t base0 = a.in.base_off[r], seq_end = a.in.base_off[r + 1];
     const bool rev = (a.in.read_flags[r] & 1) != 0;
+    int obs = 1;  // flags of an allele observation
+    if (a.hp) {   // region_summary_hp.cpp:415-422: "hp_tag == 0 || hp_tag == k" joins set k
+        const int32_t tag = a.read_hp ? a.read_hp[r] : 0;
+        obs |= (((tag == 0 || tag == 1) ? 1 : 0) | ((tag == 0 || tag == 2) ? 2 : 0)) << 2;
+    }
     const int64_t c0 = a.in.cigar_off[r], c1 = a.in.cigar_off[r + 1];
     for (int64_t c = c0 + lane; c < c1; c += 256) {
         const int32_t ref_rel = a.op_ref[c];
@@ -762,14 +884,14 @@ __global__ __launch_bounds__(256) void k_collect(SumArgs a) {
         if (op == PV_CIGAR_IN) {
             if (!a.op_flag[c]) continue;
             const int64_t col = col_base + ref_rel - 1;
-            if (a.flags[col] & 1) push_event(a, a.site_rank[col], base0 + a.op_rd[c] - 1, len + 1, 2, rev, 1, 1);
+            if (a.flags[col] & 1) push_event(a, a.site_rank[col], base0 + a.op_rd[c] - 1, len + 1, 2, rev, 1, obs);
         } else if (op == PV_CIGAR_DEL) {
             if (!a.op_flag[c]) continue;
             const int64_t anchor = (int64_t)ref_rel - 1;
             const int64_t col = col_base + anchor;
             int64_t L = (int64_t)len + 1;
             if (anchor + L > ref_len) L = ref_len - anchor;
-            if (a.flags[col] & 1) push_event(a, a.site_rank[col], col, (int32_t)L, 3, rev, 2, 1);
+            if (a.flags[col] & 1) push_event(a, a.site_rank[col], col, (int32_t)L, 3, rev, 2, obs);
         } else if (op == PV_CIGAR_MATCH || op == PV_CIGAR_EQUAL || op == PV_CIGAR_DIFF) {
             int64_t lo = ref_rel < 0 ? -(int64_t)ref_rel : 0;
             int64_t hi = R - ref_rel;
@@ -783,13 +905,17 @@ __global__ __launch_bounds__(256) void k_collect(SumArgs a) {
             const int64_t rd = a.op_rd[c];
             for (int32_t s = s0; s < s1; s++) {
                 const int64_t col = a.site_col[s];
-                if (a.cnt[C_RARE * a.n_cols + col] == 0) continue;
+                if (a.cnt[(a.hp ? C_SNP : C_RARE) * a.n_cols + col] == 0) continue;
                 const int64_t i = col - (col_base + ref_rel);
                 const int64_t bi = base0 + rd + i;
                 if (bi >= seq_end) continue;  // already reported by k_pileup
                 const int base = a.in.bases[bi];
                 if (!((double)a.in.quals[bi] >= a.p.min_snp_baseq)) continue;
                 const int refb = a.in.ref[col];
+                if (a.hp) {  // every mismatch (raw bytes, region_summary_hp.cpp:406) is an allele observation
+                    if (refb != base) push_event(a, s, bi, 1, 1, rev, 1, obs);
+                    continue;
+                }
                 const bool refvalid = is_acgt(up(refb));
                 const bool rare = (refb != base) && !(refvalid && is_acgt(base));
                 const bool corr = refvalid && base != up(base) && is_acgt(up(base));
@@ -820,11 +946,15 @@ __device__ __forceinline__ int key_cmp(const SumArgs& a, const Key& x, const Key
     return 0;
 }
 
+// HP: the haplotag form keeps four per-strand counts per allele (forward / reverse x haplotype set 1 / 2,
+// region_summary_hp.cpp:415-447) next to the total, and no allele count comes from the planes.
+template <bool HP>
 __global__ __launch_bounds__(64) void k_site_alleles(SumArgs a) {
     __shared__ int64_t u_src[UMAX];
     __shared__ int32_t u_len[UMAX];
-    __shared__ int32_t u_fwd[UMAX];
-    __shared__ int32_t u_rev[UMAX];
+    __shared__ int32_t u_fwd[UMAX];   // HP: total observations
+    __shared__ int32_t u_rev[UMAX];   // HP: unused (0), so that u_fwd + u_rev is the total in both forms
+    __shared__ int32_t u_hc[HP ? 4 : 1][HP ? UMAX : 1];  // HP: forward set 1, forward set 2, reverse set 1, reverse set 2
     __shared__ uint8_t u_type[UMAX];
     __shared__ uint8_t u_kind[UMAX];
     __shared__ uint8_t u_imm[UMAX];
@@ -845,7 +975,7 @@ __global__ __launch_bounds__(64) void k_site_alleles(SumArgs a) {
         const bool refvalid = is_acgt(up(refraw));
         __syncthreads();
         // slots 0..3: SNP alleles whose counts are the (negated, un-clamped) A/C/G/T planes
-        if (lane < 4) {
+        if (!HP && lane < 4) {
             const int b = "ACGT"[lane];
             u_src[lane] = 0; u_len[lane] = 1; u_type[lane] = 1; u_kind[lane] = 0; u_imm[lane] = (uint8_t)b;
             const bool ok = refvalid && b != refraw;
@@ -853,7 +983,7 @@ __global__ __launch_bounds__(64) void k_site_alleles(SumArgs a) {
             u_fwd[lane] = ok ? -a.cnt[(C_PLANE + 1 + lane) * NC + col] : 0;
             u_rev[lane] = ok ? -a.cnt[(C_PLANE + 8 + 1 + lane) * NC + col] : 0;
         }
-        if (lane == 0) s_nU = 4;
+        if (lane == 0) s_nU = HP ? 0 : 4;
         __syncthreads();
         const int nev = a.site_nev[s];
         const int64_t eoff = a.site_evoff[s];
@@ -862,20 +992,26 @@ __global__ __launch_bounds__(64) void k_site_alleles(SumArgs a) {
             Event e;
             e.src = 0; e.len = 0; e.type = 0; e.rev = 0; e.kind = 1; e.flags = 0;
             if (have) e = a.ev[eoff + eb + lane];
-            if (have && (e.flags & 2)) {  // lower-case acgt was counted in plane toupper(): take it back out
+            if (!HP && have && (e.flags & 2)) {  // lower-case acgt was counted in plane toupper(): take it back out
                 const int ub = up(a.in.bases[e.src]);
                 const int sl = ub == 'A' ? 0 : ub == 'C' ? 1 : ub == 'G' ? 2 : 3;
                 if (u_ok[sl]) atomicAdd(e.rev ? &u_rev[sl] : &u_fwd[sl], -1);
             }
             bool pending = have && (e.flags & 1);
             Key ke; ke.src = e.src; ke.len = e.len; ke.type = e.type; ke.kind = e.kind; ke.imm = 0;
-            int checked = 4;  // slots 0..3 can never equal an event key (see k_pileup: those are not events)
+            int checked = HP ? 0 : 4;  // slots 0..3 can never equal an event key (see k_pileup: those are not events)
+            [[maybe_unused]] const int hs = (e.flags >> 2) & 3, hst = e.rev ? 2 : 0;
             while (true) {
                 const int nU = s_nU;
                 if (pending) {
                     for (int k = checked; k < nU; k++) {
                         Key ku; ku.src = u_src[k]; ku.len = u_len[k]; ku.type = u_type[k]; ku.kind = u_kind[k]; ku.imm = u_imm[k];
                         if (ku.type == ke.type && ku.len == ke.len && key_cmp(a, ku, ke) == 0) {
+                            if constexpr (HP) {
+                                atomicAdd(&u_fwd[k], 1);
+                                if (hs & 1) atomicAdd(&u_hc[hst + 0][k], 1);
+                                if (hs & 2) atomicAdd(&u_hc[hst + 1][k], 1);
+                            } else
                             atomicAdd(e.rev ? &u_rev[k] : &u_fwd[k], 1);
                             pending = false;
                             break;
@@ -889,7 +1025,13 @@ __global__ __launch_bounds__(64) void k_site_alleles(SumArgs a) {
                 if (lane == leader) {
                     if (nU < UMAX) {
                         u_src[nU] = ke.src; u_len[nU] = ke.len; u_type[nU] = ke.type; u_kind[nU] = ke.kind; u_imm[nU] = 0;
+                        if constexpr (HP) {
+                            u_ok[nU] = 1; u_fwd[nU] = 1; u_rev[nU] = 0;
+                            u_hc[0][nU] = (!e.rev && (hs & 1)) ? 1 : 0; u_hc[1][nU] = (!e.rev && (hs & 2)) ? 1 : 0;
+                            u_hc[2][nU] = (e.rev && (hs & 1)) ? 1 : 0;  u_hc[3][nU] = (e.rev && (hs & 2)) ? 1 : 0;
+                        } else {
                         u_ok[nU] = 1; u_fwd[nU] = e.rev ? 0 : 1; u_rev[nU] = e.rev ? 1 : 0;
+                        }
                         s_nU = nU + 1;
                     } else {
                         set_status(a.diag, PV_ERR_LIMIT);
@@ -946,6 +1088,11 @@ __global__ __launch_bounds__(64) void k_site_alleles(SumArgs a) {
                 const int e = nemit + __popcll(m & ((1ull << lane) - 1ull));
                 AlleleRec rc;
                 rc.src = u_src[k]; rc.len = u_len[k]; rc.total = u_fwd[k] + u_rev[k]; rc.fwd = u_fwd[k]; rc.rev = u_rev[k];
+                if constexpr (HP) {  // the four overlay values, already clamped (region_summary_hp.cpp:971-974)
+                    auto c8 = [](int v) { return (uint32_t)(v < PV_MAX_COLOR ? v : PV_MAX_COLOR); };
+                    rc.fwd = (int32_t)(c8(u_hc[0][k]) | (c8(u_hc[1][k]) << 8) | (c8(u_hc[2][k]) << 16) | (c8(u_hc[3][k]) << 24));
+                    rc.rev = 0;
+                }
                 rc.type = u_type[k]; rc.kind = u_kind[k]; rc.imm = u_imm[k]; rc.pad = 0; rc.pad2 = 0;
                 a.rec[recbase + e] = rc;
             }
@@ -1051,6 +1198,76 @@ __global__ __launch_bounds__(64) void k_write_windows(SumArgs a) {
                     const int b = rc.kind == 0 ? rc.imm : (rc.kind == 1 ? a.in.bases[rc.src + i] : a.in.ref[rc.src + i]);
                     a.out.cand_str[so + 1 + i] = (char)b;
                 }
+            }
+            so = send;
+        }
+    }
+}
+
+// Haplotag form of K8 (region_summary_hp.cpp:943-1003): 21 rows x 48 planes around the site, every plane clamped, the
+// five overlay values of the candidate on the middle row; no deletion tail, no sign flips.
+__global__ __launch_bounds__(64) void k_write_windows_hp(SumArgs a) {
+    const int lane = threadIdx.x;
+    if (a.diag[D_STATUS] != 0) return;
+    int64_t n_sites = a.diag[D_NSITES];
+    if (n_sites > a.max_sites) n_sites = a.max_sites;
+    const int64_t NC = a.n_cols;
+    constexpr int MID = (PV_HP_WINDOW_ROWS - 1) / 2;
+    for (int64_t s = blockIdx.x; s < n_sites; s += gridDim.x) {
+        const int nemit = a.site_nemit[s];
+        if (nemit == 0) continue;
+        const int64_t col = a.site_col[s];
+        const int g = a.site_region[s];
+        const int64_t col_base = a.in.ref_off[g];
+        const int64_t R = a.in.ref_end[g] - a.in.ref_start[g] + 1;
+        const int64_t ci = col - col_base;
+        const int cov = a.cnt[C_COV * NC + col];
+        const int depth = cov < PV_MAX_COLOR ? cov : PV_MAX_COLOR;
+        const int64_t recbase = (int64_t)a.site_evoff[s] + 4 * s;
+        int64_t so = a.site_stroff[s];
+        for (int e = 0; e < nemit; e++) {
+            const AlleleRec rc = a.rec[recbase + e];
+            const int64_t k = (int64_t)a.site_outoff[s] + e;
+            const int64_t send = so + 1 + rc.len;
+            if (k < a.out.capacity && send <= a.out.str_capacity) {
+                const int t = rc.type;  // 1 SNP, 2 INS, 3 DEL
+                const int v1 = t == 1 ? refcode(a.in.bases[rc.src]) : (rc.len < PV_MAX_COLOR ? rc.len : PV_MAX_COLOR);
+                const uint32_t hc = (uint32_t)rc.fwd;  // forward set 1, forward set 2, reverse set 1, reverse set 2
+                for (int el = lane; el < PV_HP_WINDOW_BYTES; el += 64) {
+                    const int row = el / PV_HP_FEATURES, pl = el - row * PV_HP_FEATURES;
+                    const int64_t i = ci - MID + row;
+                    int v = 0;
+                    if (i >= 0 && i < R) {  // row R of the reference's matrix exists and is all zero
+                        const int64_t c2 = col_base + i;
+                        if (pl == 0) v = refcode(a.in.ref[c2]);
+                        else if (pl >= 4) {
+                            const int grp = (pl - 4) / 11, w = (pl - 4) - 11 * grp;  // 0 REF count, 1-3 overlays, 4-10 symbols
+                            if (w == 0) v = a.cnt[(int64_t)(HC_PLANE + 8 * grp) * NC + c2];
+                            else if (w >= 4) v = a.cnt[(int64_t)(HC_PLANE + 8 * grp + (w - 3)) * NC + c2];
+                        }
+                        v = v > PV_MAX_COLOR ? PV_MAX_COLOR : (v < -PV_MAX_COLOR ? -PV_MAX_COLOR : v);  // :762-767
+                    }
+                    if (row == MID) {  // :970-974, :983-987, :996-1000
+                        if (pl == t) v = v1;
+                        if (pl == 4 + t) v = (int)(hc & 0xFF);
+                        if (pl == 26 + t) v = (int)((hc >> 8) & 0xFF);
+                        if (pl == 15 + t) v = (int)((hc >> 16) & 0xFF);
+                        if (pl == 37 + t) v = (int)((hc >> 24) & 0xFF);
+                    }
+                    a.out.images[k * PV_HP_WINDOW_BYTES + el] = (int8_t)(uint8_t)(v & 0xFF);
+                    if (a.out.images_i32) a.out.images_i32[k * PV_HP_WINDOW_BYTES + el] = v;
+                }
+                if (lane == 0) {
+                    a.out.region[k] = g;
+                    a.out.position[k] = a.in.ref_start[g] + ci;
+                    a.out.depth[k] = (uint8_t)depth;
+                    a.out.cand_freq[k] = (uint8_t)(rc.total < PV_MAX_COLOR ? rc.total : PV_MAX_COLOR);
+                    a.out.cand_off[k] = so;
+                    a.out.cand_off[k + 1] = send;
+                    a.out.cand_str[so] = (char)('0' + rc.type);
+                }
+                for (int i = lane; i < rc.len; i += 64)
+                    a.out.cand_str[so + 1 + i] = (char)(rc.kind == 1 ? a.in.bases[rc.src + i] : a.in.ref[rc.src + i]);
             }
             so = send;
         }
@@ -1379,7 +1596,13 @@ static inline unsigned int grid_for(int64_t n, int per) { return (unsigned int)(
 // Workspace + launch sequence. Everything asynchronous on `st`.
 static int summarize_launch(pv_ctx* ctx, const pv_batch_in* in, const pv_params* params, int64_t n_reads,
                             int64_t n_bases, int64_t n_cigar, int64_t n_cols, int64_t max_sites, int64_t max_events,
-                            int64_t max_pairs, const pv_batch_out* out, int64_t* d_counts, hipStream_t st) {
+                            int64_t max_pairs, const pv_batch_out* out, int64_t* d_counts, hipStream_t st,
+                            bool hp = false, const int32_t* read_hp = nullptr) {
+    if (hp)
+        PV_CHECK(params->candidate_window_size == PV_HP_WINDOW_ROWS - 1 && params->feature_size == PV_HP_FEATURES,
+                 PV_ERR_INVALID, "haplotag builder: candidate_window_size must be 20 and feature_size 48 (got %d, %d)",
+                 params->candidate_window_size, params->feature_size);
+    else
     PV_CHECK(params->candidate_window_size == 32 && params->feature_size == PV_FEATURES, PV_ERR_INVALID,
              "candidate_window_size must be 32 and feature_size 26 (got %d, %d)", params->candidate_window_size,
              params->feature_size);
@@ -1393,6 +1616,8 @@ static int summarize_launch(pv_ctx* ctx, const pv_batch_in* in, const pv_params*
     a.max_sites = max_sites; a.max_events = max_events;
     a.out = *out;
     a.d_counts = d_counts;
+    a.hp = hp ? 1 : 0;
+    a.read_hp = read_hp;
     const int64_t n_blk = (n_cols + 1023) / 1024;
     int rc;
     const int64_t nc1 = n_cigar > 0 ? n_cigar : 1, nr1 = n_reads > 0 ? n_reads : 1;
@@ -1414,7 +1639,7 @@ static int summarize_launch(pv_ctx* ctx, const pv_batch_in* in, const pv_params*
     if ((rc = pv_get(ctx, "sum.tile_off", a.n_tiles, &a.tile_off))) return rc;
     if ((rc = pv_get(ctx, "sum.tile_fill", a.n_tiles, &a.tile_fill))) return rc;
     if ((rc = pv_get(ctx, "sum.pairs", max_pairs, &a.pairs))) return rc;
-    if ((rc = pv_get(ctx, "sum.cnt", (size_t)NCNT * n_cols, &a.cnt))) return rc;
+    if ((rc = pv_get(ctx, "sum.cnt", (size_t)(hp ? NCNT_HP : NCNT) * n_cols, &a.cnt))) return rc;
     if ((rc = pv_get(ctx, "sum.flags", n_cols, &a.flags))) return rc;
     if ((rc = pv_get(ctx, "sum.site_rank", n_cols, &a.site_rank))) return rc;
     if ((rc = pv_get(ctx, "sum.blk_cnt", n_blk, &a.blk_cnt))) return rc;
@@ -1437,16 +1662,28 @@ static int summarize_launch(pv_ctx* ctx, const pv_batch_in* in, const pv_params*
     if (n_reads > 0) { pv_prof_scope ps(ctx, "k_cigar_scan", st); k_cigar_scan<<<grid_for(n_reads, 4), 256, 0, st>>>(a); }
     k_scan_tiles<<<1, 1024, 0, st>>>(a);
     if (n_reads > 0) { pv_prof_scope ps(ctx, "k_tile_fill", st); k_tile_fill<<<grid_for(n_reads, 4), 256, 0, st>>>(a); }
-    { pv_prof_scope ps(ctx, "k_pileup", st); k_pileup_tiles<<<(unsigned)a.n_tiles, PT_THREADS, 0, st>>>(a); }
+    {
+        pv_prof_scope ps(ctx, "k_pileup", st);
+        if (hp) k_pileup_tiles<true><<<(unsigned)a.n_tiles, PT_THREADS, 0, st>>>(a);
+        else k_pileup_tiles<false><<<(unsigned)a.n_tiles, PT_THREADS, 0, st>>>(a);
+    }
     k_site_scan<<<(unsigned)n_blk, 1024, 0, st>>>(a);
     k_scan_blocks<<<1, 1024, 0, st>>>(a, n_blk);
     k_site_rank<<<(unsigned)n_blk, 1024, 0, st>>>(a);
     k_scan_events<<<1, 1024, 0, st>>>(a);
     if (n_cigar > 0 && n_reads > 0) { pv_prof_scope ps(ctx, "k_collect", st); k_collect<<<(unsigned)n_reads, 256, 0, st>>>(a); }
     const unsigned site_grid = (unsigned)(max_sites < 4096 ? (max_sites > 0 ? max_sites : 1) : 4096);
-    { pv_prof_scope ps(ctx, "k_site_alleles", st); k_site_alleles<<<site_grid, 64, 0, st>>>(a); }
+    {
+        pv_prof_scope ps(ctx, "k_site_alleles", st);
+        if (hp) k_site_alleles<true><<<site_grid, 64, 0, st>>>(a);
+        else k_site_alleles<false><<<site_grid, 64, 0, st>>>(a);
+    }
     k_scan_outputs<<<1, 1024, 0, st>>>(a);
-    { pv_prof_scope ps(ctx, "k_write_windows", st); k_write_windows<<<site_grid, 64, 0, st>>>(a); }
+    {
+        pv_prof_scope ps(ctx, "k_write_windows", st);
+        if (hp) k_write_windows_hp<<<site_grid, 64, 0, st>>>(a);
+        else k_write_windows<<<site_grid, 64, 0, st>>>(a);
+    }
     PV_HIP(hipGetLastError());
     return PV_OK;
 }
@@ -1478,6 +1715,19 @@ extern "C" int pv_summarize_regions_dev(pv_ctx* ctx, const pv_batch_in* in, cons
                             d_counts, pv_pick_stream(ctx, stream));
 }
 
+extern "C" int pv_summarize_regions_hp_dev(pv_ctx* ctx, const pv_batch_in* in, const int32_t* read_hp, const pv_params* params,
+                                           int64_t n_reads, int64_t n_bases, int64_t n_cigar, int64_t n_ref_bytes,
+                                           pv_batch_out* out, int64_t* d_counts, void* stream) {
+    PV_CHECK(ctx && in && params && out && d_counts, PV_ERR_INVALID, "null argument");
+    PV_CHECK(in->n_regions >= 0 && n_ref_bytes >= 0, PV_ERR_INVALID, "negative sizes");
+    PV_HIP(hipSetDevice(ctx->device));
+    int64_t ms, me, mp;
+    default_limits(n_ref_bytes, n_cigar, n_bases, n_reads, out->capacity, &ms, &me, &mp);
+    me += n_bases / 16;  // every SNP observation at a site is an event in this form
+    return summarize_launch(ctx, in, params, n_reads, n_bases, n_cigar, n_ref_bytes > 0 ? n_ref_bytes : 1, ms, me, mp, out,
+                            d_counts, pv_pick_stream(ctx, stream), true, read_hp);
+}
+
 template <typename T>
 static int upload(pv_ctx* ctx, const char* name, const T* h, size_t n, const T** d, hipStream_t st) {
     T* p = nullptr;
@@ -1488,8 +1738,21 @@ static int upload(pv_ctx* ctx, const char* name, const T* h, size_t n, const T**
     return PV_OK;
 }
 
+static int summarize_host(pv_ctx* ctx, const pv_batch_in* in, const pv_params* params, pv_batch_out* out, bool hp,
+                          const int32_t* read_hp);
 extern "C" int pv_summarize_regions(pv_ctx* ctx, const pv_batch_in* in, const pv_params* params, pv_batch_out* out) {
+    return summarize_host(ctx, in, params, out, false, nullptr);
+}
+extern "C" int pv_summarize_regions_hp(pv_ctx* ctx, const pv_batch_in* in, const int32_t* read_hp, const pv_params* params,
+                                       pv_batch_out* out) {
+    return summarize_host(ctx, in, params, out, true, read_hp);
+}
+
+// host buffers in and out; `hp` selects the haplotag-aware builder (window bytes, one more input array)
+static int summarize_host(pv_ctx* ctx, const pv_batch_in* in, const pv_params* params, pv_batch_out* out, bool hp,
+                          const int32_t* read_hp) {
     PV_CHECK(ctx && in && params && out, PV_ERR_INVALID, "null argument");
+    const size_t WB = hp ? PV_HP_WINDOW_BYTES : PV_WINDOW_BYTES;
     PV_HIP(hipSetDevice(ctx->device));
     hipStream_t st = ctx->stream;
     const int G = in->n_regions;
@@ -1528,6 +1791,9 @@ extern "C" int pv_summarize_regions(pv_ctx* ctx, const pv_batch_in* in, const pv
     if ((rc = upload(ctx, "in.quals", in->quals, n_bases, &d.quals, st))) return rc;
     if ((rc = upload(ctx, "in.cigar_off", in->cigar_off, n_reads + 1, &d.cigar_off, st))) return rc;
     if ((rc = upload(ctx, "in.cigar", in->cigar, n_cigar, &d.cigar, st))) return rc;
+    const int32_t* d_hp = nullptr;
+    if (hp && read_hp)
+        if ((rc = upload(ctx, "in.read_hp", read_hp, n_reads, &d_hp, st))) return rc;
 
     const int64_t cap = out->capacity > 0 ? out->capacity : 0, scap = out->str_capacity > 0 ? out->str_capacity : 0;
     pv_batch_out dout = *out;
@@ -1535,10 +1801,10 @@ extern "C" int pv_summarize_regions(pv_ctx* ctx, const pv_batch_in* in, const pv
     if ((rc = pv_get(ctx, "out.position", cap + 1, &dout.position))) return rc;
     if ((rc = pv_get(ctx, "out.depth", cap + 1, &dout.depth))) return rc;
     if ((rc = pv_get(ctx, "out.cand_freq", cap + 1, &dout.cand_freq))) return rc;
-    if ((rc = pv_get(ctx, "out.images", (size_t)(cap + 1) * PV_WINDOW_BYTES, &dout.images))) return rc;
+    if ((rc = pv_get(ctx, "out.images", (size_t)(cap + 1) * WB, &dout.images))) return rc;
     dout.images_i32 = nullptr;
     if (out->images_i32)
-        if ((rc = pv_get(ctx, "out.images_i32", (size_t)(cap + 1) * PV_WINDOW_BYTES, &dout.images_i32))) return rc;
+        if ((rc = pv_get(ctx, "out.images_i32", (size_t)(cap + 1) * WB, &dout.images_i32))) return rc;
     if ((rc = pv_get(ctx, "out.cand_str", scap + 1, &dout.cand_str))) return rc;
     if ((rc = pv_get(ctx, "out.cand_off", cap + 2, &dout.cand_off))) return rc;
     int64_t* d_counts = nullptr;
@@ -1546,8 +1812,9 @@ extern "C" int pv_summarize_regions(pv_ctx* ctx, const pv_batch_in* in, const pv
 
     int64_t ms, me, mp;
     default_limits(n_cols, n_cigar, n_bases, n_reads, cap, &ms, &me, &mp);
+    if (hp) me += n_bases / 16;
     for (int attempt = 0; attempt < 3; attempt++) {
-        rc = summarize_launch(ctx, &d, params, n_reads, n_bases, n_cigar, n_cols, ms, me, mp, &dout, d_counts, st);
+        rc = summarize_launch(ctx, &d, params, n_reads, n_bases, n_cigar, n_cols, ms, me, mp, &dout, d_counts, st, hp, d_hp);
         if (rc) return rc;
         PV_HIP(hipMemcpyAsync(ctx->h_counts, d_counts, 4 * sizeof(int64_t), hipMemcpyDeviceToHost, st));
         PV_HIP(hipStreamSynchronize(st));
@@ -1576,10 +1843,9 @@ extern "C" int pv_summarize_regions(pv_ctx* ctx, const pv_batch_in* in, const pv
         PV_HIP(hipMemcpyAsync(out->position, dout.position, n * sizeof(int64_t), hipMemcpyDeviceToHost, st));
         PV_HIP(hipMemcpyAsync(out->depth, dout.depth, n, hipMemcpyDeviceToHost, st));
         PV_HIP(hipMemcpyAsync(out->cand_freq, dout.cand_freq, n, hipMemcpyDeviceToHost, st));
-        PV_HIP(hipMemcpyAsync(out->images, dout.images, n * PV_WINDOW_BYTES, hipMemcpyDeviceToHost, st));
+        PV_HIP(hipMemcpyAsync(out->images, dout.images, n * WB, hipMemcpyDeviceToHost, st));
         if (out->images_i32)
-            PV_HIP(hipMemcpyAsync(out->images_i32, dout.images_i32, n * PV_WINDOW_BYTES * sizeof(int32_t),
-                                  hipMemcpyDeviceToHost, st));
+            PV_HIP(hipMemcpyAsync(out->images_i32, dout.images_i32, n * WB * sizeof(int32_t), hipMemcpyDeviceToHost, st));
         PV_HIP(hipMemcpyAsync(out->cand_str, dout.cand_str, out->str_bytes, hipMemcpyDeviceToHost, st));
         PV_HIP(hipMemcpyAsync(out->cand_off, dout.cand_off, (n + 1) * sizeof(int64_t), hipMemcpyDeviceToHost, st));
         PV_HIP(hipStreamSynchronize(st));

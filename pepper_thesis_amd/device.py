@@ -41,6 +41,8 @@ class DeviceBatch:
             self.t[f] = t
             setattr(c, f, t.data_ptr())
         self.c = c
+        # type_read::hp_tag per read for the haplotag-aware builder (passed next to pv_batch_in); None = untagged
+        self.read_hp = None if batch.read_hp is None else torch.from_numpy(batch.read_hp).to(device)
         self.n_reads, self.n_bases, self.n_cigar = batch.n_reads, batch.n_bases, batch.n_cigar
         self.n_ref_bytes = int(batch.ref.shape[0])
         self.max_region_len = batch.max_region_len
@@ -66,6 +68,7 @@ class DeviceOut:
         self.position = torch.zeros(capacity, dtype=torch.int64, device=device)
         self.depth = torch.zeros(capacity, dtype=torch.uint8, device=device)
         self.cand_freq = torch.zeros(capacity, dtype=torch.uint8, device=device)
+        # [capacity,33,26]; the haplotag-aware builder writes [capacity,21,48] (pass such a tensor as `images`)
         self.images = images if images is not None else torch.zeros((capacity, 33, 26), dtype=torch.int8, device=device)
         assert self.images.is_contiguous() and self.images.shape[0] >= capacity
         self.cand_str = torch.zeros(str_capacity, dtype=torch.uint8, device=device)

@@ -70,6 +70,25 @@ class Context:
             return ob.result()
         _ffi.check(rc)
 
+    def summarize_hp(self, batch: RegionBatch, params: Params, want_i32: bool = False,
+                     capacity: Optional[int] = None, str_capacity: Optional[int] = None) -> SummaryOut:
+        """RegionalSummaryGeneratorHP.generate_summary (haplotag-aware, 48 planes x 21 rows) for every region of the
+        batch; batch.read_hp carries type_read::hp_tag (None = untagged reads); params must carry window 20 / 48 features
+        (batch.hp_params)."""
+        from .batch import hp_pointer
+        cin, cp = batch.as_c(), params.as_c()
+        cap = capacity or max(1024, batch.n_regions * 1024)
+        scap = str_capacity or cap * 8
+        for _ in range(3):
+            ob = OutBuffers(cap, scap, want_i32, _ffi.PV_HP_WINDOW_ROWS, _ffi.PV_HP_FEATURES)
+            rc = self.lib.pv_summarize_regions_hp(self.handle, C.byref(cin), hp_pointer(batch), C.byref(cp), C.byref(ob.c))
+            if rc == _ffi.PV_ERR_CAPACITY:
+                cap, scap = max(cap, int(ob.c.n_out)), max(scap, int(ob.c.str_bytes))
+                continue
+            _ffi.check(rc)
+            return ob.result()
+        _ffi.check(rc)
+
     # ---- RNN ------------------------------------------------------------------------------------------
     def load_p1(self, weights: dict, dtype: int = _ffi.PV_DTYPE_F32):
         """weights: state_dict of the pepper_variant TransducerGRU as numpy arrays (ModelHander.py:18-44)."""
@@ -155,6 +174,15 @@ class Context:
         _ffi.check(self.lib.pv_summarize_regions_dev(
             self.handle, C.byref(dbatch.c), C.byref(cp), dbatch.n_reads, dbatch.n_bases, dbatch.n_cigar,
             dbatch.n_ref_bytes, dbatch.max_region_len, C.byref(dout.c), dout.counts.data_ptr(), stream or None))
+
+    def summarize_hp_dev(self, dbatch: "DeviceBatch", params: Params, dout: "DeviceOut", stream: int = 0):
+        """asynchronous, device-resident haplotag-aware builder: dout.images must be an int8 [capacity,21,48] tensor"""
+        cp = params.as_c()
+        assert tuple(dout.images.shape[1:]) == (_ffi.PV_HP_WINDOW_ROWS, _ffi.PV_HP_FEATURES), dout.images.shape
+        _ffi.check(self.lib.pv_summarize_regions_hp_dev(
+            self.handle, C.byref(dbatch.c), None if dbatch.read_hp is None else dbatch.read_hp.data_ptr(), C.byref(cp),
+            dbatch.n_reads, dbatch.n_bases, dbatch.n_cigar, dbatch.n_ref_bytes, C.byref(dout.c), dout.counts.data_ptr(),
+            stream or None))
 
     def polish_summarize(self, batch: RegionBatch, seq_length: int = 1000, seq_overlap: int = 50, want_flat: bool = False):
         """Polisher (P2) SummaryGenerator.generate_summary + chunk_images for a batch (host buffers), see polish_summary.py."""

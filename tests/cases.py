@@ -217,3 +217,42 @@ GOLDEN_RANDOM = [
 
 def random_batch(seed, kw):
     return pack_regions([synth.synth_region(seed, **kw)])
+
+
+# ---- haplotag-aware builder (region_summary_hp.cpp): the same regions with an HP tag on every read -------------------
+# tags 0 (untagged), 1, 2 and the values a real BAM never carries but the reference still has a defined answer for (3, -1)
+HP_TAG_CHOICES = (0, 0, 1, 2, 1, 2, 3, -1)
+
+
+def tag_reads(regions, seed, choices=HP_TAG_CHOICES):
+    rng = np.random.default_rng(seed)
+    for r in regions:
+        for rd in r.reads:
+            rd.hp_tag = int(rng.choice(choices))
+    return regions
+
+
+def hp_edge_batch(name, seed=5):
+    return pack_regions(tag_reads(EDGE_CASES[name](), seed))
+
+
+def hp_all_edges_batch(seed=5):
+    regs = []
+    for name in EDGE_CASES:
+        regs.extend(EDGE_CASES[name]())
+    return pack_regions(tag_reads(regs, seed))
+
+
+def hp_known_answer():
+    """hand-checkable: 8 reads over ACGTACGTAC...; column 40 (ref 'A') carries a T in three reads (one per tag 0, 1, 2)"""
+    ref = (b"ACGT" * 30)[:100]
+    reads = []
+    for i, (hp, rev, alt) in enumerate([(0, False, True), (1, False, True), (2, True, True), (0, True, False),
+                                        (1, False, False), (2, False, False), (1, True, False), (2, True, False)]):
+        seq = _flip(ref, 40, "T") if alt else ref
+        reads.append(Read.make(0, "100M", seq, 30, rev, hp_tag=hp))
+    return Region(0, 99, ref, reads)
+
+
+def hp_random_batch(seed, kw):
+    return pack_regions(tag_reads([synth.synth_region(seed, **kw)], seed))

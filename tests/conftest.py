@@ -29,6 +29,13 @@ def summary_golden():
 
 
 @pytest.fixture(scope="session")
+def summary_hp_golden():
+    import numpy as np
+    path = os.path.join(ROOT, "tests", "golden", "summary_hp_golden.npz")
+    return np.load(path, allow_pickle=False)
+
+
+@pytest.fixture(scope="session")
 def hip_ctx():
     """one device context for the whole GPU session; fails loudly if the extension is missing"""
     from pepper_thesis_amd import runtime

@@ -18,6 +18,21 @@ def golden_case(g, entry):
     return batch, PRESETS[preset], exp
 
 
+def hp_golden_case(g, entry):
+    """tests/golden/summary_hp_golden.npz: the same layout plus in/read_hp; parameters carry the 20 / 48 window geometry"""
+    from pepper_thesis_amd.batch import hp_params
+    name, preset = entry.split("|")
+    arrs = {f: np.ascontiguousarray(g["%s/in/%s" % (name, f)]) for f in RegionBatch.FIELDS}
+    batch = RegionBatch(n_regions=int(arrs["ref_start"].shape[0]), **arrs)
+    hp = np.ascontiguousarray(g["%s/in/read_hp" % name]).astype(np.int32)
+    batch.read_hp = hp if hp.any() else None
+    exp = {k: g["%s/out/%s" % (name, k)] for k in ("region", "position", "depth", "cand_freq", "images", "candidates")}
+    key = "%s/out/images_i32" % name
+    exp["images_i32"] = g[key] if key in g.files else None
+    exp["candidates"] = [c.decode("latin-1") for c in exp["candidates"]]
+    return batch, hp_params(PRESETS[preset]), exp
+
+
 def assert_summary_equal(out, exp, what=""):
     assert len(out) == len(exp["position"]), "%s: window count %d != %d" % (what, len(out), len(exp["position"]))
     assert out.candidates == list(exp["candidates"]), what

@@ -1,0 +1,113 @@
+"""GPU: the haplotag-aware HIP image builder (pv_summarize_regions_hp through the C-ABI) against the golden vectors of
+the reference's region_summary_hp.cpp and against the CPU oracle. Integer work: bit-exact."""
+import numpy as np
+import pytest
+
+import cases
+from golden_io import assert_summary_equal, golden_names, hp_golden_case, summary_as_expected
+from pepper_thesis_amd import synth
+from pepper_thesis_amd.batch import PRESETS, hp_params, pack_regions
+from test_oracle_summary_hp import HP_KNOWN_ROW
+
+pytestmark = pytest.mark.gpu
+
+
+def test_golden_vectors(hip_ctx, summary_hp_golden):
+    n = 0
+    for entry in golden_names(summary_hp_golden):
+        batch, params, exp = hp_golden_case(summary_hp_golden, entry)
+        out = hip_ctx.summarize_hp(batch, params, want_i32=True)
+        assert_summary_equal(out, exp, entry)
+        n += len(out)
+    assert n > 400
+
+
+def test_known_answer(hip_ctx):
+    o = hip_ctx.summarize_hp(pack_regions([cases.hp_known_answer()]), hp_params(PRESETS["ont_r9_guppy5_sup"]), True)
+    assert (len(o), int(o.position[0]), int(o.depth[0]), o.candidates, int(o.cand_freq[0])) == (1, 40, 8, ["1T"], 3)
+    assert o.images.shape == (1, 21, 48) and o.images_i32[0, 10].tolist() == HP_KNOWN_ROW
+
+
+def test_all_edges_one_batch(hip_ctx, oracle_lib):
+    for preset in PRESETS:
+        b = cases.hp_all_edges_batch()
+        P = hp_params(PRESETS[preset])
+        o = hip_ctx.summarize_hp(b, P, True)
+        assert_summary_equal(o, summary_as_expected(oracle_lib.summarize_hp(b, P, True)), preset)
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_random_regions_vs_oracle(hip_ctx, oracle_lib, seed):
+    rng = np.random.default_rng(seed)
+    preset = list(PRESETS)[seed % len(PRESETS)]
+    regs = [synth.synth_region(500 + 10 * seed + k, region_len=int(rng.integers(300, 6000)),
+                               depth=int(rng.integers(5, 90)), read_len=int(rng.integers(200, 3000)),
+                               site_every=int(rng.integers(15, 200)), n_rate=0.002 * (seed % 2),
+                               ref_n_rate=0.0, mismatch=0.03 * (1 + seed % 3))
+            for k in range(5)]
+    batch = pack_regions(cases.tag_reads(regs, seed))
+    P = hp_params(PRESETS[preset])
+    o = hip_ctx.summarize_hp(batch, P, True)
+    assert_summary_equal(o, summary_as_expected(oracle_lib.summarize_hp(batch, P, True)), "seed %d" % seed)
+    assert len(o) > 0
+
+
+def test_untagged_batch_has_equal_haplotype_halves(hip_ctx, oracle_lib):
+    """read_hp == NULL: every read counts in both haplotypes; still the oracle's answer"""
+    b = cases.random_batch(16, cases.GOLDEN_RANDOM[5][1])
+    assert b.read_hp is None
+    P = hp_params(PRESETS["ont_r9_guppy5_sup"])
+    o = hip_ctx.summarize_hp(b, P, True)
+    np.testing.assert_array_equal(o.images_i32[:, :, 4:26], o.images_i32[:, :, 26:48])
+    assert_summary_equal(o, summary_as_expected(oracle_lib.summarize_hp(b, P, True)), "untagged")
+
+
+def test_lowercase_and_foreign_bytes(hip_ctx, oracle_lib):
+    from pepper_thesis_amd.batch import Read, Region
+    ref = b"ACGTacgtACGTNNACGTacgtACGTACGTAAAACCCCGGGGTTTTACGT"
+    reads = []
+    rng = np.random.default_rng(3)
+    syms = np.frombuffer(b"ACGTacgtNnRYKM*-=", dtype=np.uint8)
+    for i in range(40):
+        seq = bytearray(ref)
+        for j in rng.integers(0, len(ref), size=6):
+            seq[j] = int(rng.choice(syms))
+        if i % 3 == 0:
+            seq[5], seq[2], seq[13] = ord("C"), ord("g"), ord("A")  # over 'c' (raw mismatch), over 'G' (lower-case allele), over 'N'
+        reads.append(Read.make(10, "%dM" % len(ref), bytes(seq), 20, i % 2 == 0, hp_tag=i % 4))
+    P = hp_params(PRESETS["ont_r9_guppy5_sup"])
+    b = pack_regions([Region(10, 10 + len(ref) - 1, ref, reads)])
+    o = hip_ctx.summarize_hp(b, P, True)
+    assert_summary_equal(o, summary_as_expected(oracle_lib.summarize_hp(b, P, True)), "foreign")
+    assert {"1C", "1g", "1A"} <= set(o.candidates)
+
+
+def test_full_size_region_many_sites(hip_ctx, oracle_lib):
+    """a 10 kb region at 60x with a site every ~25 columns: the event buckets hold every SNP observation"""
+    reg = synth.synth_region(77, region_len=10000, depth=60, read_len=4000, site_every=25, mismatch=0.05)
+    batch = pack_regions(cases.tag_reads([reg], 77))
+    P = hp_params(PRESETS["ont_r9_guppy5_sup"])
+    o = hip_ctx.summarize_hp(batch, P)
+    assert_summary_equal(o, summary_as_expected(oracle_lib.summarize_hp(batch, P)), "full size")
+    assert len(o) > 300
+
+
+def test_capacity_growth_and_geometry_check(hip_ctx):
+    from pepper_thesis_amd import _ffi
+    b = cases.hp_random_batch(11, cases.GOLDEN_RANDOM[0][1])
+    o = hip_ctx.summarize_hp(b, hp_params(PRESETS["ont_r9_guppy5_sup"]), capacity=3, str_capacity=5)
+    assert len(o) == 74
+    with pytest.raises(_ffi.PepperHipError) as e:
+        hip_ctx.summarize_hp(b, PRESETS["ont_r9_guppy5_sup"])  # window 32 / 26 planes belongs to the other builder
+    assert e.value.code == _ffi.PV_ERR_INVALID
+
+
+def test_host_mirror_class(hip_ctx, oracle_lib):
+    """RegionalSummaryGeneratorHP with the reference's constructor / generate_summary argument order"""
+    from pepper_thesis_amd.region_summary import RegionalSummaryGeneratorHP
+    reg = cases.hp_known_answer()
+    gen = RegionalSummaryGeneratorHP("chr20", reg.ref_start, reg.ref_end, reg.ref.decode(), ctx=hip_ctx)
+    gen.generate_max_insert_summary(reg.reads)
+    res = gen.generate_summary(reg.reads, 1, 1, 0.10, 0.15, 0.15, 3, 0.10, 0.10, 2, False, reg.ref_start, reg.ref_end, 20, 48, False)
+    assert len(res) == 1 and res[0].contig == "chr20" and res[0].position == 40 and res[0].candidates == ["1T"]
+    assert res[0].image_matrix.shape == (21, 48) and res[0].image_matrix[10].tolist() == HP_KNOWN_ROW
