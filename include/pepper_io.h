@@ -75,6 +75,7 @@ typedef struct pvio_batch {
     double t_inflate;              /* stage timers (seconds): BGZF read + inflate ... */
     double t_total;                /* ... and the whole call (record decode + clip + FASTA = t_total - t_inflate) */
     int64_t bytes_inflated;
+    const int32_t* read_hp;        /* [n_reads] HP aux tag or 0: the `read_hp` argument of pv_summarize_regions_hp */
 } pvio_batch;
 int pvio_fill_batch(pv_bam* bam, pv_fasta* fa, int n_intervals, const char* const* contigs, const int64_t* starts,
                     const int64_t* ends, int safe_bases, int include_supplementary, int min_mapq, double downsample_rate,

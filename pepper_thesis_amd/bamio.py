@@ -35,7 +35,8 @@ class pvio_batch(C.Structure):
                 ("base_off", C.POINTER(C.c_int64)), ("bases", C.POINTER(C.c_uint8)), ("quals", C.POINTER(C.c_uint8)),
                 ("cigar_off", C.POINTER(C.c_int64)), ("cigar", C.POINTER(C.c_uint32)),
                 ("interval_index", C.POINTER(C.c_int64)), ("reads_seen", C.POINTER(C.c_int64)),
-                ("t_inflate", C.c_double), ("t_total", C.c_double), ("bytes_inflated", C.c_int64)]
+                ("t_inflate", C.c_double), ("t_total", C.c_double), ("bytes_inflated", C.c_int64),
+                ("read_hp", C.POINTER(C.c_int32))]
 
 
 IO_SYMBOLS = [
@@ -216,6 +217,8 @@ class FilledBatch:
             view(v.read_mapq, n, np.uint8), view(v.base_off, n + 1, np.int64), view(v.bases, nb, np.uint8),
             view(v.quals, nb, np.uint8), view(v.cigar_off, n + 1, np.int64), view(v.cigar, nc, np.uint32),
             [self.intervals[int(i)][0] for i in self.interval_index])
+        hp = view(v.read_hp, n, np.int32)
+        self.batch.read_hp = hp if hp.any() else None   # type_read::hp_tag, read only by the haplotag-aware builder
 
     def close(self):
         if getattr(self, "_ptr", None) is not None:

@@ -889,6 +889,7 @@ extern "C" int pvio_fill_batch(pv_bam* b, pv_fasta* fa, int n_intervals, const c
     v.t_inflate = b->z.t_inflate - infl0;
     v.t_total = now_s() - t_begin;
     v.bytes_inflated = b->z.bytes_inflated - inflb0;
+    v.read_hp = s.hp.data();
     *out = &st->view;
     return 0;
 }

@@ -97,7 +97,8 @@ def list_intervals(fasta, bam, region: str = None, region_size: int = 100_000) -
 def generate_images(ctx, bam_path: str, fasta_path: str, output_dir: str, params: Params, region: str = None,
                     region_size: int = 100_000, min_mapq: int = 5, include_supplementary: bool = False,
                     downsample_rate: float = 1.0, intervals_per_call: int = 16, rank: int = 0, world: int = 1,
-                    reader_threads: int = None, timers: dict = None, intervals_per_read: int = 1) -> int:
+                    reader_threads: int = None, timers: dict = None, intervals_per_read: int = 1,
+                    use_hp_info: bool = False) -> int:
     """generate_images (ImageGenerationUI.py:277-345) on the MI355X path: intervals of region_size, interval i handled
     by rank i % world (:211), `intervals_per_call` intervals per builder launch chain, one HDF5 file per rank.
 
@@ -106,7 +107,9 @@ def generate_images(ctx, bam_path: str, fasta_path: str, output_dir: str, params
     `intervals_per_read` intervals at a time straight into the flat pv_batch_in arrays in native code (bamio.fill_batch, GIL
     released), running ahead of the GPU; the calling thread merges `intervals_per_call` of them per builder launch chain
     (array concatenation), hands them to the builder and writes the HDF5 groups.
-    `timers` (optional dict) receives the stage times in seconds."""
+    `timers` (optional dict) receives the stage times in seconds.
+    use_hp_info (`-hp`, ImageGenerationUI.py:48-71,206-207): the haplotag-aware builder (AlignmentSummarizerHP.py:176-233:
+    the same fetch, RegionalSummaryGeneratorHP with window 20 / 48 planes, the reads' HP tags); the file name gets "_hp"."""
     import os
     import threading
     import time
@@ -134,7 +137,11 @@ def generate_images(ctx, bam_path: str, fasta_path: str, output_dir: str, params
     T = dict(read_inflate_cpu_s=0.0, read_decode_cpu_s=0.0, reader_stall_s=0.0, merge_s=0.0, builder_call_s=0.0, hdf5_write_s=0.0,
              bytes_inflated=0, reader_threads=n_thr, intervals=len(mine), bases=0, reads=0)
     n_windows = 0
-    with ImageStore(os.path.join(output_dir, "pepper_variants_images_thread_%d.hdf5" % rank), "w") as store, \
+    if use_hp_info:
+        from .batch import hp_params
+        params = hp_params(params)
+    fname = "pepper_variants_images_thread_%d%s.hdf5" % (rank, "_hp" if use_hp_info else "")
+    with ImageStore(os.path.join(output_dir, fname), "w") as store, \
             ThreadPoolExecutor(n_thr) as pool:
         pending = deque()
         nxt = 0
@@ -167,7 +174,7 @@ def generate_images(ctx, bam_path: str, fasta_path: str, output_dir: str, params
             T["bases"] += batch.n_bases
             T["reads"] += batch.n_reads
             t0 = time.perf_counter()
-            out = ctx.summarize(batch, params)
+            out = ctx.summarize_hp(batch, params) if use_hp_info else ctx.summarize(batch, params)
             T["builder_call_s"] += time.perf_counter() - t0
             t0 = time.perf_counter()
             for g, (contig, start, end) in enumerate(names):
@@ -230,6 +237,8 @@ def main(argv=None):
     ap.add_argument("--include_supplementary", action="store_true")
     ap.add_argument("--min_mapq", type=int, default=None, help="default: the platform preset's value (SetParameters.py)")
     ap.add_argument("-t", "--threads", type=int, default=1)
+    ap.add_argument("-hp", "--use_hp_info", action="store_true", default=False,
+                    help="haplotag-aware images (48 planes x 21 rows) from the reads' HP tags")
     g = ap.add_mutually_exclusive_group(required=True)
     for name in PRESETS:
         g.add_argument("--" + name, action="store_true")
@@ -240,7 +249,8 @@ def main(argv=None):
     rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
     ctx = Context(int(os.environ.get("LOCAL_RANK", "0")))
     n = generate_images(ctx, args.bam, args.fasta, args.output_dir, params, args.region, args.region_size,
-                        args.min_mapq, args.include_supplementary, args.downsample_rate, rank=rank, world=world)
+                        args.min_mapq, args.include_supplementary, args.downsample_rate, rank=rank, world=world,
+                        use_hp_info=args.use_hp_info)
     ctx.close()
     import sys
     sys.stderr.write("INFO: FINISHED IMAGE GENERATION: %d WINDOWS\n" % n)

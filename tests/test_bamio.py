@@ -210,6 +210,9 @@ def test_fill_batch_equals_per_read_path_and_reservoir(files):
         assert fb.interval_index.tolist() == keep
         for fld in RegionBatch.FIELDS:
             np.testing.assert_array_equal(getattr(ref, fld), getattr(fb.batch, fld), err_msg=fld)
+        # the HP tags travel next to the batch (input of the haplotag-aware builder)
+        assert ref.read_hp is not None and set(np.unique(ref.read_hp).tolist()) == {0, 1, 2}
+        np.testing.assert_array_equal(ref.read_hp, fb.batch.read_hp)
         fb.close()
 
 

@@ -112,6 +112,18 @@ def test_bam_to_predictions_end_to_end(hip_ctx, oracle_lib, tmp_path):
     with hdf5io.PredictionStore(str(tmp_path / "pred" / "pepper_prediction.hdf"), "r") as st:
         total = sum(bt["base_prediction"].shape[0] for _, bt in st.batches())
     assert total == n
+    # make_images -hp: the same BAM (half of its reads carry an HP tag) through the haplotag-aware builder
+    from pepper_thesis_amd.batch import hp_params
+    make_images.main(["-b", str(tmp_path / "reads.bam"), "-f", str(tmp_path / "ref.fa"), "-o", str(tmp_path / "images_hp"),
+                      "-r", "chr20:5000-45000", "--region_size", "10000", "--ont_r9_guppy5_sup", "-hp"])
+    tagged = pack_regions([bamio.region_from_files(b, f, c, a, e) for c, a, e in ivs])
+    assert tagged.read_hp is not None and set(np.unique(tagged.read_hp).tolist()) == {0, 1, 2}
+    exp_hp = oracle_lib.summarize_hp(tagged, hp_params(P))
+    with hdf5io.ImageStore(str(tmp_path / "images_hp" / "pepper_variants_images_thread_0_hp.hdf5"), "r") as st:
+        parts = {nm: st.read_summary(nm) for nm in st.summaries()}
+    got_hp = np.concatenate([parts["%s_%d_%d" % iv]["images"] for iv in ivs])
+    assert got_hp.shape == (len(exp_hp), 21, 48) and len(exp_hp) > 100
+    np.testing.assert_array_equal(got_hp, exp_hp.images)
 
 
 def test_call_variant_bam_to_vcf(hip_ctx, oracle_lib, tmp_path):

@@ -16,8 +16,8 @@ def run(ctx, dev, regions=None, reps=20):
     from pepper_thesis_amd.batch import PRESETS, hp_params, pack_regions
     from pepper_thesis_amd.device import DeviceBatch, DeviceOut
     if regions is None:
-        regions = [synth.synth_region(1234 + 97 * i, region_len=10200, depth=60, read_len=9000, site_every=198,
-                                      ref_start=1_000_000 + i * 10000) for i in range(16)]
+        regions = [synth.synth_region(1234 + 97 * i, region_len=100_200, depth=60, read_len=10_000, site_every=198,
+                                      ref_start=1_000_000 + i * 100_000) for i in range(16)]   # bench.py's regions
     rng = np.random.default_rng(7)
     for r in regions:
         for rd in r.reads:
