@@ -307,6 +307,275 @@ __global__ __launch_bounds__(512, 2) void k_lstm_layer(LstmArgs a) {
     }
 }
 
+
+// ---- unit-split form of the LSTM layer: ONE small batch on the whole chip ----------------------------------------------
+// A single 512-window call is 32 tiles of 16 rows x 2 directions = 64 workgroups of the form above on 256 CUs, and a launch
+// is a chain of 33 dependent steps whose length is the per-step MFMA time of ONE workgroup. Here the 256 hidden units of a
+// (tile, direction) are split over SP_NS = 4 workgroups of 4 waves (one per SIMD); a wave owns 16 units x 4 gates (one
+// 16x16 accumulator per gate), so a step costs a quarter of the MFMA cycles. What the split costs is one exchange per step:
+// every workgroup needs all 256 values of h_t for the recurrent product of step t+1. It is hidden behind the x-part of that
+// step, which does not depend on h_t (two thirds of the decoder's MFMAs), and it needs no flag, fence or store drain:
+//   * h leaves a lane as DATA-TAGGED 8-byte pairs {h(row r), tag}, tag = launch base + step + 1, two pairs per 16-byte
+//     store, written through (sc1) to slot (step parity) of the exchange buffer; an aligned 8-byte pair lands whole;
+//   * after its x-part MFMAs of the next step every thread reads the granules of the same thread of the three partner
+//     workgroups with L1-bypassing (sc1) loads until their tags match (bounded), and writes them to the h tile in LDS.
+//   A workgroup overwrites slot p two steps later; by then it has consumed every partner's granules of the step in between,
+//   which a partner only writes after reading slot p. (PV_SPLIT_FENCES builds the counter + agent-scope release / acquire
+//   form of the same exchange: 1.15 instead of 0.9x ms per 512-window call.)
+// Used only while every workgroup of the launch can be resident at once (grid <= CUs).
+// Weight stream of a wave: [k-block of 8][2][lane][4] = {i j0, i j1, f j0, f j1}, {g j0, g j1, o j0, o j1} with
+// W[gate*H + 64*part + 16*wave + (lane&15)][8kb + 2*(lane>>4) + j], K = [x (padded) | h], through a ring of SP_D register
+// sets requested SP_D-1 k-blocks ahead (a k-block is only 8 MFMAs = 256 cycles and nothing else hides L2 latency with one
+// wave per SIMD); the ring wraps into the next step.
+constexpr int SP_NS = 4;
+constexpr int SP_D = 12;
+constexpr int SP_FLAG_STRIDE = 32;   // ints between two counters: every counter on a 128-byte line of its own (fence form)
+constexpr int SP_SC1 = 16;           // cache policy bit 4 = sc1 on gfx94x / gfx950: write-through stores, L1-bypassing loads
+constexpr int SP_HX_QUADS = 2 * SP_NS * 2 * 256;   // 16-byte granules per (tile, direction): [2 slots][4 parts][2][256 threads]
+
+struct LstmSplitArgs {
+    const int8_t* x_i8;   // [B,33,26]    (encoder)
+    const float* x_f32;   // [Bp,33,512]  (decoder)
+    const float* wp;      // packed [2 dirs][4 parts][4 waves][nkb][2][64][4]
+    const float* bias;    // [2][1024]
+    float* out;           // [Bp,33,512]
+    u32x4* hx;            // [n_tiles*2][SP_HX_QUADS] tagged h granules
+    int* flags;           // [n_tiles*2][4 parts][SP_FLAG_STRIDE] (fence form only)
+    int64_t B;
+    int n_tiles;          // 16-row tiles
+    int flag_base;        // tags of this launch run from flag_base + 1
+};
+
+template <int KB0, int NKB, int NTOT>
+__device__ __forceinline__ void ring_split(f32x4 (&acc)[4], const float* __restrict__ A, int lda, __amdgpu_buffer_rsrc_t wr,
+                                           f32x4 (&bq)[SP_D][2], int lane) {
+    static_assert(NTOT % SP_D == 0, "ring depth must divide the stream length");
+    const float* ap = afrag_ptr<16>(A, lda, lane);
+    const unsigned lane16 = (unsigned)lane * 16u;
+    f32x2 aq[2];
+    aq[0] = *reinterpret_cast<const f32x2*>(ap);
+#pragma unroll
+    for (int i = 0; i < NKB; i++) {
+        {   // request block i + SP_D - 1 (wrapping into the next step's first blocks)
+            const int kbv = (KB0 + i + SP_D - 1) % NTOT;
+            const int slot = (KB0 + i + SP_D - 1) % SP_D;
+            bq[slot][0] = buf_load4(wr, lane16, (unsigned)((kbv * 2 + 0) * 1024));
+            bq[slot][1] = buf_load4(wr, lane16, (unsigned)((kbv * 2 + 1) * 1024));
+        }
+        if (i + 1 < NKB) aq[(i + 1) & 1] = *reinterpret_cast<const f32x2*>(ap + 8 * (i + 1));
+        __builtin_amdgcn_sched_barrier(0);
+        {   // j outer, gate inner: an accumulator is reused only after three other MFMAs
+            const int slot = (KB0 + i) % SP_D;
+            const f32x2 av = aq[i & 1];
+#pragma unroll
+            for (int j = 0; j < 2; j++) {
+                acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j], bq[slot][0][j], acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j], bq[slot][0][2 + j], acc[1], 0, 0, 0);
+                acc[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j], bq[slot][1][j], acc[2], 0, 0, 0);
+                acc[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j], bq[slot][1][2 + j], acc[3], 0, 0, 0);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+template <int KP, bool INT8>
+__global__ __launch_bounds__(256) void k_lstm_split(LstmSplitArgs a) {
+    constexpr int TR = 16, LDX = KP + 4, LDH = H + 4;
+    constexpr int NKB_X = KP / 8, NKB_H = H / 8, NTOT = NKB_X + NKB_H;
+    constexpr int NTHR = 256;
+    extern __shared__ float smem[];
+    float* xbuf = smem;               // [16][LDX]
+    float* hbuf = smem + TR * LDX;    // [2][16][LDH]: all 256 units of h
+    const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // the four parts of a (tile, direction) sit on ONE XCD (they exchange through its L2), one direction per XCD
+    const int xcd = blockIdx.x & 7, q = blockIdx.x >> 3;
+    const int part = q & 3;
+    const int dir = xcd & 1;
+    const int tile = (q >> 2) * 4 + (xcd >> 1);
+    if (tile >= a.n_tiles) return;   // whole groups leave together: `tile` does not depend on `part`
+    const int td = tile * 2 + dir;
+    const int64_t b0 = (int64_t)tile * TR;
+    const float* wp = a.wp + ((size_t)((dir * SP_NS + part) * 4 + wv) * NTOT) * 2 * 256;
+    const float* bias = a.bias + dir * 4 * H;
+    const int unit = 64 * part + 16 * wv + (lane & 15);
+    const int rowg = lane >> 4;       // this lane holds rows 4*rowg .. 4*rowg+3 of its unit
+
+    for (int i = tid; i < 2 * TR * LDH; i += NTHR) hbuf[i] = 0.0f;
+    float cst[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    float bs[4];
+#pragma unroll
+    for (int g = 0; g < 4; g++) bs[g] = bias[g * H + unit];
+    const __amdgpu_buffer_rsrc_t wr = make_rsrc(wp);
+    f32x4 bq[SP_D][2];
+#pragma unroll
+    for (int k = 0; k < SP_D - 1; k++) {
+        bq[k][0] = buf_load4(wr, (unsigned)lane * 16u, (unsigned)((k * 2 + 0) * 1024));
+        bq[k][1] = buf_load4(wr, (unsigned)lane * 16u, (unsigned)((k * 2 + 1) * 1024));
+    }
+
+    // x_t staging through registers (as in k_lstm_layer): every part loads the whole 16-row x tile
+    constexpr int V4 = KP / 4;
+    constexpr int XR = INT8 ? 1 : TR * V4 / NTHR;   // decoder: 8 float4 per thread, rows tid/128 + 2u
+    constexpr int XI = INT8 ? TR * KP / NTHR : 1;   // encoder: 2 bytes per thread, rows tid/32 + 8u
+    f32x4 xr[XR];
+    unsigned xi[XI];
+    int xoff[XI];
+    const __amdgpu_buffer_rsrc_t xsr = make_rsrc(INT8 ? (const void*)a.wp : (const void*)(a.x_f32 + (size_t)b0 * T_STEPS * KP));
+    const __amdgpu_buffer_rsrc_t osr = make_rsrc(a.out + (size_t)b0 * T_STEPS * 2 * H);
+    const unsigned xg_l = (unsigned)(((tid / V4) * T_STEPS * KP + (tid % V4) * 4) * 4);
+    const unsigned xl_l = (unsigned)((tid / V4) * LDX + (tid % V4) * 4);
+    const unsigned xe_l = (unsigned)((tid >> 5) * LDX + (tid & 31));
+    const bool xe_valid = (tid & 31) < F_IN;
+    if constexpr (INT8) {
+        static_assert(KP == 32, "encoder staging assumes 32 padded features");
+#pragma unroll
+        for (int u = 0; u < XI; u++) {
+            int64_t r = (tid >> 5) + 8 * u;
+            if (b0 + r >= a.B) r = a.B - 1 - b0;   // rows beyond B replicate row B-1
+            xoff[u] = (int)(r * T_STEPS * F_IN) + ((tid & 31) < F_IN ? (tid & 31) : F_IN - 1);
+        }
+    }
+    const int8_t* img0 = a.x_i8 + (size_t)b0 * T_STEPS * F_IN;
+    auto x_load = [&](int t) {
+        if constexpr (INT8) {
+            const int8_t* src = img0 + t * F_IN;
+#pragma unroll
+            for (int u = 0; u < XI; u++) xi[u] = (unsigned)(int)src[xoff[u]];
+        } else {
+#pragma unroll
+            for (int u = 0; u < XR; u++) xr[u] = PV_XLOAD(xsr, xg_l, (unsigned)(((u * (NTHR / V4)) * T_STEPS + t) * KP * 4));
+        }
+    };
+    auto x_store = [&]() {
+        if constexpr (INT8) {
+#pragma unroll
+            for (int u = 0; u < XI; u++) (xbuf + u * 8 * LDX)[xe_l] = xe_valid ? (float)(int)xi[u] : 0.0f;
+        } else {
+#pragma unroll
+            for (int u = 0; u < XR; u++) *reinterpret_cast<f32x4*>(xbuf + u * (NTHR / V4) * LDX + xl_l) = xr[u];
+        }
+    };
+    const unsigned h_l = (unsigned)(4 * rowg * LDH + unit);
+    const unsigned og_l = (unsigned)((4 * rowg * T_STEPS * 2 * H + unit) * 4);
+    const __amdgpu_buffer_rsrc_t hsr = make_rsrc(a.hx + (size_t)td * SP_HX_QUADS);
+    // granule (slot, part, g) of thread tid: 16-byte index ((slot * SP_NS + part) * 2 + g) * 256 + tid
+    auto hx_off = [](int slot, int prt, int g) { return (unsigned)((((slot * SP_NS + prt) * 2 + g) * 256) * 16); };
+#ifdef PV_SPLIT_FENCES
+    int* flags_td = a.flags + (size_t)td * SP_NS * SP_FLAG_STRIDE;
+#endif
+    x_load(dir ? T_STEPS - 1 : 0);
+    x_store();
+    __syncthreads();
+
+    for (int s = 0; s < T_STEPS; s++) {
+        const int t = dir ? (T_STEPS - 1 - s) : s;
+        const int cur = s & 1, nxt = cur ^ 1;
+        if (s + 1 < T_STEPS) x_load(dir ? (T_STEPS - 2 - s) : (s + 1));
+        f32x4 acc[4];
+#pragma unroll
+        for (int g = 0; g < 4; g++) acc[g] = f32x4{bs[g], bs[g], bs[g], bs[g]};
+        ring_split<0, NKB_X, NTOT>(acc, xbuf, LDX, wr, bq, lane);          // x-part: independent of h_{t-1}
+        if (s > 0) {
+            // ---- the other three quarters of h_{t-1}: the granules of this thread's twins in the partner workgroups ----
+            const unsigned want = (unsigned)(a.flag_base + s);
+            const int ps = (s - 1) & 1;
+            u32x4 fq[3][2];
+#ifdef PV_SPLIT_FENCES
+            if (tid == 0) {
+#pragma unroll
+                for (int k = 1; k < SP_NS; k++) {
+                    const int* f = flags_td + ((part + k) & 3) * SP_FLAG_STRIDE;
+                    int spins = 0;
+                    while (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (int)want) {
+                        __builtin_amdgcn_s_sleep(1);
+                        if (++spins > (1 << 24)) break;
+                    }
+                }
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            __syncthreads();
+#pragma unroll
+            for (int u = 0; u < 3; u++)
+#pragma unroll
+                for (int g = 0; g < 2; g++)
+                    fq[u][g] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(hsr, (unsigned)tid * 16u, hx_off(ps, (part + 1 + u) & 3, g), 0));
+#else
+            int spins = 0;
+            while (true) {   // bounded: a lost partner ends in wrong results, never in a hung device
+                bool ok = true;
+#pragma unroll
+                for (int u = 0; u < 3; u++)
+#pragma unroll
+                    for (int g = 0; g < 2; g++) {
+                        fq[u][g] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(hsr, (unsigned)tid * 16u, hx_off(ps, (part + 1 + u) & 3, g), SP_SC1));
+                        ok = ok && fq[u][g][1] == want && fq[u][g][3] == want;
+                    }
+                asm volatile("" ::: "memory");   // the loads are repeated, not hoisted
+                if (ok || ++spins > (1 << 18)) break;
+            }
+#endif
+            float* hc = hbuf + cur * TR * LDH;
+#pragma unroll
+            for (int u = 0; u < 3; u++) {
+                const int fp = (part + 1 + u) & 3;
+                float* dst = hc + 4 * ((tid & 63) >> 4) * LDH + 64 * fp + 16 * (tid >> 6) + (tid & 15);
+#pragma unroll
+                for (int g = 0; g < 2; g++) {
+                    // (elements go through scalars: hipcc 7.2 compiles __builtin_bit_cast(float, vec[2]) as element 0)
+                    const unsigned lo = fq[u][g][0], hi = fq[u][g][2];
+                    dst[(2 * g + 0) * LDH] = __builtin_bit_cast(float, lo);
+                    dst[(2 * g + 1) * LDH] = __builtin_bit_cast(float, hi);
+                }
+            }
+        }
+        lds_barrier();   // h tile complete; every wave is past its x-part (x_store below overwrites xbuf)
+        ring_split<NKB_X, NKB_H, NTOT>(acc, hbuf + cur * TR * LDH, LDH, wr, bq, lane);   // h-part (h_0 = 0: zeros at s = 0)
+        // ---- cell update (gate order i,f,g,o) ---------------------------------------------------------------------
+        float* hn = hbuf + nxt * TR * LDH;
+        float hv[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const float ig = sigmoidf_(acc[0][i]);
+            const float fg = sigmoidf_(acc[1][i]);
+            const float gg = tanhf_(acc[2][i]);
+            const float og = sigmoidf_(acc[3][i]);
+            const float c = fg * cst[i] + ig * gg;
+            cst[i] = c;
+            hv[i] = og * tanhf_(c);
+        }
+        if (s + 1 < T_STEPS) {   // the exchange first: it is what the partners wait for
+            const unsigned tag = (unsigned)(a.flag_base + s + 1);
+            // 8-byte stores, one per pair: a 16-byte buffer store with an SGPR soffset has a data hazard on gfx950 that hipcc
+            // (ROCm 7.2) does not pad (see k_gemm_bf16x3), and an inline-asm store would hide an entry of the vmcnt queue from
+            // the compiler's counted waits on the weight ring
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+                const u32x2 pr = {__builtin_bit_cast(unsigned, hv[i]), tag};
+                __builtin_amdgcn_raw_buffer_store_b64(pr, hsr, (unsigned)tid * 16u + 8u * (i & 1), hx_off(cur, part, i >> 1), SP_SC1);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            (hn + i * LDH)[h_l] = hv[i];
+            PV_OSTORE(hv[i], osr, og_l, (unsigned)((t * 2 * H + dir * H + i * T_STEPS * 2 * H) * 4));
+        }
+        if (s + 1 < T_STEPS) x_store();
+#ifdef PV_SPLIT_FENCES
+        __syncthreads();   // stores have left, LDS tiles (x_{t+1}, own slice of h_t) are complete
+        if (s + 1 < T_STEPS && tid == 0) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __hip_atomic_store(flags_td + part * SP_FLAG_STRIDE, a.flag_base + s + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+#else
+        lds_barrier();     // LDS tiles (x_{t+1}, own slice of h_t) are complete; nothing in flight is waited for
+#endif
+    }
+}
+
 struct HeadArgs {
     const float* dec;     // [B,33,512]
     const float* w1p;     // packed linear_1 [4 waves][2112 kb][4][64][4]
@@ -793,6 +1062,29 @@ static void pack_lstm(const pv_rnn_dir* dirs, int K, int KP, int TR, std::vector
     }
 }
 
+// unit-split form (k_lstm_split): [dir][part][wave][k-block][2][lane][4], see the kernel
+static void pack_lstm_split(const pv_rnn_dir* dirs, int K, int KP, std::vector<float>& wp) {
+    const int nkb = (KP + H) / 8;
+    wp.assign((size_t)2 * SP_NS * 4 * nkb * 2 * 256, 0.0f);
+    for (int d = 0; d < 2; d++) {
+        auto wval = [&](int n, int k) -> float {
+            if (k < KP) return k < K ? dirs[d].w_ih[(size_t)n * K + k] : 0.0f;
+            return dirs[d].w_hh[(size_t)n * H + (k - KP)];
+        };
+        for (int p = 0; p < SP_NS; p++)
+            for (int w = 0; w < 4; w++)
+                for (int kb = 0; kb < nkb; kb++)
+                    for (int half = 0; half < 2; half++)
+                        for (int lane = 0; lane < 64; lane++) {
+                            float* dst = &wp[(((((size_t)(d * SP_NS + p) * 4 + w) * nkb + kb) * 2 + half) * 64 + lane) * 4];
+                            const int u = 64 * p + 16 * w + (lane & 15);
+                            for (int gg = 0; gg < 2; gg++)
+                                for (int j = 0; j < 2; j++)
+                                    dst[2 * gg + j] = wval((2 * half + gg) * H + u, kb * 8 + 2 * (lane >> 4) + j);
+                        }
+    }
+}
+
 // Linear [512, K]: wave w owns columns [128w, 128w+128) as four 32-column "gate tiles" nt; tile forms as in pack_lstm
 static void pack_linear(const float* W, int K, int TR, std::vector<float>& wp) {
     const int nkb = K / 8;
@@ -816,6 +1108,8 @@ static void pack_linear(const float* W, int K, int TR, std::vector<float>& wp) {
 }  // namespace
 
 static constexpr int64_t P1_BF16_MAX_BATCH = 16384;
+template <int KP> constexpr size_t lds_lstm_split() { return (size_t)(16 * (KP + 4) + 2 * 16 * (H + 4)) * sizeof(float); }
+static constexpr int SP_MAX_TILES = 64;   // 16-row tiles the exchange buffers are sized for (1024 windows)
 template <int KP, int TR> constexpr size_t lds_lstm() { return (size_t)(TR * (KP + 4) + 2 * TR * (H + 4)) * sizeof(float); }
 static constexpr size_t LDS_REC = (size_t)(2 * ROWS * (H + 4)) * sizeof(float);
 static constexpr size_t LDS_GEMM = (size_t)2 * 4 * 256 * 32 * 2 + 1024;   // 2 buffers x {A_hi, A_lo, W_hi, W_lo} x 256 rows x 32 bf16 = 128 KB, + bias slot
@@ -826,6 +1120,9 @@ struct pv_rnn_p1 {
     float* enc_wp[2] = {nullptr, nullptr};  // [0] 32-row tile form, [1] 16-row tile form (mfma_tiles.hpp)
     float* dec_wp[2] = {nullptr, nullptr};
     float* enc_bias = nullptr; float* dec_bias = nullptr;
+    float* enc_wps = nullptr; float* dec_wps = nullptr;    // unit-split form (k_lstm_split)
+    u32x4* sp_hx = nullptr; int* sp_flags = nullptr;       // its exchange buffer (tagged granules) and counters (fence form)
+    int sp_epoch = 0;
     float* w1p = nullptr; float* b1 = nullptr;
     float* wlp[2][4] = {{nullptr, nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr, nullptr}};  // [tile form][layer]
     float* bl[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -919,6 +1216,20 @@ extern "C" int pv_rnn_load_p1(pv_ctx* ctx, const pv_weights_p1* w, int dtype) {
         if ((rc = dev_upload(wp, &m->dec_wp[f], m->owned))) return rc;
         if (!f && (rc = dev_upload(bias, &m->dec_bias, m->owned))) return rc;
     }
+    pack_lstm_split(w->encoder, F_IN, 32, wp);
+    if ((rc = dev_upload(wp, &m->enc_wps, m->owned))) return rc;
+    pack_lstm_split(w->decoder, 2 * H, 2 * H, wp);
+    if ((rc = dev_upload(wp, &m->dec_wps, m->owned))) return rc;
+    {
+        const size_t hx_bytes = (size_t)SP_MAX_TILES * 2 * SP_HX_QUADS * sizeof(u32x4);
+        const size_t fl_bytes = (size_t)SP_MAX_TILES * 2 * SP_NS * SP_FLAG_STRIDE * sizeof(int);
+        PV_HIP(hipMalloc((void**)&m->sp_hx, hx_bytes));
+        m->owned.push_back(m->sp_hx);
+        PV_HIP(hipMalloc((void**)&m->sp_flags, fl_bytes));
+        m->owned.push_back(m->sp_flags);
+        PV_HIP(hipMemset(m->sp_flags, 0, fl_bytes));
+        PV_HIP(hipMemset(m->sp_hx, 0, hx_bytes));   // tags start at 0: no launch ever waits for tag 0
+    }
     pack_linear(w->linear_w[0], HEAD_K, 32, wp);
     if ((rc = dev_upload(wp, &m->w1p, m->owned)) || (rc = dev_upload(w->linear_b[0], HEAD_N, &m->b1, m->owned))) return rc;
     for (int i = 0; i < 4; i++) {
@@ -946,6 +1257,8 @@ extern "C" int pv_rnn_load_p1(pv_ctx* ctx, const pv_weights_p1* w, int dtype) {
     PV_HIP(hipFuncSetAttribute((const void*)k_lstm_layer<32, true, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_lstm<32, 16>()));
     PV_HIP(hipFuncSetAttribute((const void*)k_lstm_layer<512, false, 32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_lstm<512, 32>()));
     PV_HIP(hipFuncSetAttribute((const void*)k_lstm_layer<512, false, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_lstm<512, 16>()));
+    PV_HIP(hipFuncSetAttribute((const void*)k_lstm_split<32, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_lstm_split<32>()));
+    PV_HIP(hipFuncSetAttribute((const void*)k_lstm_split<512, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_lstm_split<512>()));
     PV_HIP(hipFuncSetAttribute((const void*)k_head_splitk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_SPLITK));
     PV_HIP(hipFuncSetAttribute((const void*)k_head_tail<32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_tail<32>()));
     PV_HIP(hipFuncSetAttribute((const void*)k_head_tail<16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_tail<16>()));
@@ -987,7 +1300,25 @@ static int p1_forward_launch(pv_ctx* ctx, const int8_t* d_images, int64_t B, flo
         e.out_split = enc_split; e.Bp = (int64_t)n_tiles * ROWS;
         if (!taps) e.out = nullptr;
     }
-    {
+    // unit-split form: one small fp32 batch whose (16-row tile, direction, quarter of the hidden units) workgroups all fit
+    // on the chip at once (<= 512 windows on 256 CUs); PV_LSTM_SPLIT=0 keeps the one-workgroup form
+    const int n_t16 = n_tiles * 2;
+    bool split = m->dtype == PV_DTYPE_F32 && n_t16 <= SP_MAX_TILES && (int64_t)n_t16 * 2 * SP_NS <= ctx->num_cu;
+    if (const char* ev = getenv("PV_LSTM_SPLIT")) { if (atoi(ev) == 0) split = false; }
+    if (getenv("PV_LSTM_ROWS")) split = false;   // an explicit tile form was asked for
+    LstmSplitArgs se;
+    const unsigned split_grid = (unsigned)(((n_t16 + 3) / 4) * 8 * SP_NS);
+    if (split) {
+        if (m->sp_epoch > (1 << 23)) {   // tags / counters are monotonic over launches: restart them long before they overflow
+            PV_HIP(hipMemsetAsync(m->sp_flags, 0, (size_t)SP_MAX_TILES * 2 * SP_NS * SP_FLAG_STRIDE * sizeof(int), st));
+            PV_HIP(hipMemsetAsync(m->sp_hx, 0, (size_t)SP_MAX_TILES * 2 * SP_HX_QUADS * sizeof(u32x4), st));
+            m->sp_epoch = 0;
+        }
+        se.x_i8 = d_images; se.x_f32 = nullptr; se.wp = m->enc_wps; se.bias = m->enc_bias; se.out = enc_out;
+        se.hx = m->sp_hx; se.flags = m->sp_flags; se.B = B; se.n_tiles = n_t16; se.flag_base = (m->sp_epoch++) * 64;
+        pv_prof_scope ps(ctx, "k_lstm_split_enc", st);
+        k_lstm_split<32, true><<<split_grid, 256, lds_lstm_split<32>(), st>>>(se);
+    } else {
         pv_prof_scope ps(ctx, "k_lstm_layer_enc", st);
         if (tr == 32) k_lstm_layer<32, true, 32><<<lstm_grid, 512, lds_lstm<32, 32>(), st>>>(e);
         else k_lstm_layer<32, true, 16><<<lstm_grid, 512, lds_lstm<32, 16>(), st>>>(e);
@@ -1036,7 +1367,13 @@ static int p1_forward_launch(pv_ctx* ctx, const int8_t* d_images, int64_t B, flo
     }
     LstmArgs d = e;
     d.x_i8 = nullptr; d.x_f32 = enc_out; d.wp = m->dec_wp[f]; d.bias = m->dec_bias; d.out = dec_out;
-    {
+    if (split) {
+        LstmSplitArgs sd = se;
+        sd.x_i8 = nullptr; sd.x_f32 = enc_out; sd.wp = m->dec_wps; sd.bias = m->dec_bias; sd.out = dec_out;
+        sd.flag_base = (m->sp_epoch++) * 64;
+        pv_prof_scope ps(ctx, "k_lstm_split_dec", st);
+        k_lstm_split<512, false><<<split_grid, 256, lds_lstm_split<512>(), st>>>(sd);
+    } else {
         pv_prof_scope ps(ctx, "k_lstm_layer_dec", st);
         if (tr == 32) k_lstm_layer<512, false, 32><<<lstm_grid, 512, lds_lstm<512, 32>(), st>>>(d);
         else k_lstm_layer<512, false, 16><<<lstm_grid, 512, lds_lstm<512, 16>(), st>>>(d);

@@ -20,10 +20,19 @@ def gold():
     return np.load(GOLD, allow_pickle=False)
 
 
-@pytest.mark.parametrize("rows", ["16", "32"])
+def _lstm_form(monkeypatch, rows):
+    """"16" / "32": the two tile forms of k_lstm_layer (16x16x4 and 32x32x2 MFMA); "split": the library's own choice for a small
+    batch, the unit-split form k_lstm_split (four workgroups per tile and direction, h exchanged every step)"""
+    if rows == "split":
+        monkeypatch.delenv("PV_LSTM_ROWS", raising=False)
+    else:
+        monkeypatch.setenv("PV_LSTM_ROWS", rows)
+
+
+@pytest.mark.parametrize("rows", ["16", "32", "split"])
 @pytest.mark.parametrize("tag", ["p1", "p1sharp"])
 def test_p1_matches_reference_golden(hip_ctx, gold, tag, rows, monkeypatch):
-    monkeypatch.setenv("PV_LSTM_ROWS", rows)  # both tile forms of k_lstm_layer (16x16x4 and 32x32x2 MFMA)
+    _lstm_form(monkeypatch, rows)
     w = synth.make_weights_p1(int(gold[tag + "/seed"][0]), float(gold[tag + "/gain"][0]))
     hip_ctx.load_p1(w)
     probs, enc, dec = hip_ctx.forward_p1(gold[tag + "/images"], taps=True)
@@ -32,11 +41,11 @@ def test_p1_matches_reference_golden(hip_ctx, gold, tag, rows, monkeypatch):
     np.testing.assert_allclose(probs, gold[tag + "/probs"], atol=TOL_PROBS, rtol=0)
 
 
-@pytest.mark.parametrize("rows", ["16", "32"])
+@pytest.mark.parametrize("rows", ["16", "32", "split"])
 @pytest.mark.parametrize("B", [1, 15, 16, 17, 31, 32, 33, 100, 512])
 def test_p1_ragged_batches_vs_oracle(hip_ctx, B, rows, monkeypatch):
-    """batch sizes around the 16- and 32-row tile edges, both tile forms; the oracle runs in float64"""
-    monkeypatch.setenv("PV_LSTM_ROWS", rows)
+    """batch sizes around the 16- and 32-row tile edges, all three kernel forms; the oracle runs in float64"""
+    _lstm_form(monkeypatch, rows)
     w = synth.make_weights_p1(99, 2.5)
     hip_ctx.load_p1(w)
     x = synth.synth_windows(1000 + B, B)
@@ -48,6 +57,59 @@ def test_p1_ragged_batches_vs_oracle(hip_ctx, B, rows, monkeypatch):
     if B > 64:  # rows are independent: the tail of a big batch equals the same windows run alone
         alone = hip_ctx.forward_p1(x[-40:])
         np.testing.assert_allclose(probs[-40:], alone, atol=1e-6, rtol=0)
+
+
+@pytest.mark.parametrize("B", [1, 17, 100, 512])
+def test_p1_unit_split_form_equals_one_workgroup_form(hip_ctx, B, monkeypatch):
+    """a small batch runs with the hidden units of every (tile, direction) split over four workgroups that exchange h once per
+    step (agent-scope counters). Same MFMA shape, same K order per accumulator as the 16-row one-workgroup form: the layer
+    outputs and the probabilities are BIT-identical to it, and run to run"""
+    w = synth.make_weights_p1(31, 2.0)
+    hip_ctx.load_p1(w)
+    x = synth.synth_windows(3100 + B, B)
+    monkeypatch.delenv("PV_LSTM_ROWS", raising=False)
+    runs = [hip_ctx.forward_p1(x, taps=True) for _ in range(3)]
+    monkeypatch.setenv("PV_LSTM_ROWS", "16")
+    p0, e0, d0 = hip_ctx.forward_p1(x, taps=True)
+    for p1, e1, d1 in runs:
+        assert np.array_equal(e1.view(np.uint32), e0.view(np.uint32))
+        assert np.array_equal(d1.view(np.uint32), d0.view(np.uint32))
+        assert np.array_equal(p1.view(np.uint32), p0.view(np.uint32))
+
+
+def test_p1_unit_split_exchange_under_uneven_load(hip_ctx):
+    """the per-step h exchange of the unit-split form (data-tagged 8-byte pairs, write-through stores, L1-bypassing polls)
+    with the chip shared unevenly: a second context keeps big one-workgroup-form launches in flight on its own stream while
+    512-window calls run in the split form; every call must reproduce the quiet result bit for bit"""
+    import torch
+    from pepper_thesis_amd import runtime
+    w = synth.make_weights_p1(33, 2.0)
+    hip_ctx.load_p1(w)
+    other = runtime.Context(hip_ctx.device_id)
+    other.load_p1(w)
+    dev = "cuda:%d" % hip_ctx.device_id
+    xs = [torch.from_numpy(synth.synth_windows(3300 + i, 512)).to(dev) for i in range(3)]
+    big = torch.from_numpy(synth.synth_windows(3400, 6000)).to(dev)
+    pbig = torch.zeros((6000, 3), dtype=torch.float32, device=dev)
+    quiet = []
+    for x in xs:
+        p = torch.zeros((512, 3), dtype=torch.float32, device=dev)
+        hip_ctx.forward_p1_dev(x.data_ptr(), 512, p.data_ptr())
+        hip_ctx.synchronize()
+        quiet.append(p.cpu().numpy().copy())
+    ref = rnn_oracle.p1_forward(w, xs[0][:8].cpu().numpy(), np.float64)
+    np.testing.assert_allclose(quiet[0][:8], ref, atol=TOL_PROBS, rtol=0)
+    outs = [torch.zeros((512, 3), dtype=torch.float32, device=dev) for _ in range(24)]
+    for k, o in enumerate(outs):
+        if k % 2 == 0:
+            other.forward_p1_dev(big.data_ptr(), 6000 - 37 * k, pbig.data_ptr())   # asynchronous, overlaps the calls below
+        hip_ctx.forward_p1_dev(xs[k % 3].data_ptr(), 512, o.data_ptr())
+    hip_ctx.synchronize()
+    other.synchronize()
+    for k, o in enumerate(outs):
+        got = o.cpu().numpy()
+        assert np.array_equal(got.view(np.uint32), quiet[k % 3].view(np.uint32)), "call %d" % k
+    other.close()
 
 
 def test_p1_extreme_inputs(hip_ctx):
