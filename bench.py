@@ -278,7 +278,14 @@ def single_call_secondary(ctx, dev, weights):
     # (RunInferenceArguments.py:67-74, default 4). Here: N contexts = N HIP streams, each looping over its own 512-window
     # batches with no fusion across callers; the (tile, direction) workgroups of the callers share the CUs.
     from pepper_thesis_amd import runtime
-    for ncall in (4, 8):
+    # (a 512-window call alone runs in the unit-split LSTM form, which takes the whole chip for one call; callers that share
+    # the GPU without fusion do better in the one-workgroup form, PV_LSTM_SPLIT=0: both are reported)
+    for ncall, form in ((4, "default"), (8, "default"), (4, "one_workgroup_form"), (8, "one_workgroup_form")):
+        key = "callers%d_x_B512" % ncall + ("" if form == "default" else "_" + form)
+        if form == "default":
+            os.environ.pop("PV_LSTM_SPLIT", None)
+        else:
+            os.environ["PV_LSTM_SPLIT"] = "0"
         try:
             ctxs = [ctx] + [runtime.Context(ctx.device_id) for _ in range(ncall - 1)]
             for c in ctxs[1:]:
@@ -298,13 +305,14 @@ def single_call_secondary(ctx, dev, weights):
                 c.synchronize()
             dt = time.perf_counter() - t0
             wps = reps * ncall * 512 / dt
-            out["callers%d_x_B512" % ncall] = {"windows_per_s": wps, "ms_per_round": dt / reps * 1e3, "tflops": FLOP_PER_WINDOW * wps / 1e12,
+            out[key] = {"windows_per_s": wps, "ms_per_round": dt / reps * 1e3, "tflops": FLOP_PER_WINDOW * wps / 1e12,
                                                "frac_of_f32_peak": FLOP_PER_WINDOW * wps / 1e12 / PEAK_F32_TFLOPS,
                                                "note": "%d independent callers (contexts / streams), 512 windows per call each, no fusion" % ncall}
             for c in ctxs[1:]:
                 c.close()
         except Exception as e:
-            out["callers%d_x_B512" % ncall] = {"error": repr(e)}
+            out[key] = {"error": repr(e)}
+    os.environ.pop("PV_LSTM_SPLIT", None)
     return out
 
 
