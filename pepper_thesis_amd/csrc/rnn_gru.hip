@@ -135,6 +135,10 @@ struct GruArgs {
     float* hidden_out;      // [B,2,128] or NULL
     float* logits;          // [B,100,5] raw dense1 output of the LAST window, or NULL
     int* pair_flags;        // split form only: [n_tiles][2] hand-off counters of the two direction workgroups of a tile (zeroed per launch)
+    // unit-split form only (k_gru_us):
+    u32x4* hx;              // [n_tiles][2 dirs][US_HX_QUADS] data-tagged h pairs
+    int* quad_flags;        // [n_tiles][4][US_FLAG_STRIDE] layer-boundary counters of the four workgroups of a tile (zeroed per launch)
+    unsigned tag_base;      // tags of this launch run from tag_base + 1
 };
 
 // ---- the two directions of a tile on two CUs (small batches) -----------------------------------------------------------
@@ -578,6 +582,351 @@ __global__ __launch_bounds__(SPLIT ? 256 : 512, SPLIT ? 1 : 2) void k_gru_p2(Gru
     }
 }
 
+
+// ---- unit-split form: the 128 hidden units of a (tile, direction) on TWO workgroups (small batches) ----------------------
+// Same idea as k_lstm_split (rnn_kernels.hip): the launch is a chain of 3800 dependent steps, so what counts is the MFMA time
+// of ONE workgroup per step. Workgroup = (16-row tile, direction, half of the units), 4 waves, one per SIMD; a wave owns 16
+// units x {r, z, n} (three 16x16 accumulators for the x-part, three for the h-part). Every step the two halves swap their
+// 64 new h values per row: data-tagged 8-byte pairs {h, tag} written through (sc1) into the slot (step parity) of a per-(tile,
+// direction) buffer, polled by the twin thread of the partner with L1-bypassing loads AFTER that thread's x-part MFMAs of the
+// next step (two thirds of the decoder's MFMAs do not depend on h): no flag, no fence, no store drain. The four workgroups of
+// a tile meet only where the model joins directions (decoder input, dense1): counters + agent-scope release / acquire, 38
+// times per launch. Weight stream of a wave: [pair of k-blocks][gate][lane][4] = {kb even j0, j1, kb odd j0, j1} with
+// W[gate*HG + 64*half + 16*wave + (lane&15)][16p + 8*(kb&1) + 2*(lane>>4) + j], stream order [h | x], through a ring of D
+// register sets requested D-1 pairs ahead (a pair is 12 MFMAs = 384 cycles).
+constexpr int US_HX_QUADS = 2 * 2 * 2 * 256;   // 16-byte granules per (tile, direction): [2 slots][2 halves][2][256 threads]
+constexpr int US_FLAG_STRIDE = 32;
+constexpr int US_SC1 = 16;                     // cache policy bit 4 = sc1 (gfx94x / gfx950)
+
+template <int P0, int NP, int NTOTP, int D>
+__device__ __forceinline__ void ring_us(f32x4& gr, f32x4& gz, f32x4& gn, const float* __restrict__ A, int lda,
+                                        __amdgpu_buffer_rsrc_t wr, f32x4 (&bq)[D][3], int lane) {
+    static_assert(NTOTP % D == 0, "ring depth must divide the stream length");
+    const float* ap = afrag_ptr<16>(A, lda, lane);
+    const unsigned lane16 = (unsigned)lane * 16u;
+    f32x2 aq[2][2];
+    aq[0][0] = *reinterpret_cast<const f32x2*>(ap);
+    aq[0][1] = *reinterpret_cast<const f32x2*>(ap + 8);
+#pragma unroll
+    for (int i = 0; i < NP; i++) {
+        {
+            const int pv = (P0 + i + D - 1) % NTOTP, slot = (P0 + i + D - 1) % D;
+#pragma unroll
+            for (int g = 0; g < 3; g++) bq[slot][g] = buf_load4(wr, lane16, (unsigned)((pv * 3 + g) * 1024));
+        }
+        if (i + 1 < NP) {
+            aq[(i + 1) & 1][0] = *reinterpret_cast<const f32x2*>(ap + 16 * (i + 1));
+            aq[(i + 1) & 1][1] = *reinterpret_cast<const f32x2*>(ap + 16 * (i + 1) + 8);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        {
+            const int slot = (P0 + i) % D;
+#pragma unroll
+            for (int kh = 0; kh < 2; kh++)
+#pragma unroll
+                for (int j = 0; j < 2; j++) {
+                    const float av = aq[i & 1][kh][j];
+                    gr = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bq[slot][0][2 * kh + j], gr, 0, 0, 0);
+                    gz = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bq[slot][1][2 * kh + j], gz, 0, 0, 0);
+                    gn = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bq[slot][2][2 * kh + j], gn, 0, 0, 0);
+                }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+// counters + fences among the four workgroups of a tile (layer boundaries only)
+__device__ __forceinline__ void quad_handoff(int* flags_tile, int me, int value, int tid) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __hip_atomic_store(flags_tile + me * US_FLAG_STRIDE, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+        for (int k = 1; k < 4; k++) {
+            const int* f = flags_tile + ((me + k) & 3) * US_FLAG_STRIDE;
+            int spins = 0;
+            while (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < value) {
+                __builtin_amdgcn_s_sleep(2);
+                if (++spins > (1 << 24)) break;   // bounded: a lost partner ends in wrong results, never in a hung device
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __syncthreads();
+}
+
+// one GRU layer over one 100-column window for this workgroup's (direction, half). `step` counts the steps of the launch (tags).
+template <int KP, bool ENC, int D>
+__device__ __forceinline__ void gru_window_us(const GruArgs& a, int win_start, int dir, int half, int wv, int lane, int tid,
+                                              int64_t b0, float* xbuf, float* hbuf, int& cur, float (&hst)[4], unsigned& step,
+                                              const float* wp, const float* bias, const float* x_src, float* out_dst,
+                                              __amdgpu_buffer_rsrc_t hsr) {
+    constexpr int TR = 16;
+    constexpr int LDX = KP + 4;
+    constexpr int NP_X = KP / 16, NP_H = HG / 16, NTOTP = NP_X + NP_H;
+    static_assert(NTOTP % D == 0, "ring depth");
+    const int unit = 64 * half + 16 * wv + (lane & 15);
+    const int rowg = lane >> 4;
+    const float b_r = bias[0 * HG + unit], b_z = bias[1 * HG + unit], b_in = bias[2 * HG + unit], b_hn = bias[3 * HG + unit];
+    constexpr int XR = ENC ? 1 : 4;     // decoder: float4 per thread, rows tid/64 + 4u
+    constexpr int XE = 2;               // encoder: bytes per thread, rows tid/32 + 8u
+    f32x4 xr[XR];
+    unsigned xe[ENC ? XE : 1];
+    unsigned xoff[ENC ? XE : 1];
+    const unsigned xd_g = (unsigned)((tid >> 6) * KPD + (tid & 63) * 4);
+    const unsigned xd_l = (unsigned)((tid >> 6) * LDX + (tid & 63) * 4);
+    const unsigned xe_l = (unsigned)((tid >> 5) * LDX + (tid & 31));
+    const bool xe_valid = (tid & 31) < FEAT;
+    if constexpr (ENC) {
+#pragma unroll
+        for (int u = 0; u < XE; u++) {
+            int64_t r = (tid >> 5) + 8 * u;
+            if (b0 + r >= a.B) r = a.B - 1 - b0;
+            xoff[u] = (unsigned)(r * a.seq * FEAT) + (unsigned)((tid & 31) < FEAT ? (tid & 31) : FEAT - 1);
+        }
+    }
+    const uint8_t* img0 = a.images + ((size_t)b0 * a.seq + win_start) * FEAT;
+    const __amdgpu_buffer_rsrc_t wr = make_rsrc(wp), xsr = make_rsrc(ENC ? (const void*)wp : (const void*)x_src), osr = make_rsrc(out_dst);
+    auto x_load = [&](int s) {
+        const int t = dir ? (WIN - 1 - s) : s;
+        if constexpr (ENC) {
+            const uint8_t* src = img0 + t * FEAT;
+#pragma unroll
+            for (int u = 0; u < XE; u++) xe[u] = src[xoff[u]];
+        } else {
+#pragma unroll
+            for (int u = 0; u < XR; u++) xr[u] = buf_load4(xsr, xd_g * 4u, (unsigned)((t * TR + u * 4) * KPD * 4));
+        }
+    };
+    auto x_store = [&](int slot) {
+        float* xb = xbuf + slot * TR * LDXD;
+        if constexpr (ENC) {
+#pragma unroll
+            for (int u = 0; u < XE; u++) (xb + u * 8 * LDX)[xe_l] = xe_valid ? (float)xe[u] : 0.0f;
+        } else {
+#pragma unroll
+            for (int u = 0; u < XR; u++) *reinterpret_cast<f32x4*>(xb + u * 4 * LDX + xd_l) = xr[u];
+        }
+    };
+    f32x4 bq[D][3];   // the stream order is [h | x]; the prologue runs the x-part of step 0, so the ring starts at pair NP_H
+#pragma unroll
+    for (int q = 0; q < D - 1; q++)
+#pragma unroll
+        for (int g = 0; g < 3; g++)
+            bq[(NP_H + q) % D][g] = buf_load4(wr, (unsigned)lane * 16u, (unsigned)((((NP_H + q) % NTOTP) * 3 + g) * 1024));
+    const unsigned h_l = (unsigned)(4 * rowg * LDH + unit);
+    const unsigned o_l = (unsigned)(4 * rowg * KPD + unit);
+    auto hx_off = [](int slot, int hf, int g) { return (unsigned)((((slot * 2 + hf) * 2 + g) * 256) * 16); };
+    x_load(0);
+    x_store(0);
+    x_load(1);
+    x_store(1);
+    __syncthreads();
+    f32x4 xr_ = {b_r, b_r, b_r, b_r}, xz_ = {b_z, b_z, b_z, b_z}, xn_ = {b_in, b_in, b_in, b_in};   // x-part (+ biases) of the CURRENT step
+    ring_us<NP_H, NP_X, NTOTP, D>(xr_, xz_, xn_, xbuf, LDX, wr, bq, lane);
+    for (int s = 0; s < WIN; s++) {
+        const int t = dir ? (WIN - 1 - s) : s;
+        const int nxt = cur ^ 1;
+        if (s + 2 < WIN) x_load(s + 2);
+        if (step > 0) {
+            // ---- the other half of h (previous step of the launch): the pairs of this thread's twin in the partner workgroup ----
+            const unsigned want = a.tag_base + step;
+            const int ps = (int)((step - 1) & 1);
+            u32x4 fq[2];
+            int spins = 0;
+            while (true) {   // bounded: a lost partner ends in wrong results, never in a hung device
+                bool ok = true;
+#pragma unroll
+                for (int g = 0; g < 2; g++) {
+                    fq[g] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(hsr, (unsigned)tid * 16u, hx_off(ps, half ^ 1, g), US_SC1));
+                    ok = ok && fq[g][1] == want && fq[g][3] == want;
+                }
+                asm volatile("" ::: "memory");   // the loads are repeated, not hoisted
+                if (ok || ++spins > (1 << 18)) break;
+            }
+            float* dst = hbuf + cur * TR * LDH + 4 * rowg * LDH + 64 * (half ^ 1) + 16 * wv + (lane & 15);
+#pragma unroll
+            for (int g = 0; g < 2; g++) {
+                // (elements go through scalars: hipcc 7.2 compiles __builtin_bit_cast(float, vec[2]) as element 0)
+                const unsigned lo = fq[g][0], hi = fq[g][2];
+                dst[(2 * g + 0) * LDH] = __builtin_bit_cast(float, lo);
+                dst[(2 * g + 1) * LDH] = __builtin_bit_cast(float, hi);
+            }
+            lds_barrier();
+        }
+        f32x4 hr = {0.0f, 0.0f, 0.0f, 0.0f}, hz = {0.0f, 0.0f, 0.0f, 0.0f}, hn_ = {b_hn, b_hn, b_hn, b_hn};
+        ring_us<0, NP_H, NTOTP, D>(hr, hz, hn_, hbuf + cur * TR * LDH, LDH, wr, bq, lane);
+        // ---- cell update; the new h leaves first (the partner waits for it) -------------------------------------------
+        float* hnx = hbuf + nxt * TR * LDH;
+        float hv[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const float r = sigmoidf_(xr_[i] + hr[i]);
+            const float z = sigmoidf_(xz_[i] + hz[i]);
+            const float n = tanhf_(xn_[i] + r * hn_[i]);
+            hv[i] = (1.0f - z) * n + z * hst[i];
+            hst[i] = hv[i];
+        }
+        {
+            const unsigned tag = a.tag_base + step + 1;
+            const int slot = (int)(step & 1);
+#pragma unroll
+            for (int i = 0; i < 4; i++) {   // 8-byte stores (a 16-byte buffer store with an SGPR soffset has an unpadded data hazard on gfx950)
+                typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+                const u32x2 pr = {__builtin_bit_cast(unsigned, hv[i]), tag};
+                __builtin_amdgcn_raw_buffer_store_b64(pr, hsr, (unsigned)tid * 16u + 8u * (i & 1), hx_off(slot, half, i >> 1), US_SC1);
+            }
+        }
+        const unsigned ob = (unsigned)((t * TR * KPD + dir * HG) * 4);
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            (hnx + i * LDH)[h_l] = hv[i];
+            buf_store1(hv[i], osr, o_l * 4u, ob + (unsigned)(i * KPD * 4));
+        }
+        step++;
+        if (s + 1 < WIN) {   // x-part of the NEXT step: the exchange above travels meanwhile
+            f32x4 nr = {b_r, b_r, b_r, b_r}, nz = {b_z, b_z, b_z, b_z}, nn = {b_in, b_in, b_in, b_in};
+            ring_us<NP_H, NP_X, NTOTP, D>(nr, nz, nn, xbuf + ((s + 1) & 1) * TR * LDXD, LDX, wr, bq, lane);
+            xr_ = nr; xz_ = nz; xn_ = nn;
+        }
+        if (s + 2 < WIN) x_store(s & 1);   // x_{s+2} into the slot x_s left: its last reader was the x-part issued in step s-1
+        cur = nxt;
+        lds_barrier();
+    }
+    __syncthreads();   // the window's outputs (global scratch) are read by the next phase (after the hand-off)
+}
+
+__global__ __launch_bounds__(256, 1) void k_gru_us(GruArgs a) {
+    extern __shared__ float smem[];
+    constexpr int TR = 16;
+    float* hbuf = smem;                    // [2][16][LDH]: all 128 units
+    float* xbuf = hbuf + 2 * TR * LDH;     // [2][16][LDXD]
+    const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // the four workgroups of a tile sit on ONE XCD (they exchange through its L2)
+    const int xcd = blockIdx.x & 7, q = blockIdx.x >> 3;
+    const int sub = q & 3, dir = sub & 1, half = sub >> 1;
+    const int tile = (q >> 2) * 8 + xcd;
+    const int n_tiles = (int)((a.B + TR - 1) / TR);
+    if (tile >= n_tiles) return;           // whole tiles leave together
+    const int64_t b0 = (int64_t)tile * TR;
+    float* enc_out = a.enc_out + (size_t)tile * WIN * TR * KPD;
+    float* dec_out = a.dec_out + (size_t)tile * WIN * TR * KPD;
+    constexpr int NPE = (KPE + HG) / 16, NPD = (KPD + HG) / 16;
+    const float* enc_wp = a.enc_wp + ((size_t)((dir * 2 + half) * 4 + wv) * NPE) * 3 * 256;
+    const float* dec_wp = a.dec_wp + ((size_t)((dir * 2 + half) * 4 + wv) * NPD) * 3 * 256;
+    const float* enc_bias = a.enc_bias + dir * 4 * HG;
+    const float* dec_bias = a.dec_bias + dir * 4 * HG;
+    const __amdgpu_buffer_rsrc_t hsr = make_rsrc(a.hx + ((size_t)tile * 2 + dir) * US_HX_QUADS);
+    int* flags_tile = a.quad_flags + (size_t)tile * 4 * US_FLAG_STRIDE;
+    int handoffs = 0;
+    unsigned step = 0;
+
+    for (int i = tid; i < 2 * TR * LDH; i += 256) hbuf[i] = 0.0f;  // hidden = zeros (predict.py:55)
+    float hst[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    int cur = 0;
+    __syncthreads();
+    const int unit = 64 * half + 16 * wv + (lane & 15);
+    if (a.hidden_in) {  // TransducerGRU.forward(x, hidden): every workgroup needs all 128 units of its direction
+        for (int p = tid; p < TR * HG; p += 256) {
+            const int row = p / HG, u = p - row * HG;
+            int64_t b = b0 + row;
+            if (b >= a.B) b = a.B - 1;
+            hbuf[row * LDH + u] = a.hidden_in[(b * 2 + dir) * HG + u];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 4; i++) hst[i] = hbuf[(4 * (lane >> 4) + i) * LDH + unit];
+    }
+
+    for (int w = 0; w < a.nwin; w++) {
+        const int ws = w * JUMP;
+        gru_window_us<KPE, true, NPE>(a, ws, dir, half, wv, lane, tid, b0, xbuf, hbuf, cur, hst, step, enc_wp, enc_bias, nullptr, enc_out, hsr);
+        quad_handoff(flags_tile, sub, ++handoffs, tid);   // all four quarters of the encoder output are there
+        gru_window_us<KPD, false, 8>(a, ws, dir, half, wv, lane, tid, b0, xbuf, hbuf, cur, hst, step, dec_wp, dec_bias, enc_out, dec_out, hsr);
+        quad_handoff(flags_tile, sub, ++handoffs, tid);   // the decoder output; everybody is done reading the encoder output too
+        // dense1 + softmax + accumulate (predict.py:70-89): workgroup `sub` owns the columns with (position & 3) == sub, for
+        // acc, logits and labels alike (windows overlap, positions do not move), so no column is shared
+        for (int p = tid; p < TR * WIN; p += 256) {
+            const int t = p / TR, row = p - t * TR;
+            const int64_t b = b0 + row;
+            if (b >= a.B || ((ws + t) & 3) != sub) continue;
+            const float* d = dec_out + ((size_t)t * TR + row) * KPD;
+            float lg[NCLS];
+#pragma unroll
+            for (int c = 0; c < NCLS; c++) lg[c] = a.dense_b[c];
+            for (int k = 0; k < KPD; k += 4) {
+                const f32x4 v = *reinterpret_cast<const f32x4*>(d + k);
+#pragma unroll
+                for (int c = 0; c < NCLS; c++) {
+                    const f32x4 wv4 = *reinterpret_cast<const f32x4*>(a.dense_w + c * KPD + k);
+                    lg[c] += v[0] * wv4[0] + v[1] * wv4[1] + v[2] * wv4[2] + v[3] * wv4[3];
+                }
+            }
+            float m = lg[0];
+#pragma unroll
+            for (int c = 1; c < NCLS; c++) m = fmaxf(m, lg[c]);
+            float e[NCLS], sum = 0.0f;
+#pragma unroll
+            for (int c = 0; c < NCLS; c++) { e[c] = expf(lg[c] - m); sum += e[c]; }
+            const float inv = 1.0f / sum;
+            float* ac = a.acc + ((size_t)b * a.seq + ws + t) * NCLS;
+#pragma unroll
+            for (int c = 0; c < NCLS; c++) ac[c] += e[c] * inv;
+            if (a.logits && w == a.nwin - 1) {
+#pragma unroll
+                for (int c = 0; c < NCLS; c++) a.logits[((size_t)b * WIN + t) * NCLS + c] = lg[c];
+            }
+        }
+        __syncthreads();
+    }
+    if (a.hidden_out) {
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const int64_t b = b0 + 4 * (lane >> 4) + i;
+            if (b < a.B) a.hidden_out[(b * 2 + dir) * HG + unit] = hst[i];
+        }
+    }
+    for (int p = tid; a.labels && p < TR * a.seq; p += 256) {
+        const int row = p / a.seq, pos = p - row * a.seq;
+        const int64_t b = b0 + row;
+        if (b >= a.B || (pos & 3) != sub) continue;
+        const float* ac = a.acc + ((size_t)b * a.seq + pos) * NCLS;
+        int best = 0;
+        float bv = ac[0];
+#pragma unroll
+        for (int c = 1; c < NCLS; c++) if (ac[c] > bv) { bv = ac[c]; best = c; }
+        a.labels[(size_t)b * a.seq + pos] = (uint8_t)best;
+    }
+}
+
+// unit-split form: [dir][half][wave][pair of k-blocks][gate r,z,n][lane][4], stream order [h | x] (see k_gru_us)
+void pack_gru_us(const pv_rnn_dir* dirs, int K, int KP, std::vector<float>& wp) {
+    const int np_h = HG / 16, np = (KP + HG) / 16;
+    wp.assign((size_t)2 * 2 * 4 * np * 3 * 256, 0.0f);
+    for (int d = 0; d < 2; d++) {
+        auto wval = [&](int n, int kpos) -> float {   // kpos: position in the [h | x] stream
+            if (kpos < HG) return dirs[d].w_hh[(size_t)n * HG + kpos];
+            const int k = kpos - HG;
+            return k < K ? dirs[d].w_ih[(size_t)n * K + k] : 0.0f;
+        };
+        (void)np_h;
+        for (int hf = 0; hf < 2; hf++)
+            for (int w = 0; w < 4; w++)
+                for (int pp = 0; pp < np; pp++)
+                    for (int g = 0; g < 3; g++)
+                        for (int lane = 0; lane < 64; lane++) {
+                            float* dst = &wp[(((((size_t)(d * 2 + hf) * 4 + w) * np + pp) * 3 + g) * 64 + lane) * 4];
+                            const int n = g * HG + 64 * hf + 16 * w + (lane & 15);
+                            for (int kh = 0; kh < 2; kh++)
+                                for (int j = 0; j < 2; j++) dst[2 * kh + j] = wval(n, 16 * pp + 8 * kh + 2 * (lane >> 4) + j);
+                        }
+    }
+}
+constexpr size_t LDS_US = (size_t)(2 * 16 * LDH + 2 * 16 * LDXD) * sizeof(float);
+
 // Packed weight stream of one wave: [k-block of 8][gate r,z,n][lane][4]; K = [x (padded to KP) | h].
 //  32-row form: lane -> gate column 32w + (lane&31), the four values are k = 8kb + 4*(lane>>5) + j, j = 0..3
 //  16-row form: lane -> gate columns 32w + (lane&15) (tile 0) and 32w + 16 + (lane&15) (tile 1),
@@ -621,8 +970,10 @@ template <int TR, bool SPLIT> constexpr size_t lds_p2() { return (size_t)(SPLIT 
 }  // namespace
 
 struct pv_rnn_p2 {
-    float* enc_wp[3] = {nullptr, nullptr, nullptr};  // [0] 32-row tile form, [1] 16-row tile form, [2] 16-row form in [h | x] order (split form)
-    float* dec_wp[3] = {nullptr, nullptr, nullptr};
+    float* enc_wp[4] = {nullptr, nullptr, nullptr, nullptr};  // [0] 32-row tile form, [1] 16-row tile form, [2] 16-row form in [h | x] order (split form), [3] unit-split form
+    float* dec_wp[4] = {nullptr, nullptr, nullptr, nullptr};
+    unsigned us_epoch = 0;
+    const void* us_hx_seen = nullptr; size_t us_hx_n = 0;   // the exchange buffer whose tags belong to this epoch sequence
     float* enc_bias = nullptr; float* dec_bias = nullptr;
     float* dense_w = nullptr; float* dense_b = nullptr;
     std::vector<void*> owned;
@@ -668,6 +1019,11 @@ extern "C" int pv_rnn_load_p2(pv_ctx* ctx, const pv_weights_p2* w, int dtype) {
         if ((rc = up2(wp.data(), wp.size(), &m->dec_wp[f], m->owned))) return rc;
         if (!f && (rc = up2(bias.data(), bias.size(), &m->dec_bias, m->owned))) return rc;
     }
+    pack_gru_us(w->encoder, FEAT, KPE, wp);
+    if ((rc = up2(wp.data(), wp.size(), &m->enc_wp[3], m->owned))) return rc;
+    pack_gru_us(w->decoder, KPD, KPD, wp);
+    if ((rc = up2(wp.data(), wp.size(), &m->dec_wp[3], m->owned))) return rc;
+    PV_HIP(hipFuncSetAttribute((const void*)k_gru_us, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_US));
     if ((rc = up2(w->dense_w, (size_t)NCLS * KPD, &m->dense_w, m->owned)) || (rc = up2(w->dense_b, NCLS, &m->dense_b, m->owned))) return rc;
     PV_HIP(hipFuncSetAttribute((const void*)k_gru_p2<32, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_p2<32, false>()));
     PV_HIP(hipFuncSetAttribute((const void*)k_gru_p2<16, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_p2<16, false>()));
@@ -703,6 +1059,32 @@ static int p2_launch(pv_ctx* ctx, const uint8_t* d_images, int64_t B, uint8_t* d
     bool split = tr == 16 && 2 * n_tiles <= ctx->num_cu;
     if (const char* e = getenv("PV_GRU_SPLIT")) split = split && atoi(e) != 0;
     g.pair_flags = nullptr;
+    g.hx = nullptr; g.quad_flags = nullptr; g.tag_base = 0;
+    // unit-split form: (tile, direction, half of the units) workgroups with a per-step h exchange, while all of them can be
+    // resident at once (up to 1024 chunks on 256 CUs); PV_GRU_USPLIT=0 keeps the direction-split form
+    bool usplit = tr == 16 && 4 * n_tiles <= ctx->num_cu;
+    if (const char* e = getenv("PV_GRU_USPLIT")) usplit = usplit && atoi(e) != 0;
+    if (const char* e = getenv("PV_GRU_SPLIT")) usplit = usplit && atoi(e) != 0;
+    if (usplit) {
+        g.enc_wp = m->enc_wp[3]; g.dec_wp = m->dec_wp[3];
+        const size_t nfl = (size_t)n_tiles * 4 * US_FLAG_STRIDE;
+        if ((rc = pv_get(ctx, "p2.quad_flags", nfl, &g.quad_flags))) return rc;
+        PV_HIP(hipMemsetAsync(g.quad_flags, 0, nfl * sizeof(int), st));
+        const size_t nhx = (size_t)n_tiles * 2 * US_HX_QUADS;
+        if ((rc = pv_get(ctx, "p2.hx", nhx, &g.hx))) return rc;
+        // tags are monotonic over launches (4096 per launch): a buffer this sequence has not written yet is cleared, and the
+        // sequence restarts long before it wraps
+        if (m->us_epoch == 0 || m->us_epoch > (1u << 19) || m->us_hx_seen != (const void*)g.hx || m->us_hx_n != nhx) {
+            m->us_hx_seen = g.hx; m->us_hx_n = nhx;
+            PV_HIP(hipMemsetAsync(g.hx, 0, nhx * sizeof(u32x4), st));
+            m->us_epoch = 0;
+        }
+        g.tag_base = (++m->us_epoch) * 4096u;
+        pv_prof_scope ps(ctx, "k_gru_us", st);
+        k_gru_us<<<(unsigned)(((n_tiles + 7) / 8) * 32), 256, LDS_US, st>>>(g);
+        PV_HIP(hipGetLastError());
+        return PV_OK;
+    }
     if (split) {
         g.enc_wp = m->enc_wp[2]; g.dec_wp = m->dec_wp[2];   // [h | x] stream order of the overlapped window form
         if ((rc = pv_get(ctx, "p2.pair_flags", (size_t)2 * n_tiles + 96, &g.pair_flags))) return rc;

@@ -318,26 +318,62 @@ def test_p1_bf16_mode_chunks_large_batches():
     ctx.close()
 
 
-@pytest.mark.parametrize("B", [5, 40, 200])
-def test_p2_split_direction_form_equals_fused_form(hip_ctx, B, monkeypatch):
-    """small batches run the two directions of a tile on two CUs (hand-offs through agent-scope counters) with the x-part of
-    step s+1 issued behind step s (x- and h-products in separate accumulators, so sums round differently from the
-    one-workgroup form): agreement to 1e-5 on logits / accumulated softmax, equal labels away from ties, and bit-identical run
-    to run, for the 19-window loop and for the single-window operator"""
+@pytest.mark.parametrize("B", [5, 40, 200, 1000])
+def test_p2_split_forms_equal_fused_form(hip_ctx, B, monkeypatch):
+    """small batches run split over CUs: by default the UNIT-split form (workgroup = tile x direction x half of the hidden
+    units, the halves swap h every step through data-tagged write-through pairs; up to 1024 chunks), with PV_GRU_USPLIT=0 the
+    direction-split form (two workgroups per tile, hand-offs at the layer boundaries only). Both keep x- and h-products in
+    separate accumulators, so sums round differently from the one-workgroup form: agreement to 1e-5 on logits / accumulated
+    softmax, equal labels away from ties, and bit-identical run to run, for the 19-window loop and the single-window operator"""
     hip_ctx.load_p2(synth.make_weights_p2(11, 2.0))
     y = synth.synth_p2_images(500 + B, B)
-    l1, a1 = hip_ctx.forward_p2(y, want_acc=True)                       # split form (2 * tiles <= CUs)
-    lg1, h1 = hip_ctx.forward_p2_window(y[:, :100].copy())
     monkeypatch.setenv("PV_GRU_SPLIT", "0")
-    l0, a0 = hip_ctx.forward_p2(y, want_acc=True)
+    l0, a0 = hip_ctx.forward_p2(y, want_acc=True)                       # one workgroup per tile
     lg0, h0 = hip_ctx.forward_p2_window(y[:, :100].copy())
-    np.testing.assert_allclose(a1, a0, atol=1e-5, rtol=0)
-    np.testing.assert_allclose(lg1, lg0, atol=1e-5, rtol=0)
-    np.testing.assert_allclose(h1, h0, atol=1e-5, rtol=0)
+    monkeypatch.delenv("PV_GRU_SPLIT")
     top2 = np.sort(a0, axis=2)
     clear = (top2[..., -1] - top2[..., -2]) > 1e-4
-    assert np.array_equal(l1[clear], l0[clear])
-    # and run to run (the hand-off protocol is a synchronisation, not a source of non-determinism)
-    monkeypatch.delenv("PV_GRU_SPLIT")
-    l2, a2 = hip_ctx.forward_p2(y, want_acc=True)
-    assert np.array_equal(a2.view(np.uint32), a1.view(np.uint32)) and np.array_equal(l2, l1)
+    for form in ("unit_split", "direction_split"):
+        if form == "direction_split":
+            monkeypatch.setenv("PV_GRU_USPLIT", "0")
+        l1, a1 = hip_ctx.forward_p2(y, want_acc=True)
+        lg1, h1 = hip_ctx.forward_p2_window(y[:, :100].copy())
+        np.testing.assert_allclose(a1, a0, atol=1e-5, rtol=0, err_msg=form)
+        np.testing.assert_allclose(lg1, lg0, atol=1e-5, rtol=0, err_msg=form)
+        np.testing.assert_allclose(h1, h0, atol=1e-5, rtol=0, err_msg=form)
+        assert np.array_equal(l1[clear], l0[clear]), form
+        # and run to run (the exchange is a synchronisation, not a source of non-determinism)
+        l2, a2 = hip_ctx.forward_p2(y, want_acc=True)
+        assert np.array_equal(a2.view(np.uint32), a1.view(np.uint32)) and np.array_equal(l2, l1), form
+
+
+def test_p2_unit_split_exchange_under_uneven_load(hip_ctx):
+    """the per-step h exchange of the unit-split GRU form with the chip shared unevenly: a second context keeps chip-filling
+    P1 launches in flight on its own stream while 64-chunk P2 calls run; every call reproduces the quiet result bit for bit"""
+    import torch
+    from pepper_thesis_amd import _ffi, runtime
+    hip_ctx.load_p2(synth.make_weights_p2(12, 2.0))
+    other = runtime.Context(hip_ctx.device_id)
+    other.load_p1(synth.make_weights_p1(5, 2.0))
+    dev = "cuda:%d" % hip_ctx.device_id
+    lib = _ffi.load()
+    y = torch.from_numpy(synth.synth_p2_images(900, 64)).to(dev)
+    big = torch.from_numpy(synth.synth_windows(901, 8000)).to(dev)
+    pbig = torch.zeros((8000, 3), dtype=torch.float32, device=dev)
+
+    def call(labels, acc):
+        _ffi.check(lib.pv_rnn_forward_p2_dev(hip_ctx.handle, y.data_ptr(), 64, labels.data_ptr(), acc.data_ptr(), None))
+
+    mk = lambda: (torch.zeros((64, 1000), dtype=torch.uint8, device=dev), torch.zeros((64, 1000, 5), dtype=torch.float32, device=dev))
+    ql, qa = mk()
+    call(ql, qa)
+    hip_ctx.synchronize()
+    outs = [mk() for _ in range(6)]
+    for k, (l, a) in enumerate(outs):
+        other.forward_p1_dev(big.data_ptr(), 8000 - 100 * k, pbig.data_ptr())   # asynchronous: overlaps the call below
+        call(l, a)
+    hip_ctx.synchronize()
+    other.synchronize()
+    for k, (l, a) in enumerate(outs):
+        assert torch.equal(a.view(torch.int32), qa.view(torch.int32)) and torch.equal(l, ql), "call %d" % k
+    other.close()
