@@ -254,7 +254,7 @@ def single_call_secondary(ctx, dev, weights):
     import torch
     from pepper_thesis_amd import synth
     out = {}
-    for B in (512, 2048, 4096):
+    for B in (512, 1024, 2048, 4096):
         x = torch.from_numpy(synth.synth_windows(3, B)).to(dev)
         probs = torch.zeros((B, 3), dtype=torch.float32, device=dev)
         for _ in range(2):

@@ -327,16 +327,17 @@ __global__ __launch_bounds__(512, 2) void k_lstm_layer(LstmArgs a) {
 // W[gate*H + 64*part + 16*wave + (lane&15)][8kb + 2*(lane>>4) + j], K = [x (padded) | h], through a ring of SP_D register
 // sets requested SP_D-1 k-blocks ahead (a k-block is only 8 MFMAs = 256 cycles and nothing else hides L2 latency with one
 // wave per SIMD); the ring wraps into the next step.
-constexpr int SP_NS = 4;
 constexpr int SP_D = 12;
+// NS = workgroups per (tile, direction): 4 (4 waves each, up to 512 windows on 256 CUs) or 2 (8 waves each, two per SIMD,
+// up to 1024 windows). NS * threads per workgroup = 1024 in both, so the exchange buffer has one shape.
 constexpr int SP_FLAG_STRIDE = 32;   // ints between two counters: every counter on a 128-byte line of its own (fence form)
 constexpr int SP_SC1 = 16;           // cache policy bit 4 = sc1 on gfx94x / gfx950: write-through stores, L1-bypassing loads
-constexpr int SP_HX_QUADS = 2 * SP_NS * 2 * 256;   // 16-byte granules per (tile, direction): [2 slots][4 parts][2][256 threads]
+constexpr int SP_HX_QUADS = 2 * 2 * 1024;          // 16-byte granules per (tile, direction): [2 slots][NS parts][2][1024 / NS threads]
 
 struct LstmSplitArgs {
     const int8_t* x_i8;   // [B,33,26]    (encoder)
     const float* x_f32;   // [Bp,33,512]  (decoder)
-    const float* wp;      // packed [2 dirs][4 parts][4 waves][nkb][2][64][4]
+    const float* wp;      // packed [2 dirs][NS parts][16 / NS waves][nkb][2][64][4]
     const float* bias;    // [2][1024]
     float* out;           // [Bp,33,512]
     u32x4* hx;            // [n_tiles*2][SP_HX_QUADS] tagged h granules
@@ -379,26 +380,26 @@ __device__ __forceinline__ void ring_split(f32x4 (&acc)[4], const float* __restr
     }
 }
 
-template <int KP, bool INT8>
-__global__ __launch_bounds__(256) void k_lstm_split(LstmSplitArgs a) {
+template <int KP, bool INT8, int SP_NS>
+__global__ __launch_bounds__(1024 / SP_NS) void k_lstm_split(LstmSplitArgs a) {
     constexpr int TR = 16, LDX = KP + 4, LDH = H + 4;
     constexpr int NKB_X = KP / 8, NKB_H = H / 8, NTOT = NKB_X + NKB_H;
-    constexpr int NTHR = 256;
+    constexpr int NTHR = 1024 / SP_NS, NW = NTHR / 64, UPP = H / SP_NS;   // threads, waves, units per part
     extern __shared__ float smem[];
     float* xbuf = smem;               // [16][LDX]
     float* hbuf = smem + TR * LDX;    // [2][16][LDH]: all 256 units of h
     const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     // the four parts of a (tile, direction) sit on ONE XCD (they exchange through its L2), one direction per XCD
     const int xcd = blockIdx.x & 7, q = blockIdx.x >> 3;
-    const int part = q & 3;
+    const int part = q % SP_NS;
     const int dir = xcd & 1;
-    const int tile = (q >> 2) * 4 + (xcd >> 1);
+    const int tile = (q / SP_NS) * 4 + (xcd >> 1);
     if (tile >= a.n_tiles) return;   // whole groups leave together: `tile` does not depend on `part`
     const int td = tile * 2 + dir;
     const int64_t b0 = (int64_t)tile * TR;
-    const float* wp = a.wp + ((size_t)((dir * SP_NS + part) * 4 + wv) * NTOT) * 2 * 256;
+    const float* wp = a.wp + ((size_t)((dir * SP_NS + part) * NW + wv) * NTOT) * 2 * 256;
     const float* bias = a.bias + dir * 4 * H;
-    const int unit = 64 * part + 16 * wv + (lane & 15);
+    const int unit = UPP * part + 16 * wv + (lane & 15);
     const int rowg = lane >> 4;       // this lane holds rows 4*rowg .. 4*rowg+3 of its unit
 
     for (int i = tid; i < 2 * TR * LDH; i += NTHR) hbuf[i] = 0.0f;
@@ -416,8 +417,9 @@ __global__ __launch_bounds__(256) void k_lstm_split(LstmSplitArgs a) {
 
     // x_t staging through registers (as in k_lstm_layer): every part loads the whole 16-row x tile
     constexpr int V4 = KP / 4;
-    constexpr int XR = INT8 ? 1 : TR * V4 / NTHR;   // decoder: 8 float4 per thread, rows tid/128 + 2u
-    constexpr int XI = INT8 ? TR * KP / NTHR : 1;   // encoder: 2 bytes per thread, rows tid/32 + 8u
+    constexpr int XR = INT8 ? 1 : TR * V4 / NTHR;   // decoder: 8 (4) float4 per thread, rows tid/128 + (NTHR/128) u
+    constexpr int XI = INT8 ? TR * KP / NTHR : 1;   // encoder: 2 (1) bytes per thread, rows tid/32 + (NTHR/32) u
+    constexpr int XRS = NTHR / 32;                  // encoder row stride between a thread's elements
     f32x4 xr[XR];
     unsigned xi[XI];
     int xoff[XI];
@@ -431,7 +433,7 @@ __global__ __launch_bounds__(256) void k_lstm_split(LstmSplitArgs a) {
         static_assert(KP == 32, "encoder staging assumes 32 padded features");
 #pragma unroll
         for (int u = 0; u < XI; u++) {
-            int64_t r = (tid >> 5) + 8 * u;
+            int64_t r = (tid >> 5) + XRS * u;
             if (b0 + r >= a.B) r = a.B - 1 - b0;   // rows beyond B replicate row B-1
             xoff[u] = (int)(r * T_STEPS * F_IN) + ((tid & 31) < F_IN ? (tid & 31) : F_IN - 1);
         }
@@ -450,7 +452,7 @@ __global__ __launch_bounds__(256) void k_lstm_split(LstmSplitArgs a) {
     auto x_store = [&]() {
         if constexpr (INT8) {
 #pragma unroll
-            for (int u = 0; u < XI; u++) (xbuf + u * 8 * LDX)[xe_l] = xe_valid ? (float)(int)xi[u] : 0.0f;
+            for (int u = 0; u < XI; u++) (xbuf + u * XRS * LDX)[xe_l] = xe_valid ? (float)(int)xi[u] : 0.0f;
         } else {
 #pragma unroll
             for (int u = 0; u < XR; u++) *reinterpret_cast<f32x4*>(xbuf + u * (NTHR / V4) * LDX + xl_l) = xr[u];
@@ -459,8 +461,8 @@ __global__ __launch_bounds__(256) void k_lstm_split(LstmSplitArgs a) {
     const unsigned h_l = (unsigned)(4 * rowg * LDH + unit);
     const unsigned og_l = (unsigned)((4 * rowg * T_STEPS * 2 * H + unit) * 4);
     const __amdgpu_buffer_rsrc_t hsr = make_rsrc(a.hx + (size_t)td * SP_HX_QUADS);
-    // granule (slot, part, g) of thread tid: 16-byte index ((slot * SP_NS + part) * 2 + g) * 256 + tid
-    auto hx_off = [](int slot, int prt, int g) { return (unsigned)((((slot * SP_NS + prt) * 2 + g) * 256) * 16); };
+    // granule (slot, part, g) of thread tid: 16-byte index ((slot * SP_NS + part) * 2 + g) * NTHR + tid
+    auto hx_off = [](int slot, int prt, int g) { return (unsigned)((((slot * SP_NS + prt) * 2 + g) * NTHR) * 16); };
 #ifdef PV_SPLIT_FENCES
     int* flags_td = a.flags + (size_t)td * SP_NS * SP_FLAG_STRIDE;
 #endif
@@ -480,12 +482,12 @@ __global__ __launch_bounds__(256) void k_lstm_split(LstmSplitArgs a) {
             // ---- the other three quarters of h_{t-1}: the granules of this thread's twins in the partner workgroups ----
             const unsigned want = (unsigned)(a.flag_base + s);
             const int ps = (s - 1) & 1;
-            u32x4 fq[3][2];
+            u32x4 fq[SP_NS - 1][2];
 #ifdef PV_SPLIT_FENCES
             if (tid == 0) {
 #pragma unroll
                 for (int k = 1; k < SP_NS; k++) {
-                    const int* f = flags_td + ((part + k) & 3) * SP_FLAG_STRIDE;
+                    const int* f = flags_td + ((part + k) % SP_NS) * SP_FLAG_STRIDE;
                     int spins = 0;
                     while (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (int)want) {
                         __builtin_amdgcn_s_sleep(1);
@@ -497,19 +499,19 @@ __global__ __launch_bounds__(256) void k_lstm_split(LstmSplitArgs a) {
             }
             __syncthreads();
 #pragma unroll
-            for (int u = 0; u < 3; u++)
+            for (int u = 0; u < SP_NS - 1; u++)
 #pragma unroll
                 for (int g = 0; g < 2; g++)
-                    fq[u][g] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(hsr, (unsigned)tid * 16u, hx_off(ps, (part + 1 + u) & 3, g), 0));
+                    fq[u][g] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(hsr, (unsigned)tid * 16u, hx_off(ps, (part + 1 + u) % SP_NS, g), 0));
 #else
             int spins = 0;
             while (true) {   // bounded: a lost partner ends in wrong results, never in a hung device
                 bool ok = true;
 #pragma unroll
-                for (int u = 0; u < 3; u++)
+                for (int u = 0; u < SP_NS - 1; u++)
 #pragma unroll
                     for (int g = 0; g < 2; g++) {
-                        fq[u][g] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(hsr, (unsigned)tid * 16u, hx_off(ps, (part + 1 + u) & 3, g), SP_SC1));
+                        fq[u][g] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(hsr, (unsigned)tid * 16u, hx_off(ps, (part + 1 + u) % SP_NS, g), SP_SC1));
                         ok = ok && fq[u][g][1] == want && fq[u][g][3] == want;
                     }
                 asm volatile("" ::: "memory");   // the loads are repeated, not hoisted
@@ -518,9 +520,9 @@ __global__ __launch_bounds__(256) void k_lstm_split(LstmSplitArgs a) {
 #endif
             float* hc = hbuf + cur * TR * LDH;
 #pragma unroll
-            for (int u = 0; u < 3; u++) {
-                const int fp = (part + 1 + u) & 3;
-                float* dst = hc + 4 * ((tid & 63) >> 4) * LDH + 64 * fp + 16 * (tid >> 6) + (tid & 15);
+            for (int u = 0; u < SP_NS - 1; u++) {
+                const int fp = (part + 1 + u) % SP_NS;
+                float* dst = hc + 4 * ((tid & 63) >> 4) * LDH + UPP * fp + 16 * (tid >> 6) + (tid & 15);
 #pragma unroll
                 for (int g = 0; g < 2; g++) {
                     // (elements go through scalars: hipcc 7.2 compiles __builtin_bit_cast(float, vec[2]) as element 0)
@@ -1063,21 +1065,21 @@ static void pack_lstm(const pv_rnn_dir* dirs, int K, int KP, int TR, std::vector
 }
 
 // unit-split form (k_lstm_split): [dir][part][wave][k-block][2][lane][4], see the kernel
-static void pack_lstm_split(const pv_rnn_dir* dirs, int K, int KP, std::vector<float>& wp) {
-    const int nkb = (KP + H) / 8;
-    wp.assign((size_t)2 * SP_NS * 4 * nkb * 2 * 256, 0.0f);
+static void pack_lstm_split(const pv_rnn_dir* dirs, int K, int KP, int SP_NS, std::vector<float>& wp) {
+    const int nkb = (KP + H) / 8, NW = 16 / SP_NS, UPP = H / SP_NS;
+    wp.assign((size_t)2 * 16 * nkb * 2 * 256, 0.0f);
     for (int d = 0; d < 2; d++) {
         auto wval = [&](int n, int k) -> float {
             if (k < KP) return k < K ? dirs[d].w_ih[(size_t)n * K + k] : 0.0f;
             return dirs[d].w_hh[(size_t)n * H + (k - KP)];
         };
         for (int p = 0; p < SP_NS; p++)
-            for (int w = 0; w < 4; w++)
+            for (int w = 0; w < NW; w++)
                 for (int kb = 0; kb < nkb; kb++)
                     for (int half = 0; half < 2; half++)
                         for (int lane = 0; lane < 64; lane++) {
-                            float* dst = &wp[(((((size_t)(d * SP_NS + p) * 4 + w) * nkb + kb) * 2 + half) * 64 + lane) * 4];
-                            const int u = 64 * p + 16 * w + (lane & 15);
+                            float* dst = &wp[(((((size_t)(d * SP_NS + p) * NW + w) * nkb + kb) * 2 + half) * 64 + lane) * 4];
+                            const int u = UPP * p + 16 * w + (lane & 15);
                             for (int gg = 0; gg < 2; gg++)
                                 for (int j = 0; j < 2; j++)
                                     dst[2 * gg + j] = wval((2 * half + gg) * H + u, kb * 8 + 2 * (lane >> 4) + j);
@@ -1120,7 +1122,8 @@ struct pv_rnn_p1 {
     float* enc_wp[2] = {nullptr, nullptr};  // [0] 32-row tile form, [1] 16-row tile form (mfma_tiles.hpp)
     float* dec_wp[2] = {nullptr, nullptr};
     float* enc_bias = nullptr; float* dec_bias = nullptr;
-    float* enc_wps = nullptr; float* dec_wps = nullptr;    // unit-split form (k_lstm_split)
+    float* enc_wps[2] = {nullptr, nullptr};                // unit-split form (k_lstm_split): [0] four parts, [1] two parts
+    float* dec_wps[2] = {nullptr, nullptr};
     u32x4* sp_hx = nullptr; int* sp_flags = nullptr;       // its exchange buffer (tagged granules) and counters (fence form)
     int sp_epoch = 0;
     float* w1p = nullptr; float* b1 = nullptr;
@@ -1216,13 +1219,15 @@ extern "C" int pv_rnn_load_p1(pv_ctx* ctx, const pv_weights_p1* w, int dtype) {
         if ((rc = dev_upload(wp, &m->dec_wp[f], m->owned))) return rc;
         if (!f && (rc = dev_upload(bias, &m->dec_bias, m->owned))) return rc;
     }
-    pack_lstm_split(w->encoder, F_IN, 32, wp);
-    if ((rc = dev_upload(wp, &m->enc_wps, m->owned))) return rc;
-    pack_lstm_split(w->decoder, 2 * H, 2 * H, wp);
-    if ((rc = dev_upload(wp, &m->dec_wps, m->owned))) return rc;
+    for (int f = 0; f < 2; f++) {
+        pack_lstm_split(w->encoder, F_IN, 32, f ? 2 : 4, wp);
+        if ((rc = dev_upload(wp, &m->enc_wps[f], m->owned))) return rc;
+        pack_lstm_split(w->decoder, 2 * H, 2 * H, f ? 2 : 4, wp);
+        if ((rc = dev_upload(wp, &m->dec_wps[f], m->owned))) return rc;
+    }
     {
         const size_t hx_bytes = (size_t)SP_MAX_TILES * 2 * SP_HX_QUADS * sizeof(u32x4);
-        const size_t fl_bytes = (size_t)SP_MAX_TILES * 2 * SP_NS * SP_FLAG_STRIDE * sizeof(int);
+        const size_t fl_bytes = (size_t)SP_MAX_TILES * 2 * 4 * SP_FLAG_STRIDE * sizeof(int);
         PV_HIP(hipMalloc((void**)&m->sp_hx, hx_bytes));
         m->owned.push_back(m->sp_hx);
         PV_HIP(hipMalloc((void**)&m->sp_flags, fl_bytes));
@@ -1257,8 +1262,10 @@ extern "C" int pv_rnn_load_p1(pv_ctx* ctx, const pv_weights_p1* w, int dtype) {
     PV_HIP(hipFuncSetAttribute((const void*)k_lstm_layer<32, true, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_lstm<32, 16>()));
     PV_HIP(hipFuncSetAttribute((const void*)k_lstm_layer<512, false, 32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_lstm<512, 32>()));
     PV_HIP(hipFuncSetAttribute((const void*)k_lstm_layer<512, false, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_lstm<512, 16>()));
-    PV_HIP(hipFuncSetAttribute((const void*)k_lstm_split<32, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_lstm_split<32>()));
-    PV_HIP(hipFuncSetAttribute((const void*)k_lstm_split<512, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_lstm_split<512>()));
+    PV_HIP(hipFuncSetAttribute((const void*)k_lstm_split<32, true, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_lstm_split<32>()));
+    PV_HIP(hipFuncSetAttribute((const void*)k_lstm_split<512, false, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_lstm_split<512>()));
+    PV_HIP(hipFuncSetAttribute((const void*)k_lstm_split<32, true, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_lstm_split<32>()));
+    PV_HIP(hipFuncSetAttribute((const void*)k_lstm_split<512, false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_lstm_split<512>()));
     PV_HIP(hipFuncSetAttribute((const void*)k_head_splitk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_SPLITK));
     PV_HIP(hipFuncSetAttribute((const void*)k_head_tail<32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_tail<32>()));
     PV_HIP(hipFuncSetAttribute((const void*)k_head_tail<16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_tail<16>()));
@@ -1300,24 +1307,27 @@ static int p1_forward_launch(pv_ctx* ctx, const int8_t* d_images, int64_t B, flo
         e.out_split = enc_split; e.Bp = (int64_t)n_tiles * ROWS;
         if (!taps) e.out = nullptr;
     }
-    // unit-split form: one small fp32 batch whose (16-row tile, direction, quarter of the hidden units) workgroups all fit
-    // on the chip at once (<= 512 windows on 256 CUs); PV_LSTM_SPLIT=0 keeps the one-workgroup form
+    // unit-split form: one small fp32 batch whose (16-row tile, direction, part of the hidden units) workgroups all fit on
+    // the chip at once: four parts up to 512 windows on 256 CUs, two parts up to 1024; PV_LSTM_SPLIT=0 keeps the
+    // one-workgroup form
     const int n_t16 = n_tiles * 2;
-    bool split = m->dtype == PV_DTYPE_F32 && n_t16 <= SP_MAX_TILES && (int64_t)n_t16 * 2 * SP_NS <= ctx->num_cu;
+    const int sp_ns = (int64_t)n_t16 * 2 * 4 <= ctx->num_cu ? 4 : 2;
+    bool split = m->dtype == PV_DTYPE_F32 && n_t16 <= SP_MAX_TILES && (int64_t)n_t16 * 2 * sp_ns <= ctx->num_cu;
     if (const char* ev = getenv("PV_LSTM_SPLIT")) { if (atoi(ev) == 0) split = false; }
     if (getenv("PV_LSTM_ROWS")) split = false;   // an explicit tile form was asked for
     LstmSplitArgs se;
-    const unsigned split_grid = (unsigned)(((n_t16 + 3) / 4) * 8 * SP_NS);
+    const unsigned split_grid = (unsigned)(((n_t16 + 3) / 4) * 8 * sp_ns);
     if (split) {
         if (m->sp_epoch > (1 << 23)) {   // tags / counters are monotonic over launches: restart them long before they overflow
-            PV_HIP(hipMemsetAsync(m->sp_flags, 0, (size_t)SP_MAX_TILES * 2 * SP_NS * SP_FLAG_STRIDE * sizeof(int), st));
+            PV_HIP(hipMemsetAsync(m->sp_flags, 0, (size_t)SP_MAX_TILES * 2 * 4 * SP_FLAG_STRIDE * sizeof(int), st));
             PV_HIP(hipMemsetAsync(m->sp_hx, 0, (size_t)SP_MAX_TILES * 2 * SP_HX_QUADS * sizeof(u32x4), st));
             m->sp_epoch = 0;
         }
-        se.x_i8 = d_images; se.x_f32 = nullptr; se.wp = m->enc_wps; se.bias = m->enc_bias; se.out = enc_out;
+        se.x_i8 = d_images; se.x_f32 = nullptr; se.wp = m->enc_wps[sp_ns == 4 ? 0 : 1]; se.bias = m->enc_bias; se.out = enc_out;
         se.hx = m->sp_hx; se.flags = m->sp_flags; se.B = B; se.n_tiles = n_t16; se.flag_base = (m->sp_epoch++) * 64;
         pv_prof_scope ps(ctx, "k_lstm_split_enc", st);
-        k_lstm_split<32, true><<<split_grid, 256, lds_lstm_split<32>(), st>>>(se);
+        if (sp_ns == 4) k_lstm_split<32, true, 4><<<split_grid, 256, lds_lstm_split<32>(), st>>>(se);
+        else k_lstm_split<32, true, 2><<<split_grid, 512, lds_lstm_split<32>(), st>>>(se);
     } else {
         pv_prof_scope ps(ctx, "k_lstm_layer_enc", st);
         if (tr == 32) k_lstm_layer<32, true, 32><<<lstm_grid, 512, lds_lstm<32, 32>(), st>>>(e);
@@ -1369,10 +1379,11 @@ static int p1_forward_launch(pv_ctx* ctx, const int8_t* d_images, int64_t B, flo
     d.x_i8 = nullptr; d.x_f32 = enc_out; d.wp = m->dec_wp[f]; d.bias = m->dec_bias; d.out = dec_out;
     if (split) {
         LstmSplitArgs sd = se;
-        sd.x_i8 = nullptr; sd.x_f32 = enc_out; sd.wp = m->dec_wps; sd.bias = m->dec_bias; sd.out = dec_out;
+        sd.x_i8 = nullptr; sd.x_f32 = enc_out; sd.wp = m->dec_wps[sp_ns == 4 ? 0 : 1]; sd.bias = m->dec_bias; sd.out = dec_out;
         sd.flag_base = (m->sp_epoch++) * 64;
         pv_prof_scope ps(ctx, "k_lstm_split_dec", st);
-        k_lstm_split<512, false><<<split_grid, 256, lds_lstm_split<512>(), st>>>(sd);
+        if (sp_ns == 4) k_lstm_split<512, false, 4><<<split_grid, 256, lds_lstm_split<512>(), st>>>(sd);
+        else k_lstm_split<512, false, 2><<<split_grid, 512, lds_lstm_split<512>(), st>>>(sd);
     } else {
         pv_prof_scope ps(ctx, "k_lstm_layer_dec", st);
         if (tr == 32) k_lstm_layer<512, false, 32><<<lstm_grid, 512, lds_lstm<512, 32>(), st>>>(d);

@@ -59,11 +59,11 @@ def test_p1_ragged_batches_vs_oracle(hip_ctx, B, rows, monkeypatch):
         np.testing.assert_allclose(probs[-40:], alone, atol=1e-6, rtol=0)
 
 
-@pytest.mark.parametrize("B", [1, 17, 100, 512])
+@pytest.mark.parametrize("B", [1, 17, 100, 512, 513, 1000])
 def test_p1_unit_split_form_equals_one_workgroup_form(hip_ctx, B, monkeypatch):
-    """a small batch runs with the hidden units of every (tile, direction) split over four workgroups that exchange h once per
-    step (agent-scope counters). Same MFMA shape, same K order per accumulator as the 16-row one-workgroup form: the layer
-    outputs and the probabilities are BIT-identical to it, and run to run"""
+    """a small batch runs with the hidden units of every (tile, direction) split over four workgroups (up to 512 windows) or
+    two (up to 1024) that exchange h once per step (data-tagged write-through pairs). Same MFMA shape, same K order per
+    accumulator as the 16-row one-workgroup form: the layer outputs and the probabilities are BIT-identical to it, and run to run"""
     w = synth.make_weights_p1(31, 2.0)
     hip_ctx.load_p1(w)
     x = synth.synth_windows(3100 + B, B)
@@ -72,9 +72,18 @@ def test_p1_unit_split_form_equals_one_workgroup_form(hip_ctx, B, monkeypatch):
     monkeypatch.setenv("PV_LSTM_ROWS", "16")
     p0, e0, d0 = hip_ctx.forward_p1(x, taps=True)
     for p1, e1, d1 in runs:
-        assert np.array_equal(e1.view(np.uint32), e0.view(np.uint32))
-        assert np.array_equal(d1.view(np.uint32), d0.view(np.uint32))
-        assert np.array_equal(p1.view(np.uint32), p0.view(np.uint32))
+        if B <= 512:   # the four-part instantiation: the very same bits
+            assert np.array_equal(e1.view(np.uint32), e0.view(np.uint32))
+            assert np.array_equal(d1.view(np.uint32), d0.view(np.uint32))
+            assert np.array_equal(p1.view(np.uint32), p0.view(np.uint32))
+        else:          # the two-part instantiation: hipcc contracts the cell update's multiply-adds differently (last-bit
+            # differences on a few elements), so: to rounding, and bit-identical run to run
+            np.testing.assert_allclose(e1, e0, atol=2e-6, rtol=0)
+            np.testing.assert_allclose(d1, d0, atol=2e-6, rtol=0)
+            np.testing.assert_allclose(p1, p0, atol=2e-6, rtol=0)
+            assert np.array_equal(e1.view(np.uint32), runs[0][1].view(np.uint32))
+            assert np.array_equal(d1.view(np.uint32), runs[0][2].view(np.uint32))
+            assert np.array_equal(p1.view(np.uint32), runs[0][0].view(np.uint32))
 
 
 def test_p1_unit_split_exchange_under_uneven_load(hip_ctx):

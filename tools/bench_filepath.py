@@ -3,7 +3,7 @@ pool, HIP image builder, image HDF5) -> run_inference (image HDF5 -> HIP RNN -> 
 The BAM is synthetic (SURVEY 8(d) shape: one contig of >= 1 Mbp at 60x, 10 kb reads, planted sites) and is written here
 with the library's own BAM writer (pvio_write_bam); nothing under oracle/ is used. Not part of `value`.
 
-  python tools/bench_filepath.py [--mbp 1.0]
+  python tools/bench_filepath.py [--mbp 3.2]   (32 intervals of 100 kb: two per reader thread of a 16-core share)
 """
 import argparse
 import json
@@ -49,7 +49,7 @@ def make_files(dirname, contig_len, depth=60, read_len=10_000, site_every=198, s
                          bam_bytes=os.path.getsize(bam))
 
 
-def run(ctx, weights, dev=None, mbp=1.0, keep_dir=None):
+def run(ctx, weights, dev=None, mbp=3.2, keep_dir=None):
     from pepper_thesis_amd import make_images, run_inference
     from pepper_thesis_amd.batch import PRESETS
     d = keep_dir or tempfile.mkdtemp(prefix="pv_filepath_")
@@ -92,7 +92,7 @@ def run(ctx, weights, dev=None, mbp=1.0, keep_dir=None):
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
-    ap.add_argument("--mbp", type=float, default=1.0)
+    ap.add_argument("--mbp", type=float, default=3.2)
     a = ap.parse_args()
     from pepper_thesis_amd import runtime, synth
     c = runtime.Context(0)

@@ -64,7 +64,7 @@ if __name__ == "__main__":
     out = {}
     for form in ("split", "one_workgroup"):
         os.environ["PV_LSTM_SPLIT"] = "1" if form == "split" else "0"
-        out[form] = {"B%d" % B: one(ctx, "cuda:0", B) for B in (64, 256, 512)}
+        out[form] = {"B%d" % B: one(ctx, "cuda:0", B) for B in (64, 256, 512, 1024)}
         out[form]["callers4_x_B512_windows_per_s"] = callers(ctx, "cuda:0", w, 4)
         sys.stderr.write("[bench_single] %s done\n" % form)
     print(json.dumps(out))
