@@ -139,6 +139,7 @@ struct GruArgs {
     u32x4* hx;              // [n_tiles][2 dirs][US_HX_QUADS] data-tagged h pairs
     int* quad_flags;        // [n_tiles][4][US_FLAG_STRIDE] layer-boundary counters of the four workgroups of a tile (zeroed per launch)
     unsigned tag_base;      // tags of this launch run from tag_base + 1
+    int* err;               // bumped when a bounded poll of the exchange gave up
 };
 
 // ---- the two directions of a tile on two CUs (small batches) -----------------------------------------------------------
@@ -745,7 +746,8 @@ __device__ __forceinline__ void gru_window_us(const GruArgs& a, int win_start, i
                     ok = ok && fq[g][1] == want && fq[g][3] == want;
                 }
                 asm volatile("" ::: "memory");   // the loads are repeated, not hoisted
-                if (ok || ++spins > (1 << 18)) break;
+                if (ok) break;
+                if (++spins > (1 << 18)) { atomicAdd(a.err, 1); break; }
             }
             float* dst = hbuf + cur * TR * LDH + 4 * rowg * LDH + 64 * (half ^ 1) + 16 * wv + (lane & 15);
 #pragma unroll
@@ -973,6 +975,7 @@ struct pv_rnn_p2 {
     float* enc_wp[4] = {nullptr, nullptr, nullptr, nullptr};  // [0] 32-row tile form, [1] 16-row tile form, [2] 16-row form in [h | x] order (split form), [3] unit-split form
     float* dec_wp[4] = {nullptr, nullptr, nullptr, nullptr};
     unsigned us_epoch = 0;
+    int* us_err = nullptr;   // exchange time-outs of the unit-split form (device word)
     const void* us_hx_seen = nullptr; size_t us_hx_n = 0;   // the exchange buffer whose tags belong to this epoch sequence
     float* enc_bias = nullptr; float* dec_bias = nullptr;
     float* dense_w = nullptr; float* dense_b = nullptr;
@@ -1024,6 +1027,9 @@ extern "C" int pv_rnn_load_p2(pv_ctx* ctx, const pv_weights_p2* w, int dtype) {
     pack_gru_us(w->decoder, KPD, KPD, wp);
     if ((rc = up2(wp.data(), wp.size(), &m->dec_wp[3], m->owned))) return rc;
     PV_HIP(hipFuncSetAttribute((const void*)k_gru_us, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_US));
+    PV_HIP(hipMalloc((void**)&m->us_err, 64));
+    m->owned.push_back(m->us_err);
+    PV_HIP(hipMemset(m->us_err, 0, 64));
     if ((rc = up2(w->dense_w, (size_t)NCLS * KPD, &m->dense_w, m->owned)) || (rc = up2(w->dense_b, NCLS, &m->dense_b, m->owned))) return rc;
     PV_HIP(hipFuncSetAttribute((const void*)k_gru_p2<32, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_p2<32, false>()));
     PV_HIP(hipFuncSetAttribute((const void*)k_gru_p2<16, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_p2<16, false>()));
@@ -1059,7 +1065,7 @@ static int p2_launch(pv_ctx* ctx, const uint8_t* d_images, int64_t B, uint8_t* d
     bool split = tr == 16 && 2 * n_tiles <= ctx->num_cu;
     if (const char* e = getenv("PV_GRU_SPLIT")) split = split && atoi(e) != 0;
     g.pair_flags = nullptr;
-    g.hx = nullptr; g.quad_flags = nullptr; g.tag_base = 0;
+    g.hx = nullptr; g.quad_flags = nullptr; g.tag_base = 0; g.err = m->us_err;
     // unit-split form: (tile, direction, half of the units) workgroups with a per-step h exchange, while all of them can be
     // resident at once (up to 1024 chunks on 256 CUs); PV_GRU_USPLIT=0 keeps the direction-split form
     bool usplit = tr == 16 && 4 * n_tiles <= ctx->num_cu;
@@ -1100,6 +1106,20 @@ static int p2_launch(pv_ctx* ctx, const uint8_t* d_images, int64_t B, uint8_t* d
     return PV_OK;
 }
 
+// end of a host-buffer call: wait, and report exchange time-outs of the unit-split form (only possible when its workgroups
+// could not all be resident, i.e. on a GPU shared with other work)
+static int p2_finish(pv_ctx* ctx, hipStream_t st) {
+    int n_timeouts = 0;
+    PV_HIP(hipMemcpyAsync(&n_timeouts, ctx->p2->us_err, sizeof(int), hipMemcpyDeviceToHost, st));
+    PV_HIP(hipStreamSynchronize(st));
+    if (n_timeouts) {
+        PV_HIP(hipMemset(ctx->p2->us_err, 0, sizeof(int)));
+        pv_set_error("unit-split GRU form: %d exchange polls timed out (GPU shared with other work?); rerun with PV_GRU_USPLIT=0", n_timeouts);
+        return PV_ERR_STATE;
+    }
+    return PV_OK;
+}
+
 extern "C" int pv_rnn_forward_p2_dev(pv_ctx* ctx, const uint8_t* d_images, int64_t B, uint8_t* d_labels, float* d_acc,
                                      void* stream) {
     PV_CHECK(ctx && d_images && d_labels, PV_ERR_INVALID, "null argument");
@@ -1127,8 +1147,7 @@ extern "C" int pv_rnn_forward_p2(pv_ctx* ctx, const uint8_t* images, int64_t B, 
     if ((rc = p2_launch(ctx, d_img, B, d_lab, d_acc, st))) return rc;
     PV_HIP(hipMemcpyAsync(labels, d_lab, (size_t)B * SEQ, hipMemcpyDeviceToHost, st));
     if (acc) PV_HIP(hipMemcpyAsync(acc, d_acc, (size_t)B * SEQ * NCLS * sizeof(float), hipMemcpyDeviceToHost, st));
-    PV_HIP(hipStreamSynchronize(st));
-    return PV_OK;
+    return p2_finish(ctx, st);
 }
 
 // One TransducerGRU.forward(x, hidden) of the polisher model (pepper/modules/python/models/simple_model.py:27-42),
@@ -1157,8 +1176,7 @@ extern "C" int pv_rnn_forward_p2_window(pv_ctx* ctx, const uint8_t* images, cons
     if ((rc = p2_launch(ctx, d_img, B, nullptr, d_acc, st, WIN, 1, d_hin, d_hout, d_log))) return rc;
     PV_HIP(hipMemcpyAsync(logits, d_log, (size_t)B * WIN * NCLS * sizeof(float), hipMemcpyDeviceToHost, st));
     if (hidden_out) PV_HIP(hipMemcpyAsync(hidden_out, d_hout, (size_t)B * 2 * HG * sizeof(float), hipMemcpyDeviceToHost, st));
-    PV_HIP(hipStreamSynchronize(st));
-    return PV_OK;
+    return p2_finish(ctx, st);
 }
 
 #ifdef PV_GRU_STAMPS

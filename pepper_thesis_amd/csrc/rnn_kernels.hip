@@ -345,6 +345,7 @@ struct LstmSplitArgs {
     int64_t B;
     int n_tiles;          // 16-row tiles
     int flag_base;        // tags of this launch run from flag_base + 1
+    int* err;             // bumped when a bounded poll of the exchange gave up (a partner workgroup never showed up)
 };
 
 template <int KB0, int NKB, int NTOT>
@@ -515,7 +516,8 @@ __global__ __launch_bounds__(1024 / SP_NS) void k_lstm_split(LstmSplitArgs a) {
                         ok = ok && fq[u][g][1] == want && fq[u][g][3] == want;
                     }
                 asm volatile("" ::: "memory");   // the loads are repeated, not hoisted
-                if (ok || ++spins > (1 << 18)) break;
+                if (ok) break;
+                if (++spins > (1 << 18)) { atomicAdd(a.err, 1); break; }
             }
 #endif
             float* hc = hbuf + cur * TR * LDH;
@@ -1125,6 +1127,7 @@ struct pv_rnn_p1 {
     float* enc_wps[2] = {nullptr, nullptr};                // unit-split form (k_lstm_split): [0] four parts, [1] two parts
     float* dec_wps[2] = {nullptr, nullptr};
     u32x4* sp_hx = nullptr; int* sp_flags = nullptr;       // its exchange buffer (tagged granules) and counters (fence form)
+    int* sp_err = nullptr;                                 // exchange time-outs (device word, read by the host-buffer entry points)
     int sp_epoch = 0;
     float* w1p = nullptr; float* b1 = nullptr;
     float* wlp[2][4] = {{nullptr, nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr, nullptr}};  // [tile form][layer]
@@ -1234,6 +1237,9 @@ extern "C" int pv_rnn_load_p1(pv_ctx* ctx, const pv_weights_p1* w, int dtype) {
         m->owned.push_back(m->sp_flags);
         PV_HIP(hipMemset(m->sp_flags, 0, fl_bytes));
         PV_HIP(hipMemset(m->sp_hx, 0, hx_bytes));   // tags start at 0: no launch ever waits for tag 0
+        PV_HIP(hipMalloc((void**)&m->sp_err, 64));
+        m->owned.push_back(m->sp_err);
+        PV_HIP(hipMemset(m->sp_err, 0, 64));
     }
     pack_linear(w->linear_w[0], HEAD_K, 32, wp);
     if ((rc = dev_upload(wp, &m->w1p, m->owned)) || (rc = dev_upload(w->linear_b[0], HEAD_N, &m->b1, m->owned))) return rc;
@@ -1325,6 +1331,7 @@ static int p1_forward_launch(pv_ctx* ctx, const int8_t* d_images, int64_t B, flo
         }
         se.x_i8 = d_images; se.x_f32 = nullptr; se.wp = m->enc_wps[sp_ns == 4 ? 0 : 1]; se.bias = m->enc_bias; se.out = enc_out;
         se.hx = m->sp_hx; se.flags = m->sp_flags; se.B = B; se.n_tiles = n_t16; se.flag_base = (m->sp_epoch++) * 64;
+        se.err = m->sp_err;
         pv_prof_scope ps(ctx, "k_lstm_split_enc", st);
         if (sp_ns == 4) k_lstm_split<32, true, 4><<<split_grid, 256, lds_lstm_split<32>(), st>>>(se);
         else k_lstm_split<32, true, 2><<<split_grid, 512, lds_lstm_split<32>(), st>>>(se);
@@ -1466,7 +1473,14 @@ extern "C" int pv_rnn_forward_p1_debug(pv_ctx* ctx, const int8_t* images, int64_
     const size_t nb = (size_t)B * T_STEPS * 2 * H * sizeof(float);
     if (enc_out) PV_HIP(hipMemcpyAsync(enc_out, enc, nb, hipMemcpyDeviceToHost, st));
     if (dec_out) PV_HIP(hipMemcpyAsync(dec_out, dec, nb, hipMemcpyDeviceToHost, st));
+    int n_timeouts = 0;
+    PV_HIP(hipMemcpyAsync(&n_timeouts, ctx->p1->sp_err, sizeof(int), hipMemcpyDeviceToHost, st));
     PV_HIP(hipStreamSynchronize(st));
+    if (n_timeouts) {   // only possible when the launch's workgroups could not all be resident (a GPU shared with other work)
+        PV_HIP(hipMemset(ctx->p1->sp_err, 0, sizeof(int)));
+        pv_set_error("unit-split LSTM form: %d exchange polls timed out (GPU shared with other work?); rerun with PV_LSTM_SPLIT=0", n_timeouts);
+        return PV_ERR_STATE;
+    }
     return PV_OK;
 }
 
