@@ -304,6 +304,14 @@ int pv_debug_gemm_bf16x3(pv_ctx* ctx, const float* A, const float* W, const floa
 int pv_profile_begin(pv_ctx* ctx);
 int pv_profile_end(pv_ctx* ctx, char* names_buf, int buf_len, float* ms_sum, int* counts, int max_kernels);
 
+/* Small batches run in "split" kernel forms whose workgroups swap hidden state every time step (pv_rnn_forward_p1* up to
+ * 1024 windows, pv_rnn_forward_p2* up to 1024 chunks); a launch needs all its workgroups resident at once, which holds
+ * whenever it is chosen, except on a GPU that other work keeps busy for long stretches: a poll then gives up after a bounded
+ * wait and the results of that call are wrong. The host-buffer entry points check for it themselves (PV_ERR_STATE); callers of
+ * the asynchronous *_dev forms call this at their own synchronisation points: it synchronises the context's stream and returns
+ * the number of polls that gave up since the last call (0 = every result is good), or a negative PV_ERR_* code. */
+int pv_rnn_exchange_timeouts(pv_ctx* ctx);
+
 /* bytes of device workspace the context currently holds (diagnostics) */
 int64_t pv_workspace_bytes(pv_ctx* ctx);
 /* library/ABI version: major*10000 + minor*100 + patch */

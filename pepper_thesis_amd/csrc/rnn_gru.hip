@@ -1120,6 +1120,14 @@ static int p2_finish(pv_ctx* ctx, hipStream_t st) {
     return PV_OK;
 }
 
+int pv_p2_take_timeouts(pv_ctx* ctx, int* n) {   // read and clear (the caller has synchronised)
+    *n = 0;
+    if (!ctx->p2 || !ctx->p2->us_err) return PV_OK;
+    PV_HIP(hipMemcpy(n, ctx->p2->us_err, sizeof(int), hipMemcpyDeviceToHost));
+    if (*n) PV_HIP(hipMemset(ctx->p2->us_err, 0, sizeof(int)));
+    return PV_OK;
+}
+
 extern "C" int pv_rnn_forward_p2_dev(pv_ctx* ctx, const uint8_t* d_images, int64_t B, uint8_t* d_labels, float* d_acc,
                                      void* stream) {
     PV_CHECK(ctx && d_images && d_labels, PV_ERR_INVALID, "null argument");

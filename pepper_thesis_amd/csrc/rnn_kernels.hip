@@ -1484,6 +1484,22 @@ extern "C" int pv_rnn_forward_p1_debug(pv_ctx* ctx, const int8_t* images, int64_
     return PV_OK;
 }
 
+int pv_p2_take_timeouts(pv_ctx* ctx, int* n);   // rnn_gru.hip
+
+extern "C" int pv_rnn_exchange_timeouts(pv_ctx* ctx) {
+    PV_CHECK(ctx, PV_ERR_INVALID, "null argument");
+    PV_HIP(hipSetDevice(ctx->device));
+    PV_HIP(hipStreamSynchronize(ctx->stream));
+    int n1 = 0, n2 = 0;
+    if (ctx->p1 && ctx->p1->sp_err) {
+        PV_HIP(hipMemcpy(&n1, ctx->p1->sp_err, sizeof(int), hipMemcpyDeviceToHost));
+        if (n1) PV_HIP(hipMemset(ctx->p1->sp_err, 0, sizeof(int)));
+    }
+    int rc = pv_p2_take_timeouts(ctx, &n2);
+    if (rc) return rc;
+    return n1 + n2;
+}
+
 extern "C" int pv_rnn_forward_p1(pv_ctx* ctx, const int8_t* images, int64_t B, float* probs) {
     return pv_rnn_forward_p1_debug(ctx, images, B, probs, nullptr, nullptr);
 }

@@ -50,6 +50,13 @@ class Context:
     def synchronize(self):
         _ffi.check(self.lib.pv_synchronize(self.handle))
 
+    def exchange_timeouts(self) -> int:
+        """polls of the split kernel forms that gave up since the last call (synchronises; 0 = all results good)"""
+        n = int(self.lib.pv_rnn_exchange_timeouts(self.handle))
+        if n < 0:
+            _ffi.check(n)
+        return n
+
     def workspace_bytes(self) -> int:
         return int(self.lib.pv_workspace_bytes(self.handle))
 

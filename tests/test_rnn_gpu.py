@@ -118,6 +118,7 @@ def test_p1_unit_split_exchange_under_uneven_load(hip_ctx):
     for k, o in enumerate(outs):
         got = o.cpu().numpy()
         assert np.array_equal(got.view(np.uint32), quiet[k % 3].view(np.uint32)), "call %d" % k
+    assert hip_ctx.exchange_timeouts() == 0   # what a caller of the asynchronous forms checks at its synchronisation points
     other.close()
 
 
