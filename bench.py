@@ -316,6 +316,52 @@ def single_call_secondary(ctx, dev, weights):
     return out
 
 
+def graph_secondary(ctx, dev, weights, dbatch, P, pad):
+    """secondary: the same launch sequences replayed as hipGraphs (pv_graph_begin / _end / _launch; BASELINE configs[4] names the
+    technique): one caller's 512-window P1 call (4 kernels), and the fused 16-caller chain (image builder + P1 over 8192
+    windows, 18 launches). Eager and graph wall time per call, back to back on the context's stream."""
+    import torch
+    from pepper_thesis_amd import synth
+    from pepper_thesis_amd.device import DeviceOut
+    out = {}
+    st = ctx.stream
+
+    def timed(fn, reps):
+        fn(); ctx.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            fn()
+        ctx.synchronize()
+        return (time.perf_counter() - t0) / reps * 1e3
+
+    ctx.load_p1(weights)
+    x = torch.from_numpy(synth.synth_windows(3, 512)).to(dev)
+    probs = torch.zeros((512, 3), dtype=torch.float32, device=dev)
+    one = lambda: ctx.forward_p1_dev(x.data_ptr(), 512, probs.data_ptr(), stream=st)
+    eager = timed(one, 50)
+    with ctx.graph_capture(st) as g:
+        one()
+    graph = timed(g.launch, 50)
+    g.close()
+    out["p1_single_call_B512"] = {"eager_ms": eager, "graph_ms": graph, "frac_of_f32_peak_graph": FLOP_PER_WINDOW * 512 / graph / 1e9 / PEAK_F32_TFLOPS}
+    wins = torch.from_numpy(pad).to(dev)
+    dout = DeviceOut(CALLERS * BATCH, CALLERS * BATCH * 16, dev, images=wins)
+    p2 = torch.zeros((CALLERS * BATCH, 3), dtype=torch.float32, device=dev)
+
+    def chain():
+        ctx.summarize_dev(dbatch, P, dout, stream=st)
+        ctx.forward_p1_dev(wins.data_ptr(), CALLERS * BATCH, p2.data_ptr(), stream=st)
+
+    eager = timed(chain, 20)
+    with ctx.graph_capture(st) as g:
+        chain()
+    graph = timed(g.launch, 20)
+    g.close()
+    out["fused_chain_16_callers"] = {"eager_ms": eager, "graph_ms": graph, "windows_per_s_graph": CALLERS * BATCH / graph * 1e3,
+                                     "note": "one batch of 16 regions replayed (the timed headline rotates four batches, eager)"}
+    return out
+
+
 # ------------------------------------------------------------------------------------------------------
 def main(argv=None):
     argv = list(sys.argv[1:] if argv is None else argv)
@@ -646,6 +692,11 @@ def main(argv=None):
                 out["p2_bigru"] = p2_secondary(ctx, dev)
             except Exception as e:
                 out["p2_bigru"] = {"error": repr(e)}
+        if secondary and not args.no_p2:
+            try:
+                out["hipgraph"] = graph_secondary(ctx, dev, weights, dbatch, P, pad)
+            except Exception as e:  # noqa: BLE001
+                out["hipgraph"] = {"error": repr(e)}
         if secondary and not args.no_p2:
             try:
                 from tools import bench_hp

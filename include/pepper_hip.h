@@ -312,6 +312,22 @@ int pv_profile_end(pv_ctx* ctx, char* names_buf, int buf_len, float* ms_sum, int
  * the number of polls that gave up since the last call (0 = every result is good), or a negative PV_ERR_* code. */
 int pv_rnn_exchange_timeouts(pv_ctx* ctx);
 
+/* ---- hipGraph capture of a launch sequence ------------------------------------------------------------------------
+ * Everything the *_dev entry points do is stream work with device-resident state (no host read-back, tags / counters of
+ * the split forms kept on the device), so a sequence of them can be captured once and replayed:
+ *     run the calls once (sizes the workspace)          pv_summarize_regions_dev(...); pv_rnn_forward_p1_dev(...);
+ *     pv_graph_begin(ctx, stream);                       same calls, same pointers: recorded, not run
+ *     pv_graph_end(ctx, &graph);
+ *     per batch: refill the SAME input buffers, then     pv_graph_launch(graph, stream);
+ * `stream` must be a created stream (NULL = the context's own; the legacy null stream cannot capture) and the one the calls
+ * in between are given. A call that would have to grow the workspace inside a capture fails with PV_ERR_STATE. The
+ * reference has no counterpart (its loop is eager PyTorch); BASELINE configs[4] names the technique. */
+typedef struct pv_graph pv_graph;
+int pv_graph_begin(pv_ctx* ctx, void* stream);
+int pv_graph_end(pv_ctx* ctx, pv_graph** graph);
+int pv_graph_launch(pv_graph* graph, void* stream);
+void pv_graph_destroy(pv_graph* graph);
+
 /* bytes of device workspace the context currently holds (diagnostics) */
 int64_t pv_workspace_bytes(pv_ctx* ctx);
 /* library/ABI version: major*10000 + minor*100 + patch */

@@ -177,6 +177,10 @@ SYMBOLS = [
     ("pv_profile_begin", C.c_int, [C.c_void_p]),
     ("pv_profile_end", C.c_int, [C.c_void_p, C.c_char_p, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_int), C.c_int]),
     ("pv_rnn_exchange_timeouts", C.c_int, [C.c_void_p]),
+    ("pv_graph_begin", C.c_int, [C.c_void_p, C.c_void_p]),
+    ("pv_graph_end", C.c_int, [C.c_void_p, C.POINTER(C.c_void_p)]),
+    ("pv_graph_launch", C.c_int, [C.c_void_p, C.c_void_p]),
+    ("pv_graph_destroy", None, [C.c_void_p]),
     ("pv_workspace_bytes", C.c_int64, [C.c_void_p]),
     ("pv_version", C.c_int, []),
 ]

@@ -103,3 +103,54 @@ extern "C" int pv_profile_end(pv_ctx* c, char* names_buf, int buf_len, float* ms
 }
 
 extern "C" int64_t pv_workspace_bytes(pv_ctx* c) { return c ? (int64_t)c->arena.total : 0; }
+
+// ---- hipGraph capture of a sequence of *_dev calls -------------------------------------------------------------------
+struct pv_graph {
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t exec = nullptr;
+    int device = 0;
+};
+
+extern "C" int pv_graph_begin(pv_ctx* c, void* stream) {
+    PV_CHECK(c, PV_ERR_INVALID, "null context");
+    PV_CHECK(!c->arena.frozen, PV_ERR_STATE, "a capture is already open on this context");
+    PV_CHECK(!c->prof.on, PV_ERR_STATE, "per-kernel profiling is on: its events cannot be part of a capture");
+    PV_HIP(hipSetDevice(c->device));
+    hipStream_t st = stream ? (hipStream_t)stream : c->stream;
+    PV_HIP(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+    c->arena.frozen = true;
+    c->capture_stream = st;
+    return PV_OK;
+}
+
+extern "C" int pv_graph_end(pv_ctx* c, pv_graph** out) {
+    PV_CHECK(c && out, PV_ERR_INVALID, "null argument");
+    PV_CHECK(c->arena.frozen, PV_ERR_STATE, "no capture is open on this context");
+    c->arena.frozen = false;
+    hipGraph_t g = nullptr;
+    hipError_t e = hipStreamEndCapture(c->capture_stream, &g);
+    c->capture_stream = nullptr;
+    if (e != hipSuccess || !g) { pv_set_error("hipStreamEndCapture: %s", hipGetErrorString(e)); return PV_ERR_HIP; }
+    hipGraphExec_t x = nullptr;
+    e = hipGraphInstantiate(&x, g, nullptr, nullptr, 0);
+    if (e != hipSuccess) { (void)hipGraphDestroy(g); pv_set_error("hipGraphInstantiate: %s", hipGetErrorString(e)); return PV_ERR_HIP; }
+    pv_graph* pg = new pv_graph();
+    pg->graph = g; pg->exec = x; pg->device = c->device;
+    *out = pg;
+    return PV_OK;
+}
+
+extern "C" int pv_graph_launch(pv_graph* g, void* stream) {
+    PV_CHECK(g && g->exec, PV_ERR_INVALID, "null graph");
+    PV_CHECK(stream, PV_ERR_INVALID, "pv_graph_launch needs the stream to replay on");
+    PV_HIP(hipGraphLaunch(g->exec, (hipStream_t)stream));
+    return PV_OK;
+}
+
+extern "C" void pv_graph_destroy(pv_graph* g) {
+    if (!g) return;
+    (void)hipSetDevice(g->device);
+    if (g->exec) (void)hipGraphExecDestroy(g->exec);
+    if (g->graph) (void)hipGraphDestroy(g->graph);
+    delete g;
+}

@@ -42,10 +42,15 @@ struct pv_arena {
     };
     std::map<std::string, slot> slots;
     size_t total = 0;
+    bool frozen = false;   // a stream capture is open (pv_graph_begin): the workspace must already have its size
 
     int get(const char* name, size_t bytes, void** out) {
         slot& s = slots[name];
         if (bytes > s.bytes) {
+            if (frozen) {
+                pv_set_error("workspace %s would have to grow inside a graph capture: run the same calls once before pv_graph_begin", name);
+                return PV_ERR_STATE;
+            }
             if (s.p) {
                 hipError_t e = hipFree(s.p);  // implicit device sync: only on growth
                 if (e != hipSuccess) { pv_set_error("hipFree(%s): %s", name, hipGetErrorString(e)); return PV_ERR_HIP; }
@@ -97,6 +102,7 @@ struct pv_ctx {
     pv_rnn_p1* p1 = nullptr;
     pv_rnn_p2* p2 = nullptr;
     pv_prof prof;
+    hipStream_t capture_stream = nullptr;   // pv_graph_begin .. pv_graph_end
 };
 
 // RAII bracket: { pv_prof_scope ps(ctx, "k_name", stream); kernel<<<...>>>(...); }

@@ -138,7 +138,9 @@ struct GruArgs {
     // unit-split form only (k_gru_us):
     u32x4* hx;              // [n_tiles][2 dirs][US_HX_QUADS] data-tagged h pairs
     int* quad_flags;        // [n_tiles][4][US_FLAG_STRIDE] layer-boundary counters of the four workgroups of a tile (zeroed per launch)
-    unsigned tag_base;      // tags of this launch run from tag_base + 1
+    unsigned tag_base;      // tags of this launch run from tag_base + 1 (set by the kernel from *epoch)
+    unsigned* epoch;        // device word: launches of the unit-split form so far (bumped by k_gru_bump behind every launch, so a
+                            // replayed hipGraph advances the tags like eager launches do)
     int* err;               // bumped when a bounded poll of the exchange gave up
 };
 
@@ -801,7 +803,11 @@ __device__ __forceinline__ void gru_window_us(const GruArgs& a, int win_start, i
     __syncthreads();   // the window's outputs (global scratch) are read by the next phase (after the hand-off)
 }
 
-__global__ __launch_bounds__(256, 1) void k_gru_us(GruArgs a) {
+__global__ void k_gru_bump(unsigned* epoch) { atomicAdd(epoch, 1u); }
+
+__global__ __launch_bounds__(256, 1) void k_gru_us(GruArgs a_in) {
+    GruArgs a = a_in;
+    a.tag_base = a_in.epoch[0] * 4096u;   // 3800 steps per launch; unsigned wrap-around is harmless (tags are compared for equality)
     extern __shared__ float smem[];
     constexpr int TR = 16;
     float* hbuf = smem;                    // [2][16][LDH]: all 128 units
@@ -974,7 +980,7 @@ template <int TR, bool SPLIT> constexpr size_t lds_p2() { return (size_t)(SPLIT 
 struct pv_rnn_p2 {
     float* enc_wp[4] = {nullptr, nullptr, nullptr, nullptr};  // [0] 32-row tile form, [1] 16-row tile form, [2] 16-row form in [h | x] order (split form), [3] unit-split form
     float* dec_wp[4] = {nullptr, nullptr, nullptr, nullptr};
-    unsigned us_epoch = 0;
+    unsigned* us_epoch = nullptr;   // device word
     int* us_err = nullptr;   // exchange time-outs of the unit-split form (device word)
     const void* us_hx_seen = nullptr; size_t us_hx_n = 0;   // the exchange buffer whose tags belong to this epoch sequence
     float* enc_bias = nullptr; float* dec_bias = nullptr;
@@ -1030,6 +1036,9 @@ extern "C" int pv_rnn_load_p2(pv_ctx* ctx, const pv_weights_p2* w, int dtype) {
     PV_HIP(hipMalloc((void**)&m->us_err, 64));
     m->owned.push_back(m->us_err);
     PV_HIP(hipMemset(m->us_err, 0, 64));
+    PV_HIP(hipMalloc((void**)&m->us_epoch, 64));
+    m->owned.push_back(m->us_epoch);
+    PV_HIP(hipMemset(m->us_epoch, 0, 64));
     if ((rc = up2(w->dense_w, (size_t)NCLS * KPD, &m->dense_w, m->owned)) || (rc = up2(w->dense_b, NCLS, &m->dense_b, m->owned))) return rc;
     PV_HIP(hipFuncSetAttribute((const void*)k_gru_p2<32, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_p2<32, false>()));
     PV_HIP(hipFuncSetAttribute((const void*)k_gru_p2<16, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_p2<16, false>()));
@@ -1065,7 +1074,7 @@ static int p2_launch(pv_ctx* ctx, const uint8_t* d_images, int64_t B, uint8_t* d
     bool split = tr == 16 && 2 * n_tiles <= ctx->num_cu;
     if (const char* e = getenv("PV_GRU_SPLIT")) split = split && atoi(e) != 0;
     g.pair_flags = nullptr;
-    g.hx = nullptr; g.quad_flags = nullptr; g.tag_base = 0; g.err = m->us_err;
+    g.hx = nullptr; g.quad_flags = nullptr; g.tag_base = 0; g.err = m->us_err; g.epoch = nullptr;
     // unit-split form: (tile, direction, half of the units) workgroups with a per-step h exchange, while all of them can be
     // resident at once (up to 1024 chunks on 256 CUs); PV_GRU_USPLIT=0 keeps the direction-split form
     bool usplit = tr == 16 && 4 * n_tiles <= ctx->num_cu;
@@ -1078,16 +1087,18 @@ static int p2_launch(pv_ctx* ctx, const uint8_t* d_images, int64_t B, uint8_t* d
         PV_HIP(hipMemsetAsync(g.quad_flags, 0, nfl * sizeof(int), st));
         const size_t nhx = (size_t)n_tiles * 2 * US_HX_QUADS;
         if ((rc = pv_get(ctx, "p2.hx", nhx, &g.hx))) return rc;
-        // tags are monotonic over launches (4096 per launch): a buffer this sequence has not written yet is cleared, and the
-        // sequence restarts long before it wraps
-        if (m->us_epoch == 0 || m->us_epoch > (1u << 19) || m->us_hx_seen != (const void*)g.hx || m->us_hx_n != nhx) {
+        // tags advance with every launch (4096 per launch, device counter): a buffer this sequence has not written yet is
+        // cleared once (tag 0 is never waited for)
+        if (m->us_hx_seen != (const void*)g.hx || m->us_hx_n != nhx) {
             m->us_hx_seen = g.hx; m->us_hx_n = nhx;
             PV_HIP(hipMemsetAsync(g.hx, 0, nhx * sizeof(u32x4), st));
-            m->us_epoch = 0;
         }
-        g.tag_base = (++m->us_epoch) * 4096u;
-        pv_prof_scope ps(ctx, "k_gru_us", st);
-        k_gru_us<<<(unsigned)(((n_tiles + 7) / 8) * 32), 256, LDS_US, st>>>(g);
+        g.epoch = m->us_epoch;
+        {
+            pv_prof_scope ps(ctx, "k_gru_us", st);
+            k_gru_us<<<(unsigned)(((n_tiles + 7) / 8) * 32), 256, LDS_US, st>>>(g);
+        }
+        k_gru_bump<<<1, 1, 0, st>>>(m->us_epoch);
         PV_HIP(hipGetLastError());
         return PV_OK;
     }

@@ -344,7 +344,8 @@ struct LstmSplitArgs {
     int* flags;           // [n_tiles*2][4 parts][SP_FLAG_STRIDE] (fence form only)
     int64_t B;
     int n_tiles;          // 16-row tiles
-    int flag_base;        // tags of this launch run from flag_base + 1
+    const unsigned* epoch;  // device word, bumped once per forward call by its last kernel (k_head_tail): tags of this launch run
+    int layer;              // from (2 * epoch + layer) * 64 + 1, so a replayed hipGraph advances them like eager launches do
     int* err;             // bumped when a bounded poll of the exchange gave up (a partner workgroup never showed up)
 };
 
@@ -400,6 +401,7 @@ __global__ __launch_bounds__(1024 / SP_NS) void k_lstm_split(LstmSplitArgs a) {
     const int64_t b0 = (int64_t)tile * TR;
     const float* wp = a.wp + ((size_t)((dir * SP_NS + part) * NW + wv) * NTOT) * 2 * 256;
     const float* bias = a.bias + dir * 4 * H;
+    const unsigned flag_base = (a.epoch[0] * 2u + (unsigned)a.layer) * 64u;   // unsigned wrap-around is harmless: tags are compared for equality
     const int unit = UPP * part + 16 * wv + (lane & 15);
     const int rowg = lane >> 4;       // this lane holds rows 4*rowg .. 4*rowg+3 of its unit
 
@@ -481,7 +483,7 @@ __global__ __launch_bounds__(1024 / SP_NS) void k_lstm_split(LstmSplitArgs a) {
         ring_split<0, NKB_X, NTOT>(acc, xbuf, LDX, wr, bq, lane);          // x-part: independent of h_{t-1}
         if (s > 0) {
             // ---- the other three quarters of h_{t-1}: the granules of this thread's twins in the partner workgroups ----
-            const unsigned want = (unsigned)(a.flag_base + s);
+            const unsigned want = flag_base + (unsigned)s;
             const int ps = (s - 1) & 1;
             u32x4 fq[SP_NS - 1][2];
 #ifdef PV_SPLIT_FENCES
@@ -490,7 +492,7 @@ __global__ __launch_bounds__(1024 / SP_NS) void k_lstm_split(LstmSplitArgs a) {
                 for (int k = 1; k < SP_NS; k++) {
                     const int* f = flags_td + ((part + k) % SP_NS) * SP_FLAG_STRIDE;
                     int spins = 0;
-                    while (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (int)want) {
+                    while ((unsigned)__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != want) {
                         __builtin_amdgcn_s_sleep(1);
                         if (++spins > (1 << 24)) break;
                     }
@@ -550,7 +552,7 @@ __global__ __launch_bounds__(1024 / SP_NS) void k_lstm_split(LstmSplitArgs a) {
             hv[i] = og * tanhf_(c);
         }
         if (s + 1 < T_STEPS) {   // the exchange first: it is what the partners wait for
-            const unsigned tag = (unsigned)(a.flag_base + s + 1);
+            const unsigned tag = flag_base + (unsigned)s + 1u;
             // 8-byte stores, one per pair: a 16-byte buffer store with an SGPR soffset has a data hazard on gfx950 that hipcc
             // (ROCm 7.2) does not pad (see k_gemm_bf16x3), and an inline-asm store would hide an entry of the vmcnt queue from
             // the compiler's counted waits on the weight ring
@@ -572,7 +574,7 @@ __global__ __launch_bounds__(1024 / SP_NS) void k_lstm_split(LstmSplitArgs a) {
         if (s + 1 < T_STEPS && tid == 0) {
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __hip_atomic_store(flags_td + part * SP_FLAG_STRIDE, a.flag_base + s + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(flags_td + part * SP_FLAG_STRIDE, (int)(flag_base + (unsigned)s + 1u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
 #else
         lds_barrier();     // LDS tiles (x_{t+1}, own slice of h_t) are complete; nothing in flight is waited for
@@ -670,6 +672,7 @@ struct TailArgs {
     const float* bo;     // [3]
     float* probs;        // [B,3]
     int64_t B;
+    unsigned* epoch;     // the forward-call counter of the unit-split LSTM form: bumped here, by the call's last kernel
 };
 
 // TR = batch rows per workgroup: 32, or 16 when 32-row tiles would leave CUs idle (the tail is a chain of four dependent
@@ -684,6 +687,7 @@ __global__ __launch_bounds__(256, 1) void k_head_tail(TailArgs a) {
     __shared__ float logits[TR][4];
     const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int64_t b0 = (int64_t)blockIdx.x * TR;
+    if (a.epoch && blockIdx.x == 0 && tid == 0) atomicAdd(a.epoch, 1u);   // both LSTM kernels of this call are done (stream order)
     // y0 = selu(sum of slabs + b1)   (simple_model.py:57-59)
     for (int i = tid; i < TR * HEAD_N; i += 256) {
         const int row = i / HEAD_N, n = i - row * HEAD_N;
@@ -1128,7 +1132,7 @@ struct pv_rnn_p1 {
     float* dec_wps[2] = {nullptr, nullptr};
     u32x4* sp_hx = nullptr; int* sp_flags = nullptr;       // its exchange buffer (tagged granules) and counters (fence form)
     int* sp_err = nullptr;                                 // exchange time-outs (device word, read by the host-buffer entry points)
-    int sp_epoch = 0;
+    unsigned* sp_epoch = nullptr;                          // device word: forward calls so far (tags of the exchange derive from it)
     float* w1p = nullptr; float* b1 = nullptr;
     float* wlp[2][4] = {{nullptr, nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr, nullptr}};  // [tile form][layer]
     float* bl[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -1240,6 +1244,9 @@ extern "C" int pv_rnn_load_p1(pv_ctx* ctx, const pv_weights_p1* w, int dtype) {
         PV_HIP(hipMalloc((void**)&m->sp_err, 64));
         m->owned.push_back(m->sp_err);
         PV_HIP(hipMemset(m->sp_err, 0, 64));
+        PV_HIP(hipMalloc((void**)&m->sp_epoch, 64));
+        m->owned.push_back(m->sp_epoch);
+        PV_HIP(hipMemset(m->sp_epoch, 0, 64));
     }
     pack_linear(w->linear_w[0], HEAD_K, 32, wp);
     if ((rc = dev_upload(wp, &m->w1p, m->owned)) || (rc = dev_upload(w->linear_b[0], HEAD_N, &m->b1, m->owned))) return rc;
@@ -1324,13 +1331,8 @@ static int p1_forward_launch(pv_ctx* ctx, const int8_t* d_images, int64_t B, flo
     LstmSplitArgs se;
     const unsigned split_grid = (unsigned)(((n_t16 + 3) / 4) * 8 * sp_ns);
     if (split) {
-        if (m->sp_epoch > (1 << 23)) {   // tags / counters are monotonic over launches: restart them long before they overflow
-            PV_HIP(hipMemsetAsync(m->sp_flags, 0, (size_t)SP_MAX_TILES * 2 * 4 * SP_FLAG_STRIDE * sizeof(int), st));
-            PV_HIP(hipMemsetAsync(m->sp_hx, 0, (size_t)SP_MAX_TILES * 2 * SP_HX_QUADS * sizeof(u32x4), st));
-            m->sp_epoch = 0;
-        }
         se.x_i8 = d_images; se.x_f32 = nullptr; se.wp = m->enc_wps[sp_ns == 4 ? 0 : 1]; se.bias = m->enc_bias; se.out = enc_out;
-        se.hx = m->sp_hx; se.flags = m->sp_flags; se.B = B; se.n_tiles = n_t16; se.flag_base = (m->sp_epoch++) * 64;
+        se.hx = m->sp_hx; se.flags = m->sp_flags; se.B = B; se.n_tiles = n_t16; se.epoch = m->sp_epoch; se.layer = 0;
         se.err = m->sp_err;
         pv_prof_scope ps(ctx, "k_lstm_split_enc", st);
         if (sp_ns == 4) k_lstm_split<32, true, 4><<<split_grid, 256, lds_lstm_split<32>(), st>>>(se);
@@ -1377,7 +1379,7 @@ static int p1_forward_launch(pv_ctx* ctx, const int8_t* d_images, int64_t B, flo
         }
         TailArgs tb;
         tb.part = part; tb.b1 = m->b1; tb.splits = gs; tb.part_rows = Bp;
-        tb.wo = m->wo; tb.bo = m->bo; tb.probs = d_probs; tb.B = B;
+        tb.wo = m->wo; tb.bo = m->bo; tb.probs = d_probs; tb.B = B; tb.epoch = m->sp_epoch;
         launch_tail(ctx, m, tb, n_tiles, st);
         PV_HIP(hipGetLastError());
         return PV_OK;
@@ -1387,7 +1389,7 @@ static int p1_forward_launch(pv_ctx* ctx, const int8_t* d_images, int64_t B, flo
     if (split) {
         LstmSplitArgs sd = se;
         sd.x_i8 = nullptr; sd.x_f32 = enc_out; sd.wp = m->dec_wps[sp_ns == 4 ? 0 : 1]; sd.bias = m->dec_bias; sd.out = dec_out;
-        sd.flag_base = (m->sp_epoch++) * 64;
+        sd.layer = 1;
         pv_prof_scope ps(ctx, "k_lstm_split_dec", st);
         if (sp_ns == 4) k_lstm_split<512, false, 4><<<split_grid, 256, lds_lstm_split<512>(), st>>>(sd);
         else k_lstm_split<512, false, 2><<<split_grid, 512, lds_lstm_split<512>(), st>>>(sd);
@@ -1408,7 +1410,7 @@ static int p1_forward_launch(pv_ctx* ctx, const int8_t* d_images, int64_t B, flo
     { pv_prof_scope ps(ctx, "k_head_splitk", st); k_head_splitk<<<head_grid, 256, LDS_SPLITK, st>>>(h); }
     TailArgs t;
     t.part = part; t.b1 = m->b1; t.splits = splits; t.part_rows = B;
-    t.wo = m->wo; t.bo = m->bo; t.probs = d_probs; t.B = B;
+    t.wo = m->wo; t.bo = m->bo; t.probs = d_probs; t.B = B; t.epoch = m->sp_epoch;
     launch_tail(ctx, m, t, n_tiles, st);
     PV_HIP(hipGetLastError());
     return PV_OK;

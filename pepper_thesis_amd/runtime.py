@@ -21,6 +21,33 @@ def _dir_struct(w, prefix, suffix, keep):
     return d
 
 
+class _GraphCapture:
+    def __init__(self, ctx, stream):
+        self.ctx, self.stream, self.handle = ctx, int(stream or ctx.stream), None
+
+    def __enter__(self):
+        _ffi.check(self.ctx.lib.pv_graph_begin(self.ctx.handle, self.stream))
+        return self
+
+    def __exit__(self, et, ev, tb):
+        h = C.c_void_p()
+        rc = self.ctx.lib.pv_graph_end(self.ctx.handle, C.byref(h))
+        if et is None:
+            _ffi.check(rc)
+            self.handle = h
+        elif rc == 0:
+            self.ctx.lib.pv_graph_destroy(h)
+        return False
+
+    def launch(self, stream: int = 0):
+        _ffi.check(self.ctx.lib.pv_graph_launch(self.handle, int(stream or self.stream)))
+
+    def close(self):
+        if self.handle:
+            self.ctx.lib.pv_graph_destroy(self.handle)
+            self.handle = None
+
+
 class Context:
     """pv_create / pv_destroy with the reference operators as methods."""
 
@@ -49,6 +76,12 @@ class Context:
 
     def synchronize(self):
         _ffi.check(self.lib.pv_synchronize(self.handle))
+
+    def graph_capture(self, stream: int = 0):
+        """context manager: the *_dev calls made inside (with this stream) are recorded into a hipGraph instead of run;
+        `with ctx.graph_capture(s) as g: ...` then `g.launch()` per batch after refilling the same input buffers.
+        Run the same calls once eagerly before (the workspace cannot grow inside a capture)."""
+        return _GraphCapture(self, stream)
 
     def exchange_timeouts(self) -> int:
         """polls of the split kernel forms that gave up since the last call (synchronises; 0 = all results good)"""
