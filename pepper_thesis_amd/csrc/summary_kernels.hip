@@ -591,6 +591,18 @@ __global__ __launch_bounds__(PT_THREADS) void k_pileup_tiles(SumArgs a) {
                             else if (s_lut[refb] & 32) atomicAdd(&s_cnt[HL_M + 2 * (ss - 1) + st][SW(lc)], 1);
                         } else {
                         const int st = g[u].fl;
+                        // the usual base - A/C/G/T in upper case over an A/C/G/T reference (either case) - is classified
+                        // arithmetically: no table reads (two dependent LDS round trips per base) and one short masked region
+                        const unsigned tb = (unsigned)base - 0x41u, tr = ((unsigned)refb & 0xDFu) - 0x41u;
+                        const bool b_up = tb < 20u && ((0x80045u >> tb) & 1u);           // 'A' 'C' 'G' 'T': bits 0, 2, 6, 19
+                        const bool r_ok = tr < 20u && ((0x80045u >> tr) & 1u);           // A C G T a c g t
+                        if (b_up && r_ok) {
+                            const unsigned x = ((unsigned)base >> 1) & 3u;               // A 0, C 1, T 2, G 3
+                            atomicAdd(&s_cnt[L_P + 4 * st + (int)(x ^ (x >> 1))][SW(lc)], 1);   // -> A 0, C 1, G 2, T 3
+                            if (e == g[u].last) atomicAdd(&s_cnt[L_ANC + st][SW(lc)], 1);
+                            if (refb != base) atomicAdd(&s_cnt[L_SNP][SW(lc)], 1);       // raw bytes, :394 (never rare: both are A/C/G/T)
+                            continue;
+                        }
                         const int cb = s_lut[base];
                         const bool refvalid = (s_lut[refb] & 32) != 0;
                         const int sy = cb & 7;                                           // 1..7
