@@ -325,7 +325,7 @@ enum {
 };
 
 template <bool HP>
-__global__ __launch_bounds__(PT_THREADS) void k_pileup_tiles(SumArgs a) {
+__global__ __launch_bounds__(PT_THREADS, HP ? 2 : 4) void k_pileup_tiles(SumArgs a) {   // 26-plane form: two workgroups per CU (<= 128 VGPRs)
     __shared__ int32_t s_cnt[HP ? (int)HL_N : (int)L_N][TILE_COLS];
     __shared__ uint8_t s_ref[TILE_COLS + 4];  // the tile's reference bytes (+4: a padded group may look past the tile)
     __shared__ uint8_t s_lut[256];           // byte class: bits0-2 plane symbol 1..7, 8 = upper ACGT, 16 = lower acgt, 32 = valid reference
@@ -376,6 +376,26 @@ __global__ __launch_bounds__(PT_THREADS) void k_pileup_tiles(SumArgs a) {
         __syncthreads();
         const int total_ops = p_off[npb];
         PSTAMP(0)  // pair batch
+        // the four words of an op (start column, CIGAR word, read offset, next CIGAR word) are requested one op batch AHEAD:
+        // the batch's first phase is otherwise a chain of dependent round trips (pair lookup -> op words -> indel qualities)
+        struct OpWords { int pslot; int32_t c, c_last, rr, rdv; uint32_t w, wn; };
+        auto op_fetch = [&](int kk) {
+            OpWords o;
+            o.pslot = 0; o.c = 0; o.c_last = 0; o.rr = OP_INACTIVE; o.rdv = 0; o.w = 15u; o.wn = 15u;
+            if (kk < total_ops) {
+                int lo = 0, hi = npb;  // last pair slot with p_off[slot] <= kk
+                while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (p_off[mid] <= kk) lo = mid; else hi = mid; }
+                o.pslot = lo;
+                o.c = p_oplo[lo] + (kk - p_off[lo]);
+                o.c_last = p_clast[lo];
+                o.rr = a.op_ref[o.c];
+                o.w = a.in.cigar[o.c];
+                o.rdv = a.op_rd[o.c];
+                o.wn = a.in.cigar[o.c < o.c_last ? o.c + 1 : o.c];
+            }
+            return o;
+        };
+        OpWords ow_next = op_fetch(tid);
         for (int ob = 0; ob < total_ops; ob += PT_THREADS) {
             // ---- op batch: one thread per op -----------------------------------------------------------
             const int k = ob + tid;
@@ -384,16 +404,16 @@ __global__ __launch_bounds__(PT_THREADS) void k_pileup_tiles(SumArgs a) {
             int pslot = 0, hpbits = 0;  // hpbits: bits 0-1 count sets, bits 2-3 symbol sets (haplotag form only)
             int32_t c = 0;
             int64_t clo = 0, chi = -1;
+            const OpWords ow = ow_next;
+            if (ob + PT_THREADS < total_ops) ow_next = op_fetch(k + PT_THREADS);
             if (k < total_ops) {
-                int lo = 0, hi = npb;  // last pair slot with p_off[slot] <= k
-                while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (p_off[mid] <= k) lo = mid; else hi = mid; }
-                pslot = lo;
-                c = p_oplo[pslot] + (k - p_off[pslot]);
-                const int32_t c_last = p_clast[pslot];
-                const int32_t rr = a.op_ref[c];
-                const uint32_t w = a.in.cigar[c];
-                const int32_t rdv = a.op_rd[c];
-                const uint32_t wn = a.in.cigar[c < c_last ? c + 1 : c];
+                pslot = ow.pslot;
+                c = ow.c;
+                const int32_t c_last = ow.c_last;
+                const int32_t rr = ow.rr;
+                const uint32_t w = ow.w;
+                const int32_t rdv = ow.rdv;
+                const uint32_t wn = ow.wn;
                 col_base = p_colbase[pslot];
                 rev = (p_rev[pslot] & 1) != 0;
                 hpbits = p_rev[pslot] >> 1;
