@@ -1,3 +1,4 @@
+# A/B of diagnostic library builds (variants/libpepper_hip_<name>.so, see build.build_variant) on tools/bench_single.py; run through gpurun
 set -e
 cd $GRAFT_REPO_ROOT
 for v in default; do
