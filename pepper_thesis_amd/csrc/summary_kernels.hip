@@ -20,7 +20,7 @@
 //   k_site_scan      thread per column: frequency thresholds -> site flags, per-block site counts
 //   k_scan_*         single-block exclusive scans (tiny arrays)
 //   k_site_rank      column -> site rank, site list, per-site event bucket sizes
-//   k_collect        lane per op: second walk over the CIGAR stream only; allele events of SITES
+//   k_collect        wave per site, lane per overlapping read: the read's ops at that column by binary search; allele events
 //   k_site_alleles   wave per site: dedupe + order alleles like std::set<std::string>, filters
 //   k_write_windows  wave per site: gather 33x26, clamp, overlays, int8 cast, metadata, keys
 //
@@ -887,71 +887,77 @@ __device__ __forceinline__ void push_event(const SumArgs& a, int32_t s, int64_t 
     a.ev[(int64_t)a.site_evoff[s] + slot] = e;
 }
 
-// One WORKGROUP per read: everything that is a property of the read (region, strand, base range) is read once per wave
-// from the same addresses, a thread needs three coalesced loads per op (CIGAR word, start column, read offset) instead
-// of the thirteen dependent ones a thread-per-op walk through op -> read -> region costs, and no per-op read index exists.
-__global__ __launch_bounds__(256) void k_collect(SumArgs a) {
+// One WAVE per SITE, one lane per (read, tile) pair of the site's tile: the allele observations a read contributes at that
+// column. Sites are ~1 column in 200, so walking the CIGAR stream a second time (a workgroup per read, five loads per op,
+// 20 M ops per launch) spent nearly all its loads on ops that touch no site; here a lane finds the read's ops at the site
+// column with one binary search over the pair's op range (start columns are sorted), 8 k sites x ~70 reads x 7 steps.
+//   ops that START right behind the column and are inserts / deletes anchor on it (op_flag: counted by k_pileup_tiles);
+//   the aligned op that contains the column gives the read's base there (rare observations only, or - haplotag form - every
+//   mismatch).
+__global__ __launch_bounds__(64) void k_collect(SumArgs a) {
     const int lane = threadIdx.x;
-    const int64_t r = blockIdx.x;
-    if (r >= a.n_reads || a.diag[D_STATUS] != 0) return;
-    if (a.read_t1[r] < a.read_t0[r]) return;   // mapq 0 or outside the region: every op is inactive
-    const int g = a.read_region[r];
-    const int64_t col_base = a.in.ref_off[g];
-    const int64_t ref_len = a.in.ref_off[g + 1] - col_base;
-    const int64_t R = a.in.ref_end[g] - a.in.ref_start[g] + 1;
-    const int64_t base0 = a.in.base_off[r], seq_end = a.in.base_off[r + 1];
-    const bool rev = (a.in.read_flags[r] & 1) != 0;
-    int obs = 1;  // flags of an allele observation
-    if (a.hp) {   // region_summary_hp.cpp:415-422: "hp_tag == 0 || hp_tag == k" joins set k
-        const int32_t tag = a.read_hp ? a.read_hp[r] : 0;
-        obs |= (((tag == 0 || tag == 1) ? 1 : 0) | ((tag == 0 || tag == 2) ? 2 : 0)) << 2;
-    }
-    const int64_t c0 = a.in.cigar_off[r], c1 = a.in.cigar_off[r + 1];
-    for (int64_t c = c0 + lane; c < c1; c += 256) {
-        const int32_t ref_rel = a.op_ref[c];
-        if (ref_rel == OP_INACTIVE) continue;
-        const uint32_t w = a.in.cigar[c];
-        const int op = w & 0xF;
-        const int32_t len = (int32_t)(w >> 4);
-        if (op == PV_CIGAR_IN) {
-            if (!a.op_flag[c]) continue;
-            const int64_t col = col_base + ref_rel - 1;
-            if (a.flags[col] & 1) push_event(a, a.site_rank[col], base0 + a.op_rd[c] - 1, len + 1, 2, rev, 1, obs);
-        } else if (op == PV_CIGAR_DEL) {
-            if (!a.op_flag[c]) continue;
-            const int64_t anchor = (int64_t)ref_rel - 1;
-            const int64_t col = col_base + anchor;
-            int64_t L = (int64_t)len + 1;
-            if (anchor + L > ref_len) L = ref_len - anchor;
-            if (a.flags[col] & 1) push_event(a, a.site_rank[col], col, (int32_t)L, 3, rev, 2, obs);
-        } else if (op == PV_CIGAR_MATCH || op == PV_CIGAR_EQUAL || op == PV_CIGAR_DIFF) {
-            int64_t lo = ref_rel < 0 ? -(int64_t)ref_rel : 0;
-            int64_t hi = R - ref_rel;
-            if (hi > len) hi = len;
-            if (hi <= lo) continue;
-            const int64_t ca = col_base + ref_rel + lo;      // first column
-            const int64_t cb = col_base + ref_rel + hi - 1;  // last column
-            const int32_t s0 = a.site_rank[ca];
-            const int32_t s1 = a.site_rank[cb] + (a.flags[cb] & 1);
-            if (s1 <= s0) continue;
-            const int64_t rd = a.op_rd[c];
-            for (int32_t s = s0; s < s1; s++) {
-                const int64_t col = a.site_col[s];
-                if (a.cnt[(a.hp ? C_SNP : C_RARE) * a.n_cols + col] == 0) continue;
-                const int64_t i = col - (col_base + ref_rel);
-                const int64_t bi = base0 + rd + i;
-                if (bi >= seq_end) continue;  // already reported by k_pileup
-                const int base = a.in.bases[bi];
-                if (!((double)a.in.quals[bi] >= a.p.min_snp_baseq)) continue;
-                const int refb = a.in.ref[col];
-                if (a.hp) {  // every mismatch (raw bytes, region_summary_hp.cpp:406) is an allele observation
-                    if (refb != base) push_event(a, s, bi, 1, 1, rev, 1, obs);
+    if (a.diag[D_STATUS] != 0) return;
+    int64_t n_sites = a.diag[D_NSITES];
+    if (n_sites > a.max_sites) n_sites = a.max_sites;
+    const int64_t NC = a.n_cols;
+    for (int64_t s = blockIdx.x; s < n_sites; s += gridDim.x) {
+        const int64_t col = a.site_col[s];
+        const int g = a.site_region[s];
+        const int64_t col_base = a.in.ref_off[g];
+        const int32_t col_rel = (int32_t)(col - col_base);
+        const bool need_base = a.cnt[(a.hp ? C_SNP : C_RARE) * NC + col] != 0;
+        const int refb = a.in.ref[col];
+        const int64_t t = col / TILE_COLS;
+        const int32_t p0 = a.tile_off[t], np = a.tile_cnt[t];
+        for (int32_t pb = 0; pb < np; pb += 64) {
+            if (pb + lane >= np) continue;
+            const PairRec pr = a.pairs[p0 + pb + lane];
+            if (pr.col_base != (int32_t)col_base) continue;   // a tile can hold the end of one region and the start of the next
+            const bool rev = (pr.rev & 1) != 0;
+            int obs = 1;  // flags of an allele observation
+            if (a.hp) obs |= ((pr.rev >> 1) & 3) << 2;         // count sets of the read (k_tile_fill)
+            // first op of the pair's range that starts behind the column
+            int32_t lo = pr.op_lo, hi = pr.op_hi;
+            while (lo < hi) { const int32_t mid = (lo + hi) >> 1; if (a.op_ref[mid] <= col_rel) lo = mid + 1; else hi = mid; }
+            const int32_t f = lo;
+            for (int32_t o = f; o < pr.op_hi; o++) {            // inserts / deletes anchored on the column
+                if (a.op_ref[o] != col_rel + 1) break;
+                const uint32_t w = a.in.cigar[o];
+                const int op = w & 0xF;
+                const int32_t len = (int32_t)(w >> 4);
+                if (op == PV_CIGAR_IN) {
+                    if (a.op_flag[o]) push_event(a, (int32_t)s, pr.base0 + a.op_rd[o] - 1, len + 1, 2, rev, 1, obs);
+                } else if (op == PV_CIGAR_DEL) {
+                    int64_t L = (int64_t)len + 1;
+                    if ((int64_t)col_rel + L > pr.ref_len) L = pr.ref_len - col_rel;
+                    if (a.op_flag[o]) push_event(a, (int32_t)s, col, (int32_t)L, 3, rev, 2, obs);
+                }
+            }
+            if (!need_base) continue;
+            for (int32_t o = f - 1; o >= pr.op_lo; o--) {       // the op that holds the column, skipping ops that consume no reference
+                const uint32_t w = a.in.cigar[o];
+                const int op = w & 0xF;
+                const bool aligned = op == PV_CIGAR_MATCH || op == PV_CIGAR_EQUAL || op == PV_CIGAR_DIFF;
+                if (!aligned) {
+                    if (op == PV_CIGAR_DEL || op == PV_CIGAR_REF_SKIP || op == PV_CIGAR_PAD) break;   // the column lies in a gap of this read
                     continue;
+                }
+                const int32_t rr = a.op_ref[o];
+                const int64_t i = (int64_t)col_rel - rr;
+                if (rr == OP_INACTIVE || i < 0 || i >= (int64_t)(w >> 4)) break;
+                const int64_t bi = pr.base0 + a.op_rd[o] + i;
+                if (bi >= pr.seq_end) break;  // already reported by k_pileup
+                const int base = a.in.bases[bi];
+                if (!((double)a.in.quals[bi] >= a.p.min_snp_baseq)) break;
+                if (a.hp) {  // every mismatch (raw bytes, region_summary_hp.cpp:406) is an allele observation
+                    if (refb != base) push_event(a, (int32_t)s, bi, 1, 1, rev, 1, obs);
+                    break;
                 }
                 const bool refvalid = is_acgt(up(refb));
                 const bool rare = (refb != base) && !(refvalid && is_acgt(base));
                 const bool corr = refvalid && base != up(base) && is_acgt(up(base));
-                if (rare || corr) push_event(a, s, bi, 1, 1, rev, 1, (rare ? 1 : 0) | (corr ? 2 : 0));
+                if (rare || corr) push_event(a, (int32_t)s, bi, 1, 1, rev, 1, (rare ? 1 : 0) | (corr ? 2 : 0));
+                break;
             }
         }
     }
@@ -1703,8 +1709,8 @@ static int summarize_launch(pv_ctx* ctx, const pv_batch_in* in, const pv_params*
     k_scan_blocks<<<1, 1024, 0, st>>>(a, n_blk);
     k_site_rank<<<(unsigned)n_blk, 1024, 0, st>>>(a);
     k_scan_events<<<1, 1024, 0, st>>>(a);
-    if (n_cigar > 0 && n_reads > 0) { pv_prof_scope ps(ctx, "k_collect", st); k_collect<<<(unsigned)n_reads, 256, 0, st>>>(a); }
     const unsigned site_grid = (unsigned)(max_sites < 4096 ? (max_sites > 0 ? max_sites : 1) : 4096);
+    if (n_cigar > 0 && n_reads > 0) { pv_prof_scope ps(ctx, "k_collect", st); k_collect<<<site_grid, 64, 0, st>>>(a); }
     {
         pv_prof_scope ps(ctx, "k_site_alleles", st);
         if (hp) k_site_alleles<true><<<site_grid, 64, 0, st>>>(a);
