@@ -42,6 +42,7 @@ constexpr int C_COV = 0, C_SNP = 1, C_INS = 2, C_DEL = 3, C_RARE = 4, C_PLANE = 
 constexpr int NCNT_HP = 36, HC_PLANE = 4;
 constexpr int32_t OP_INACTIVE = 0x7fffffff;
 constexpr int UMAX = 1024;  // distinct alleles per site held in LDS
+constexpr int UM_SMALL = 96; // table of the k_site_alleles instantiation for sites with few events
 constexpr int TILE_COLS = 512;  // columns per pileup tile (one workgroup accumulates a tile in LDS)
 
 enum { D_NSITES = 0, D_NEVENTS = 1, D_NOUT = 2, D_STRBYTES = 3, D_STATUS = 4, D_NPAIRS = 5, D_NINS = 6, D_NROWS = 7, D_NCHUNKS = 8, D_NDIAG = 10 };
@@ -972,11 +973,22 @@ struct Key {
 __device__ __forceinline__ int key_byte(const SumArgs& a, const Key& k, int i) {
     return k.kind == 0 ? k.imm : (k.kind == 1 ? a.in.bases[k.src + i] : a.in.ref[k.src + i]);
 }
-// std::string compare of "<type digit><bytes>"
-__device__ __forceinline__ int key_cmp(const SumArgs& a, const Key& x, const Key& y) {
+// the first (up to) 8 bytes of a key, big-endian and zero-padded, so that integer order is byte order: fetched ONCE per
+// allele; nearly every comparison (SNP keys are one byte, most indels a few) is then decided in registers / LDS instead of
+// with dependent byte loads from the bases / reference
+__device__ __forceinline__ uint64_t key_prefix(const SumArgs& a, const Key& k) {
+    uint64_t p = 0;
+    const int n = k.len < 8 ? k.len : 8;
+    for (int i = 0; i < n; i++) p |= (uint64_t)(uint8_t)key_byte(a, k, i) << (56 - 8 * i);
+    return p;
+}
+// std::string compare of "<type digit><bytes>" given the prefixes: equal prefixes mean the first min(len, 8) bytes agree
+// (where a zero byte meets padding the shorter key is a prefix of the longer, which the length rule orders the same way)
+__device__ __forceinline__ int key_cmp(const SumArgs& a, const Key& x, uint64_t px, const Key& y, uint64_t py) {
     if (x.type != y.type) return x.type < y.type ? -1 : 1;
+    if (px != py) return px < py ? -1 : 1;
     const int m = x.len < y.len ? x.len : y.len;
-    for (int i = 0; i < m; i++) {
+    for (int i = 8; i < m; i++) {
         const int bx = key_byte(a, x, i), by = key_byte(a, y, i);
         if (bx != by) return bx < by ? -1 : 1;
     }
@@ -986,24 +998,30 @@ __device__ __forceinline__ int key_cmp(const SumArgs& a, const Key& x, const Key
 
 // HP: the haplotag form keeps four per-strand counts per allele (forward / reverse x haplotype set 1 / 2,
 // region_summary_hp.cpp:415-447) next to the total, and no allele count comes from the planes.
-template <bool HP>
+// UM = alleles the LDS table of a wave holds. The table is what limits the waves per CU (1024 entries are 34 KB: four waves
+// per CU, one per SIMD, and a site is a chain of dependent loads), while a site can never hold more distinct alleles than it
+// has events + 4: sites with few events (all but the deepest) run in the instantiation with a UM_SMALL-entry table, BIG = the
+// others.
+template <bool HP, int UM, bool BIG>
 __global__ __launch_bounds__(64) void k_site_alleles(SumArgs a) {
-    __shared__ int64_t u_src[UMAX];
-    __shared__ int32_t u_len[UMAX];
-    __shared__ int32_t u_fwd[UMAX];   // HP: total observations
-    __shared__ int32_t u_rev[UMAX];   // HP: unused (0), so that u_fwd + u_rev is the total in both forms
-    __shared__ int32_t u_hc[HP ? 4 : 1][HP ? UMAX : 1];  // HP: forward set 1, forward set 2, reverse set 1, reverse set 2
-    __shared__ uint8_t u_type[UMAX];
-    __shared__ uint8_t u_kind[UMAX];
-    __shared__ uint8_t u_imm[UMAX];
-    __shared__ uint8_t u_ok[UMAX];
-    __shared__ int16_t u_order[UMAX];
+    __shared__ int64_t u_src[UM];
+    __shared__ uint64_t u_pre[UM];  // key_prefix of the allele
+    __shared__ int32_t u_len[UM];
+    __shared__ int32_t u_fwd[UM];   // HP: total observations
+    __shared__ int32_t u_rev[UM];   // HP: unused (0), so that u_fwd + u_rev is the total in both forms
+    __shared__ int32_t u_hc[HP ? 4 : 1][HP ? UM : 1];  // HP: forward set 1, forward set 2, reverse set 1, reverse set 2
+    __shared__ uint8_t u_type[UM];
+    __shared__ uint8_t u_kind[UM];
+    __shared__ uint8_t u_imm[UM];
+    __shared__ uint8_t u_ok[UM];
+    __shared__ int16_t u_order[UM];
     __shared__ int32_t s_nU;
     const int lane = threadIdx.x;
     if (a.diag[D_STATUS] != 0) return;
     int64_t n_sites = a.diag[D_NSITES];
     if (n_sites > a.max_sites) n_sites = a.max_sites;
     for (int64_t s = blockIdx.x; s < n_sites; s += gridDim.x) {
+        if ((a.site_nev[s] + 4 > UM_SMALL) != BIG) continue;   // the other instantiation's site
         const int64_t col = a.site_col[s];
         const int64_t NC = a.n_cols;
         const int f = a.flags[col];
@@ -1016,6 +1034,7 @@ __global__ __launch_bounds__(64) void k_site_alleles(SumArgs a) {
         if (!HP && lane < 4) {
             const int b = "ACGT"[lane];
             u_src[lane] = 0; u_len[lane] = 1; u_type[lane] = 1; u_kind[lane] = 0; u_imm[lane] = (uint8_t)b;
+            u_pre[lane] = (uint64_t)(uint8_t)b << 56;
             const bool ok = refvalid && b != refraw;
             u_ok[lane] = ok;
             u_fwd[lane] = ok ? -a.cnt[(C_PLANE + 1 + lane) * NC + col] : 0;
@@ -1037,6 +1056,7 @@ __global__ __launch_bounds__(64) void k_site_alleles(SumArgs a) {
             }
             bool pending = have && (e.flags & 1);
             Key ke; ke.src = e.src; ke.len = e.len; ke.type = e.type; ke.kind = e.kind; ke.imm = 0;
+            const uint64_t pe = pending ? key_prefix(a, ke) : 0;
             int checked = HP ? 0 : 4;  // slots 0..3 can never equal an event key (see k_pileup: those are not events)
             [[maybe_unused]] const int hs = (e.flags >> 2) & 3, hst = e.rev ? 2 : 0;
             while (true) {
@@ -1044,7 +1064,7 @@ __global__ __launch_bounds__(64) void k_site_alleles(SumArgs a) {
                 if (pending) {
                     for (int k = checked; k < nU; k++) {
                         Key ku; ku.src = u_src[k]; ku.len = u_len[k]; ku.type = u_type[k]; ku.kind = u_kind[k]; ku.imm = u_imm[k];
-                        if (ku.type == ke.type && ku.len == ke.len && key_cmp(a, ku, ke) == 0) {
+                        if (ku.type == ke.type && ku.len == ke.len && u_pre[k] == pe && key_cmp(a, ku, pe, ke, pe) == 0) {
                             if constexpr (HP) {
                                 atomicAdd(&u_fwd[k], 1);
                                 if (hs & 1) atomicAdd(&u_hc[hst + 0][k], 1);
@@ -1061,8 +1081,9 @@ __global__ __launch_bounds__(64) void k_site_alleles(SumArgs a) {
                 if (m == 0) break;
                 const int leader = __ffsll((long long)m) - 1;
                 if (lane == leader) {
-                    if (nU < UMAX) {
+                    if (nU < UM) {
                         u_src[nU] = ke.src; u_len[nU] = ke.len; u_type[nU] = ke.type; u_kind[nU] = ke.kind; u_imm[nU] = 0;
+                        u_pre[nU] = pe;
                         if constexpr (HP) {
                             u_ok[nU] = 1; u_fwd[nU] = 1; u_rev[nU] = 0;
                             u_hc[0][nU] = (!e.rev && (hs & 1)) ? 1 : 0; u_hc[1][nU] = (!e.rev && (hs & 2)) ? 1 : 0;
@@ -1089,11 +1110,12 @@ __global__ __launch_bounds__(64) void k_site_alleles(SumArgs a) {
             const bool live = k < nU && u_ok[k] && (u_fwd[k] + u_rev[k]) > 0;
             if (live) {
                 Key kk; kk.src = u_src[k]; kk.len = u_len[k]; kk.type = u_type[k]; kk.kind = u_kind[k]; kk.imm = u_imm[k];
+                const uint64_t pk = u_pre[k];
                 int rank = 0;
                 for (int j = 0; j < nU; j++) {
                     if (j == k || !u_ok[j] || (u_fwd[j] + u_rev[j]) <= 0) continue;
                     Key kj; kj.src = u_src[j]; kj.len = u_len[j]; kj.type = u_type[j]; kj.kind = u_kind[j]; kj.imm = u_imm[j];
-                    if (key_cmp(a, kj, kk) < 0) rank++;
+                    if (key_cmp(a, kj, u_pre[j], kk, pk) < 0) rank++;
                 }
                 u_order[rank] = (int16_t)k;
             }
@@ -1713,8 +1735,14 @@ static int summarize_launch(pv_ctx* ctx, const pv_batch_in* in, const pv_params*
     if (n_cigar > 0 && n_reads > 0) { pv_prof_scope ps(ctx, "k_collect", st); k_collect<<<site_grid, 64, 0, st>>>(a); }
     {
         pv_prof_scope ps(ctx, "k_site_alleles", st);
-        if (hp) k_site_alleles<true><<<site_grid, 64, 0, st>>>(a);
-        else k_site_alleles<false><<<site_grid, 64, 0, st>>>(a);
+        const unsigned big_grid = site_grid < 1024 ? site_grid : 1024;
+        if (hp) {
+            k_site_alleles<true, UM_SMALL, false><<<site_grid, 64, 0, st>>>(a);
+            k_site_alleles<true, UMAX, true><<<big_grid, 64, 0, st>>>(a);
+        } else {
+            k_site_alleles<false, UM_SMALL, false><<<site_grid, 64, 0, st>>>(a);
+            k_site_alleles<false, UMAX, true><<<big_grid, 64, 0, st>>>(a);
+        }
     }
     k_scan_outputs<<<1, 1024, 0, st>>>(a);
     {
