@@ -159,6 +159,10 @@ __device__ __forceinline__ int upper_bound_i64(const int64_t* a, int n, int64_t 
     return lo;
 }
 
+__device__ __forceinline__ int64_t last_lane(int64_t v) {   // lane 63's value in every lane (scalar reads, no LDS permute)
+    const unsigned lo = __builtin_amdgcn_readlane((unsigned)v, 63), hi = __builtin_amdgcn_readlane((unsigned)((uint64_t)v >> 32), 63);
+    return (int64_t)(((uint64_t)hi << 32) | lo);
+}
 __device__ __forceinline__ int64_t wave_incl_scan(int64_t v, int lane) {
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) {
@@ -167,13 +171,17 @@ __device__ __forceinline__ int64_t wave_incl_scan(int64_t v, int lane) {
     }
     return v;
 }
-__device__ __forceinline__ int wave_incl_scan32(int v, int lane) {
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        int t = __shfl_up(v, d, 64);
-        if (lane >= d) v += t;
-    }
-    return v;
+// inclusive wave prefix sum on the DPP path: four row shifts inside the 16-lane rows, then the row totals (row_bcast:15 into
+// rows 1 and 3, row_bcast:31 into rows 2 and 3) - six v_add_u32_dpp instead of six ds_bpermute round trips
+__device__ __forceinline__ int wave_incl_scan32(int v, int) {
+    int x = v;
+    x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xf, 0xf, false);   // row_shr:1
+    x += __builtin_amdgcn_update_dpp(0, x, 0x112, 0xf, 0xf, false);   // row_shr:2
+    x += __builtin_amdgcn_update_dpp(0, x, 0x114, 0xf, 0xf, false);   // row_shr:4
+    x += __builtin_amdgcn_update_dpp(0, x, 0x118, 0xf, 0xf, false);   // row_shr:8
+    x += __builtin_amdgcn_update_dpp(0, x, 0x142, 0xa, 0xf, false);   // row_bcast:15
+    x += __builtin_amdgcn_update_dpp(0, x, 0x143, 0xc, 0xf, false);   // row_bcast:31
+    return x;
 }
 
 // ---- K1 -------------------------------------------------------------------------------------------
@@ -202,7 +210,16 @@ __global__ __launch_bounds__(256) void k_cigar_scan(SumArgs a) {
         // P2: REF_SKIP and PAD share the DEL case (summary_generator.cpp:100-114) and consume the reference only
         const bool cq = (op == 0 || op == 7 || op == 8 || op == 1 || op == 4 || (!a.polish && (op == 3 || op == 6)));
         const int64_t dr = cr ? len : 0, dq = cq ? len : 0;
-        const int64_t ir = wave_incl_scan(dr, lane), iq = wave_incl_scan(dq, lane);
+        // 64 lengths below 2^25 sum to less than 2^31: the 32-bit DPP scan is exact for every real CIGAR; anything longer takes
+        // the 64-bit shuffle scan
+        int64_t ir, iq;
+        if (__ballot(len >= (1ll << 25)) == 0) {
+            ir = wave_incl_scan32((int)dr, lane);
+            iq = wave_incl_scan32((int)dq, lane);
+        } else {
+            ir = wave_incl_scan(dr, lane);
+            iq = wave_incl_scan(dq, lane);
+        }
         const int64_t my_ref = ref_rel + ir - dr, my_rd = rd + iq - dq;
         if (c < c1) {
             const bool active = !skip && my_ref < R;
@@ -212,8 +229,8 @@ __global__ __launch_bounds__(256) void k_cigar_scan(SumArgs a) {
             if (a.polish) a.op_read[c] = (int32_t)r;   // only k_polish_insert walks op -> read
             a.op_flag[c] = 0;
         }
-        ref_rel += __shfl(ir, 63, 64);
-        rd += __shfl(iq, 63, 64);
+        ref_rel += last_lane(ir);
+        rd += last_lane(iq);
     }
     // Column span that this read can touch: every effect of populate_summary_matrix lies between the
     // column before its first position (an insert anchored at pos-1 after a leading soft clip) and its
