@@ -778,9 +778,8 @@ struct GemmArgs {
 // (16-byte chunk index ^ ((row >> 2) & 3) inside each 64-byte row) is applied on the SOURCE address of every lane. One
 // barrier per K step; per step and wave 24 ds_read_b128 feed 48 MFMAs. Work items are ordered n-tile fastest and dealt to the
 // XCDs in groups of one XCD's workgroups, so the CUs of an XCD work on the same few A row tiles at the same time. The next
-// item's first K step is requested BEFORE the epilogue stores (32 dwordx4 stores per wave in the quad layout): its DMAs are
-// older than the stores in the in-order vmcnt queue, a counted wait retires them and the stores drain behind the next
-// tile's first MFMAs.
+// item's first K step is requested BEFORE the epilogue stores (32 dwordx4 stores per wave in the quad layout), so it travels
+// while they are issued; its first K step then waits for everything the wave has in flight.
 __global__ __launch_bounds__(512, 2) void k_gemm_bf16x3(GemmArgs g) {
     constexpr int BM = 256, BN = 256, BK = 32;
     constexpr int ARR = BM * BK * 2;          // bytes of one bf16 operand image (16 KB); buffer = [A_hi | A_lo | W_hi | W_lo]
@@ -854,7 +853,6 @@ __global__ __launch_bounds__(512, 2) void k_gemm_bf16x3(GemmArgs g) {
         dma(0, 0);
         dma_bias(nt);
     }
-    bool first = true;
     while (it < g.items) {
         f32x16 acc[4][2];
 #pragma unroll
@@ -866,8 +864,10 @@ __global__ __launch_bounds__(512, 2) void k_gemm_bf16x3(GemmArgs g) {
         for (int kt = 0; kt < nk; kt++) {
             const int buf = kt & 1;
             // this step's operands have landed (every wave waits for its own DMAs, then the barrier); the other buffer is free
-            if (kt == 0 && !first) asm volatile("s_waitcnt vmcnt(32)" ::: "memory");   // the previous item's 32 stores may stay in flight
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            // (a counted wait that lets the previous item's epilogue stores stay in flight is NOT safe here: vmcnt retires loads
+            // in order among loads and stores among stores, but a store may retire before an older LDS-DMA load, so "at most 32
+            // outstanding" does not imply the DMAs have landed. It gave a sporadic 1e-4 error in one of five full test runs.)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
             if (kt + 1 < nk) dma(kt + 1, buf ^ 1);
@@ -894,7 +894,6 @@ __global__ __launch_bounds__(512, 2) void k_gemm_bf16x3(GemmArgs g) {
                 }
             }
         }
-        first = false;
         // C tile as a sized buffer resource: rows beyond M fall outside it and are dropped by the bounds check; the
         // address of every store is (tile resource) + (lane offset) + (scalar offset of (wave, mi, ni, r))
         const int64_t m0 = (int64_t)mt * BM;
