@@ -45,6 +45,7 @@ constexpr int UMAX = 1024;  // distinct alleles per site held in LDS
 constexpr int UM_SMALL = 96; // table of the k_site_alleles instantiation for sites with few events
 constexpr int TILE_COLS = 512;  // columns per pileup tile (one workgroup accumulates a tile in LDS)
 
+enum { D_SPARE = 8 };
 enum { D_NSITES = 0, D_NEVENTS = 1, D_NOUT = 2, D_STRBYTES = 3, D_STATUS = 4, D_NPAIRS = 5, D_NINS = 6, D_NROWS = 7, D_NCHUNKS = 8, D_NDIAG = 10 };
 
 struct Event {  // 16 B
@@ -163,16 +164,25 @@ __device__ __forceinline__ int64_t last_lane(int64_t v) {   // lane 63's value i
     const unsigned lo = __builtin_amdgcn_readlane((unsigned)v, 63), hi = __builtin_amdgcn_readlane((unsigned)((uint64_t)v >> 32), 63);
     return (int64_t)(((uint64_t)hi << 32) | lo);
 }
-__device__ __forceinline__ int64_t wave_incl_scan(int64_t v, int lane) {
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        int64_t t = __shfl_up(v, d, 64);
-        if (lane >= d) v += t;
-    }
-    return v;
+// inclusive wave prefix sums on the DPP path: four row shifts inside the 16-lane rows, then the row totals (row_bcast:15 into
+// rows 1 and 3, row_bcast:31 into rows 2 and 3) - six DPP adds instead of six ds_bpermute round trips (twelve for the
+// 64-bit form, whose halves move separately and are added as one number)
+template <int CTRL, int ROWS>
+__device__ __forceinline__ int64_t dpp_move64(int64_t x) {
+    const unsigned lo = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)x, CTRL, ROWS, 0xf, false);
+    const unsigned hi = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)((uint64_t)x >> 32), CTRL, ROWS, 0xf, false);
+    return (int64_t)(((uint64_t)hi << 32) | lo);
 }
-// inclusive wave prefix sum on the DPP path: four row shifts inside the 16-lane rows, then the row totals (row_bcast:15 into
-// rows 1 and 3, row_bcast:31 into rows 2 and 3) - six v_add_u32_dpp instead of six ds_bpermute round trips
+__device__ __forceinline__ int64_t wave_incl_scan(int64_t v, int) {
+    int64_t x = v;
+    x += dpp_move64<0x111, 0xf>(x);   // row_shr:1
+    x += dpp_move64<0x112, 0xf>(x);   // row_shr:2
+    x += dpp_move64<0x114, 0xf>(x);   // row_shr:4
+    x += dpp_move64<0x118, 0xf>(x);   // row_shr:8
+    x += dpp_move64<0x142, 0xa>(x);   // row_bcast:15
+    x += dpp_move64<0x143, 0xc>(x);   // row_bcast:31
+    return x;
+}
 __device__ __forceinline__ int wave_incl_scan32(int v, int) {
     int x = v;
     x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xf, 0xf, false);   // row_shr:1
@@ -774,43 +784,183 @@ __global__ __launch_bounds__(1024) void k_site_scan(SumArgs a) {
     if (threadIdx.x == 0) a.blk_cnt[blockIdx.x] = n;
 }
 
-// Single-block exclusive scans of the pipeline's small arrays (tiles, 1024-column blocks, sites). A thread owns SCAN_V
-// consecutive values per pass (8192 per pass: one pass for every array of the benchmark's 16-region batches), three
-// barriers per pass. What used to be separate one-thread kernels behind a scan (limit checks, publishing the result
-// counters) runs in the scan's last thread.
+// Exclusive scans of the pipeline's small arrays (tiles, 1024-column blocks, sites). A thread owns SCAN_V consecutive
+// values per pass, a 1024-thread workgroup 8192. These kernels are chains of dependent memory round trips, not work,
+// so the chains are kept short:
+//  * arrays whose length the host knows (tiles, blocks) run as one workgroup looping over passes, every thread
+//    summing the 16 wave totals itself (no carry cell, two barriers per pass);
+//  * the per-site arrays (length = diag[D_NSITES], 17.9 k in the benchmark's 16-region batches: three passes) run one
+//    workgroup per 8192-entry chunk. A chunk's carry is the sum of everything before it, which the workgroup adds up
+//    itself from the input (independent coalesced loads: at most n^2 / 16 k loads in all, nothing at these sizes)
+//    instead of waiting for its neighbours; the chunk's own values are loaded together WITH the length (the arrays
+//    are max_sites long, the grid covers max_sites) and masked once it has arrived. The workgroup holding the last
+//    entry publishes the totals. k_scan_outputs runs its two scans side by side.
+// What used to be separate one-thread kernels behind a scan (limit checks, publishing the result counters) runs in the
+// scan's first thread.
 constexpr int SCAN_V = 8;
+constexpr int64_t SCAN_PASS = 1024 * SCAN_V;
+constexpr int SCAN_SPEC_CHUNKS = 3;  // chunks below this add up their carry before the length has arrived
+// Loads go through a sized raw buffer: entries past `elems` read as zero without a branch per load, so all of a
+// thread's loads are in flight together. (Byte offsets are 32-bit: arrays here stay below 2^31 bytes, n_cols < 2^31.)
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t scan_rsrc(const void* p, int64_t elems, int esz) {
+    const int64_t bytes = elems > 0 ? elems * esz : 0;
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)(bytes > 0x7fffffff ? 0x7fffffff : bytes),
+                                             0x00020000);
+}
+__device__ __forceinline__ unsigned scan_voff(int64_t i, int esz) {
+    const int64_t b = i * esz;
+    return b > 0x7fffffff ? 0x80000000u : (unsigned)b;
+}
+__device__ __forceinline__ int32_t scan_ld(__amdgpu_buffer_rsrc_t r, int64_t i, int32_t) {
+    return (int32_t)__builtin_amdgcn_raw_buffer_load_b32(r, scan_voff(i, 4), 0, 0);
+}
+__device__ __forceinline__ int64_t scan_ld(__amdgpu_buffer_rsrc_t r, int64_t i, int64_t) {
+    typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
+    const u32x2_t w = __builtin_amdgcn_raw_buffer_load_b64(r, scan_voff(i, 8), 0, 0);
+    const unsigned lo = w[0], hi = w[1];
+    return (int64_t)(((uint64_t)hi << 32) | lo);
+}
+typedef unsigned scan_u32x4 __attribute__((ext_vector_type(4)));
+// sum of the 16 bytes at entry i (4 int32 or 2 int64 values)
+__device__ __forceinline__ int64_t scan_ld16_sum(__amdgpu_buffer_rsrc_t r, int64_t i, int32_t) {
+    const scan_u32x4 w = __builtin_amdgcn_raw_buffer_load_b128(r, scan_voff(i, 4), 0, 0);
+    const unsigned w0 = w[0], w1 = w[1], w2 = w[2], w3 = w[3];
+    return (int64_t)(int32_t)w0 + (int32_t)w1 + (int64_t)(int32_t)w2 + (int32_t)w3;
+}
+__device__ __forceinline__ int64_t scan_ld16_sum(__amdgpu_buffer_rsrc_t r, int64_t i, int64_t) {
+    const scan_u32x4 w = __builtin_amdgcn_raw_buffer_load_b128(r, scan_voff(i, 8), 0, 0);
+    const unsigned w0 = w[0], w1 = w[1], w2 = w[2], w3 = w[3];
+    return (int64_t)(((uint64_t)w1 << 32) | w0) + (int64_t)(((uint64_t)w3 << 32) | w2);
+}
+// A thread's SCAN_V consecutive values. The vector memory pipe of the one CU a scan workgroup sits on is what these
+// kernels wait for (about 18 cycles per load instruction, 16 waves), so the values come as 16-byte loads; only a thread
+// whose run crosses `lim` loads entry by entry.
+__device__ __forceinline__ void scan_load(const int32_t* in, int64_t i0, int64_t lim, int32_t (&v)[SCAN_V]) {
+    const __amdgpu_buffer_rsrc_t r = scan_rsrc(in, lim, 4);
+    if (i0 + SCAN_V <= lim || i0 >= lim) {
+#pragma unroll
+        for (int q = 0; q < SCAN_V / 4; q++) {
+            const scan_u32x4 w = __builtin_amdgcn_raw_buffer_load_b128(r, scan_voff(i0 + 4 * q, 4), 0, 0);
+            const unsigned w0 = w[0], w1 = w[1], w2 = w[2], w3 = w[3];
+            v[4 * q] = (int32_t)w0; v[4 * q + 1] = (int32_t)w1; v[4 * q + 2] = (int32_t)w2; v[4 * q + 3] = (int32_t)w3;
+        }
+    } else {
+#pragma unroll
+        for (int e = 0; e < SCAN_V; e++) v[e] = scan_ld(r, i0 + e, int32_t());
+    }
+}
+// (8-byte values: one load each, whole or not at all, so no branch - a branch here makes the compiler wait for the
+// loads at its end, ahead of the loads that should follow them out)
+__device__ __forceinline__ void scan_load(const int64_t* in, int64_t i0, int64_t lim, int64_t (&v)[SCAN_V]) {
+    const __amdgpu_buffer_rsrc_t r = scan_rsrc(in, lim, 8);
+#pragma unroll
+    for (int e = 0; e < SCAN_V; e++) v[e] = scan_ld(r, i0 + e, int64_t());
+}
 template <typename T>
-__device__ __forceinline__ int64_t block_excl_scan(const T* in, T* out, int64_t n, int64_t* s_w, int64_t* s_carry) {
+__device__ __forceinline__ void scan_mask(int64_t i0, int64_t n, T (&v)[SCAN_V]) {
+#pragma unroll
+    for (int e = 0; e < SCAN_V; e++) v[e] = i0 + e < n ? v[e] : (T)0;
+}
+// this thread's share of sum(in[0 .. c0)), c0 a multiple of SCAN_PASS and at most `lim`: 16 bytes per load, lanes side
+// by side
+template <typename T>
+__device__ __forceinline__ int64_t scan_carry_part(const T* in, int64_t c0, int64_t lim) {
+    constexpr int PER = 16 / (int)sizeof(T);  // values per load
+    const __amdgpu_buffer_rsrc_t r = scan_rsrc(in, lim, (int)sizeof(T));
+    int64_t pre = 0;
+    for (int64_t j0 = (int64_t)threadIdx.x * PER; j0 < c0; j0 += SCAN_PASS) {
+        int64_t q[SCAN_V / PER];
+#pragma unroll
+        for (int e = 0; e < SCAN_V / PER; e++) q[e] = scan_ld16_sum(r, j0 + 1024 * PER * e, T());
+#pragma unroll
+        for (int e = 0; e < SCAN_V / PER; e++) pre += q[e];
+    }
+    return pre;
+}
+// the same for the first SCAN_SPEC_CHUNKS chunks: a fixed number of loads (those at or past c0 read as zero: c0 is a
+// multiple of every load's span), all in flight at once
+template <typename T>
+__device__ __forceinline__ int64_t scan_carry_part_spec(const T* in, int64_t c0) {
+    constexpr int PER = 16 / (int)sizeof(T);
+    constexpr int NL = SCAN_V * (SCAN_SPEC_CHUNKS - 1) / PER;
+    const __amdgpu_buffer_rsrc_t r = scan_rsrc(in, c0, (int)sizeof(T));
+    int64_t q[NL];
+#pragma unroll
+    for (int k = 0; k < NL; k++) q[k] = scan_ld16_sum(r, ((int64_t)threadIdx.x + 1024 * k) * PER, T());
+    int64_t pre = 0;
+#pragma unroll
+    for (int k = 0; k < NL; k++) pre += q[k];
+    return pre;
+}
+// the scans' length: a vector load (kept in program order with the value loads around it: issued before the carry
+// loads, waited for after them), then made uniform
+__device__ __forceinline__ int64_t scan_len_issue(const int64_t* p) { return scan_ld(scan_rsrc(p, 1, 8), 0, int64_t()); }
+__device__ __forceinline__ int64_t scan_len_uniform(int64_t v) {
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+    return (int64_t)(((uint64_t)hi << 32) | lo);
+}
+// one pass over v[] (zero beyond n): out[i0..] = carry + exclusive prefix; returns carry + the pass total.
+// carry = `carry` (same in every thread) + the sum of `part` over the workgroup. s_w: 32 cells, reusable after the
+// closing barrier, which only a caller with another pass to run asks for (it also waits for the stores).
+template <typename T>
+__device__ __forceinline__ int64_t scan_pass(const T (&v)[SCAN_V], T* out, int64_t i0, int64_t n, int64_t carry,
+                                             int64_t part, int64_t* s_w, bool again = false) {
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    if (threadIdx.x == 0) *s_carry = 0;
+    int64_t sum = 0;
+#pragma unroll
+    for (int e = 0; e < SCAN_V; e++) sum += (int64_t)v[e];
+    const int64_t inc = wave_incl_scan(sum, lane);
+    const int64_t pinc = wave_incl_scan(part, lane);
+    if (lane == 63) { s_w[wv] = inc; s_w[16 + wv] = pinc; }
     __syncthreads();
-    for (int64_t b = 0; b < n; b += 1024 * SCAN_V) {
+    int64_t woff = 0, tot = 0;
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+        const int64_t w = s_w[k];
+        woff += k < wv ? w : 0;
+        tot += w;
+        carry += s_w[16 + k];
+    }
+    int64_t run = carry + woff + inc - sum;
+    T o[SCAN_V];
+#pragma unroll
+    for (int e = 0; e < SCAN_V; e++) { o[e] = (T)run; run += (int64_t)v[e]; }
+    if (i0 + SCAN_V <= n) {  // 16-byte stores (i0 is a multiple of SCAN_V, the arrays are 256-byte aligned)
+        typedef T ovec __attribute__((ext_vector_type(16 / sizeof(T))));
+        constexpr int PER = 16 / (int)sizeof(T);
+#pragma unroll
+        for (int q = 0; q < SCAN_V / PER; q++) {
+            ovec w;
+#pragma unroll
+            for (int e = 0; e < PER; e++) w[e] = o[PER * q + e];
+            *reinterpret_cast<ovec*>(out + i0 + PER * q) = w;
+        }
+    } else {
+#pragma unroll
+        for (int e = 0; e < SCAN_V; e++) if (i0 + e < n) out[i0 + e] = o[e];
+    }
+    if (again) __syncthreads();
+    return carry + tot;
+}
+// one workgroup, n known to the host
+template <typename T>
+__device__ __forceinline__ int64_t block_excl_scan(const T* in, T* out, int64_t n, int64_t* s_w) {
+    int64_t carry = 0;
+    for (int64_t b = 0; b == 0 || b < n; b += SCAN_PASS) {
         const int64_t i0 = b + (int64_t)threadIdx.x * SCAN_V;
         T v[SCAN_V];
-        int64_t sum = 0;
-#pragma unroll
-        for (int e = 0; e < SCAN_V; e++) { v[e] = i0 + e < n ? in[i0 + e] : (T)0; sum += (int64_t)v[e]; }
-        const int64_t inc = wave_incl_scan(sum, lane);
-        if (lane == 63) s_w[wv] = inc;
-        __syncthreads();
-        int64_t woff = 0;
-        for (int k = 0; k < wv; k++) woff += s_w[k];
-        const int64_t carry = *s_carry;
-        int64_t run = carry + woff + inc - sum;
-#pragma unroll
-        for (int e = 0; e < SCAN_V; e++) { if (i0 + e < n) out[i0 + e] = (T)run; run += (int64_t)v[e]; }
-        __syncthreads();
-        if (threadIdx.x == 1023) *s_carry = carry + woff + inc;
-        __syncthreads();
+        scan_load(in, i0, n, v);
+        carry = scan_pass(v, out, i0, n, carry, 0, s_w, b + SCAN_PASS < n);
     }
-    return *s_carry;
+    return carry;
 }
+// grid of the per-site scans
+static inline unsigned scan_chunks(int64_t cap) { return (unsigned)std::max<int64_t>(1, (cap + SCAN_PASS - 1) / SCAN_PASS); }
 
 // tile pair counts -> offsets, total -> diag[D_NPAIRS]; over the pair workspace: nothing is filled or walked
 __global__ __launch_bounds__(1024) void k_scan_tiles(SumArgs a) {
-    __shared__ int64_t s_w[16];
-    __shared__ int64_t s_carry;
-    const int64_t total = block_excl_scan<int32_t>(a.tile_cnt, a.tile_off, a.n_tiles, s_w, &s_carry);
+    __shared__ int64_t s_w[32];
+    const int64_t total = block_excl_scan<int32_t>(a.tile_cnt, a.tile_off, a.n_tiles, s_w);
     if (total > a.max_pairs) {
         if (threadIdx.x == 0) set_status(a.diag, PV_ERR_LIMIT);
         for (int64_t t = threadIdx.x; t < a.n_tiles; t += 1024) a.tile_cnt[t] = 0;
@@ -820,53 +970,77 @@ __global__ __launch_bounds__(1024) void k_scan_tiles(SumArgs a) {
 
 // sites per 1024-column block -> offsets, total -> diag[D_NSITES]
 __global__ __launch_bounds__(1024) void k_scan_blocks(SumArgs a, int64_t n_blk) {
-    __shared__ int64_t s_w[16];
-    __shared__ int64_t s_carry;
-    const int64_t total = block_excl_scan<int32_t>(a.blk_cnt, a.blk_off, n_blk, s_w, &s_carry);
+    __shared__ int64_t s_w[32];
+    const int64_t total = block_excl_scan<int32_t>(a.blk_cnt, a.blk_off, n_blk, s_w);
     if (threadIdx.x == 0) a.diag[D_NSITES] = total;
 }
 
-// events per site -> offsets, total -> diag[D_NEVENTS]; site / event workspace limits
+// events per site -> offsets, total -> diag[D_NEVENTS]; site / event workspace limits. Grid: scan_chunks(max_sites).
 __global__ __launch_bounds__(1024) void k_scan_events(SumArgs a) {
-    __shared__ int64_t s_w[16];
-    __shared__ int64_t s_carry;
-    int64_t n = a.diag[D_NSITES];
-    if (n > a.max_sites) n = a.max_sites;
-    const int64_t total = block_excl_scan<int32_t>(a.site_nev, a.site_evoff, n, s_w, &s_carry);
-    if (threadIdx.x == 0) {
+    __shared__ int64_t s_w[32];
+    const int64_t c0 = (int64_t)blockIdx.x * SCAN_PASS, i0 = c0 + (int64_t)threadIdx.x * SCAN_V;
+    const bool spec = blockIdx.x < SCAN_SPEC_CHUNKS;
+    int32_t v[SCAN_V];
+    scan_load(a.site_nev, i0, a.max_sites, v);
+    const int64_t n_raw = scan_len_issue(a.diag + D_NSITES);
+    int64_t part = spec ? scan_carry_part_spec(a.site_nev, c0) : 0;
+    const int64_t n_sites = scan_len_uniform(n_raw);
+    const int64_t n = n_sites > a.max_sites ? a.max_sites : n_sites;
+    if (c0 >= n && blockIdx.x > 0) return;
+    if (!spec) part = scan_carry_part(a.site_nev, c0, a.max_sites);
+    scan_mask(i0, n, v);
+    const int64_t total = scan_pass(v, a.site_evoff, i0, n, 0, part, s_w);
+    if (threadIdx.x == 0 && n <= c0 + SCAN_PASS) {
         a.diag[D_NEVENTS] = total;
-        if (a.diag[D_NSITES] > a.max_sites || total > a.max_events) set_status(a.diag, PV_ERR_LIMIT);
+        if (n_sites > a.max_sites || total > a.max_events) set_status(a.diag, PV_ERR_LIMIT);
     }
 }
 
-// windows and key bytes per site -> offsets, totals -> diag[D_NOUT], diag[D_STRBYTES]; result counters of the call
+// windows and key bytes per site -> offsets, totals -> diag[D_NOUT], diag[D_STRBYTES]; result counters of the call.
+// Grid: scan_chunks(max_sites).
 __global__ __launch_bounds__(1024) void k_scan_outputs(SumArgs a) {
-    __shared__ int64_t s_w[16];
-    __shared__ int64_t s_carry;
-    int64_t n = a.diag[D_NSITES];
-    if (n > a.max_sites) n = a.max_sites;
-    const int64_t n_out = block_excl_scan<int32_t>(a.site_nemit, a.site_outoff, n, s_w, &s_carry);
-    __syncthreads();
-    const int64_t n_str = block_excl_scan<int64_t>(a.site_strbytes, a.site_stroff, n, s_w, &s_carry);
-    if (threadIdx.x == 0) {
+    __shared__ int64_t s_w[2][32];
+    const int64_t c0 = (int64_t)blockIdx.x * SCAN_PASS, i0 = c0 + (int64_t)threadIdx.x * SCAN_V;
+    const bool spec = blockIdx.x < SCAN_SPEC_CHUNKS;
+    int32_t ve[SCAN_V];
+    int64_t vs[SCAN_V];
+    scan_load(a.site_nemit, i0, a.max_sites, ve);
+    scan_load(a.site_strbytes, i0, a.max_sites, vs);
+    const int64_t n_raw = scan_len_issue(a.diag + D_NSITES);
+    int64_t pe = 0, ps = 0;
+    if (spec) {
+        pe = scan_carry_part_spec(a.site_nemit, c0);
+        ps = scan_carry_part_spec(a.site_strbytes, c0);
+    }
+    const int64_t n_sites = scan_len_uniform(n_raw);
+    const int64_t n = n_sites > a.max_sites ? a.max_sites : n_sites;
+    if (c0 >= n && blockIdx.x > 0) return;
+    if (!spec) {
+        pe = scan_carry_part(a.site_nemit, c0, a.max_sites);
+        ps = scan_carry_part(a.site_strbytes, c0, a.max_sites);
+    }
+    const int64_t status = a.diag[D_STATUS];  // (k_write_windows, the only kernel behind this one, sets no status)
+    scan_mask(i0, n, ve);
+    scan_mask(i0, n, vs);
+    const int64_t n_out = scan_pass(ve, a.site_outoff, i0, n, 0, pe, s_w[0]);
+    const int64_t n_str = scan_pass(vs, a.site_stroff, i0, n, 0, ps, s_w[1]);
+    if (threadIdx.x == 0 && n <= c0 + SCAN_PASS) {
         a.diag[D_NOUT] = n_out;
         a.diag[D_STRBYTES] = n_str;
-        // (k_write_windows, the only kernel behind this one, sets no status)
         a.d_counts[0] = n_out;
         a.d_counts[1] = n_str;
-        a.d_counts[2] = a.diag[D_STATUS];
-        a.d_counts[3] = a.diag[D_NSITES];
+        a.d_counts[2] = status;
+        a.d_counts[3] = n_sites;
     }
 }
 
 // single-block exclusive scan of n int32 values; total -> *total_out (int64) (polisher pipeline)
 __global__ __launch_bounds__(1024) void k_scan_i32(const int32_t* in, int32_t* out, int64_t n_fixed,
                                                    const int64_t* n_ptr, int64_t n_cap, int64_t* total_out) {
-    __shared__ int64_t s_w[16];
-    __shared__ int64_t s_carry;
+    __shared__ int64_t s_w[32];
     int64_t n = n_ptr ? *n_ptr : n_fixed;
     if (n > n_cap) n = n_cap;
-    const int64_t total = block_excl_scan<int32_t>(in, out, n, s_w, &s_carry);
+    const int64_t total = block_excl_scan<int32_t>(in, out, n, s_w);
     if (threadIdx.x == 0 && total_out) *total_out = total;
 }
 
@@ -1735,7 +1909,7 @@ static int summarize_launch(pv_ctx* ctx, const pv_batch_in* in, const pv_params*
     if ((rc = pv_get(ctx, "sum.site_stroff", max_sites, &a.site_stroff))) return rc;
     if ((rc = pv_get(ctx, "sum.ev", max_events, &a.ev))) return rc;
     if ((rc = pv_get(ctx, "sum.rec", max_events + 4 * max_sites, &a.rec))) return rc;
-    if ((rc = pv_get(ctx, "sum.diag", (size_t)D_NDIAG + 8, &a.diag))) return rc;
+    if ((rc = pv_get(ctx, "sum.diag", (size_t)D_NDIAG + D_SPARE, &a.diag))) return rc;
 
     pv_prof_scope ps_all(ctx, "summary_pipeline", st);
     k_init<<<grid_for(std::max<int64_t>(a.n_tiles, D_NDIAG + 8), 256), 256, 0, st>>>(a);
@@ -1750,7 +1924,7 @@ static int summarize_launch(pv_ctx* ctx, const pv_batch_in* in, const pv_params*
     k_site_scan<<<(unsigned)n_blk, 1024, 0, st>>>(a);
     k_scan_blocks<<<1, 1024, 0, st>>>(a, n_blk);
     k_site_rank<<<(unsigned)n_blk, 1024, 0, st>>>(a);
-    k_scan_events<<<1, 1024, 0, st>>>(a);
+    k_scan_events<<<scan_chunks(a.max_sites), 1024, 0, st>>>(a);
     // per-site kernels are chains of dependent loads per wave: as many workgroups as can be resident (one site each for the
     // benchmark's ~8 k sites per launch)
     const unsigned site_grid = (unsigned)(max_sites < 8192 ? (max_sites > 0 ? max_sites : 1) : 8192);
@@ -1767,7 +1941,7 @@ static int summarize_launch(pv_ctx* ctx, const pv_batch_in* in, const pv_params*
             k_site_alleles<false, UMAX, true><<<big_grid, 64, 0, st>>>(a);
         }
     }
-    k_scan_outputs<<<1, 1024, 0, st>>>(a);
+    k_scan_outputs<<<scan_chunks(a.max_sites), 1024, 0, st>>>(a);
     {
         pv_prof_scope ps(ctx, "k_write_windows", st);
         if (hp) k_write_windows_hp<<<site_grid, WW_THREADS, 0, st>>>(a);
@@ -1983,7 +2157,7 @@ static int polish_launch(pv_ctx* ctx, const pv_batch_in* in, int64_t n_reads, in
     if ((rc = pv_get(ctx, "pol.ins_cnt", (size_t)(max_ins_rows > 0 ? max_ins_rows : 1) * 10, &a.ins_cnt))) return rc;
     if ((rc = pv_get(ctx, "pol.reg_rows", (size_t)G + 1, &a.reg_rows))) return rc;
     if ((rc = pv_get(ctx, "pol.reg_chunks", (size_t)G + 1, &a.reg_chunks))) return rc;
-    if ((rc = pv_get(ctx, "sum.diag", (size_t)D_NDIAG + 8, &a.diag))) return rc;
+    if ((rc = pv_get(ctx, "sum.diag", (size_t)D_NDIAG + D_SPARE, &a.diag))) return rc;
     if (out->flat_images) {
         PV_CHECK(out->flat_position && out->flat_index, PV_ERR_INVALID, "flat_position / flat_index missing");
         a.flat_img = out->flat_images; a.flat_pos = out->flat_position; a.flat_idx = out->flat_index;
@@ -2144,9 +2318,9 @@ extern "C" int pv_polish_summarize_regions(pv_ctx* ctx, const pv_batch_in* in, i
 // diagnostic builds only: phase cycle sums of the last k_pileup_tiles launch (6 values)
 extern "C" int pv_debug_read_pstamps(pv_ctx* ctx, unsigned long long* out) {
     int64_t* d = nullptr;
-    if (pv_get(ctx, "sum.diag", (size_t)D_NDIAG + 8, &d)) return PV_ERR_HIP;
+    if (pv_get(ctx, "sum.diag", (size_t)D_NDIAG + D_SPARE, &d)) return PV_ERR_HIP;
     PV_HIP(hipDeviceSynchronize());
-    PV_HIP(hipMemcpy(out, d + D_NDIAG, 6 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+        PV_HIP(hipMemcpy(out, d + D_NDIAG, 6 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     return PV_OK;
 }
 #endif

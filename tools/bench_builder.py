@@ -25,4 +25,5 @@ pr = ctx.profile_end()
 ms = {k: v[0] / v[1] for k, v in pr.items()}
 alg = b.algorithmic_bytes(do.n_out())
 print("builder alone (%d regions, %d windows):" % (n, do.n_out()), {k: round(v, 4) for k, v in ms.items()})
+print("counts (windows, key bytes, status, sites):", do.counts.tolist())
 print("algorithmic bytes %d -> %.1f GB/s (%.2f%% of 8 TB/s)" % (alg, alg / ms["summary_pipeline"] / 1e6, alg / ms["summary_pipeline"] / 1e6 / 80))
