@@ -17,7 +17,7 @@
 //   k_cigar_scan     wave per read: prefix sums over CIGAR ops -> per-op (column, read index)
 //   k_tile_fill      lane per (read, 512-column tile): op range of the read that can touch the tile
 //   k_pileup_tiles   workgroup per tile: counters in LDS, aligned bases dealt to lanes in padded groups of 4
-//   k_site_scan      thread per column: frequency thresholds -> site flags, per-block site counts
+//   (site flags: frequency thresholds per column, per-tile site counts - in the flush of k_pileup_tiles)
 //   k_scan_*         single-block exclusive scans (tiny arrays)
 //   k_site_rank      column -> site rank, site list, per-site event bucket sizes
 //   k_collect        wave per site, lane per overlapping read: the read's ops at that column by binary search; allele events
@@ -123,6 +123,7 @@ struct SumArgs {
     int32_t polish;       // 1: CIGAR semantics of SummaryGenerator::iterate_over_read (N and P consume the reference only)
     int32_t seq_len, seq_step;  // chunk length, chunk length - overlap
     int32_t* pcnt;        // [PC_N][n_cols] plane-major: 10 features, coverage, longest insert
+    int32_t* tile_g0;     // [n_tiles] region of each tile's first column
     int32_t* ins_blk;     // [n_blk] insert rows per 1024-column block
     int32_t* ins_blkoff;  // [n_blk] exclusive scan
     int32_t* ins_off;     // [n_cols + 1] insert rows before every column
@@ -352,6 +353,45 @@ enum {
     HL_SNP = 27, HL_INS = 28, HL_DEL = 29, HL_N = 30
 };
 
+// Site flag of one column from its four counters: frequency thresholds of :634-646 (bit 0 site, bits 1-3 which of the
+// SNP / insert / delete thresholds passed). Runs in the flush of k_pileup_tiles, where the counters still sit in LDS
+// (it was a kernel of its own, k_site_scan, re-reading four planes: 16 us per 1.6 M columns, mostly round trips).
+// A tile may run across region boundaries: the region of its first column is looked up when the workgroup starts
+// (SiteRegion, off the tile's critical path), a column beyond it walks on from there.
+struct SiteRegion { int g; int64_t off, next, R, start, cand_lo, cand_hi; };
+__device__ __forceinline__ SiteRegion site_region_load(const SumArgs& a, int g) {
+    SiteRegion r;
+    r.g = g;
+    const bool ok = g >= 0 && g < a.in.n_regions;
+    r.off = ok ? a.in.ref_off[g] : 0;
+    r.next = ok ? a.in.ref_off[g + 1] : 0;
+    r.start = ok ? a.in.ref_start[g] : 0;
+    r.R = ok ? a.in.ref_end[g] - r.start + 1 : 0;
+    r.cand_lo = ok ? a.in.cand_start[g] : 1;
+    r.cand_hi = ok ? a.in.cand_end[g] : 0;
+    return r;
+}
+__device__ __forceinline__ uint8_t site_flag(const SumArgs& a, const SiteRegion& r0, int64_t col, int cov, int n_snp, int n_ins,
+                                             int n_del) {
+    SiteRegion r = r0;
+    if (col >= r0.next) {  // (columns are >= the tile's first: only forwards)
+        int g = r0.g;
+        while (g + 1 <= a.in.n_regions && a.in.ref_off[g + 1] <= col) g++;
+        r = site_region_load(a, g);
+    }
+    const int64_t i = col - r.off;
+    if (i >= r.R) return 0;
+    const double cv = (double)cov > 1.0 ? (double)cov : 1.0;
+    const double fs = (double)n_snp / cv;
+    const double fi = (double)n_ins / cv;
+    const double fd = (double)n_del / cv;
+    const bool ps = fs >= a.p.snp_freq_threshold, pi = fi >= a.p.insert_freq_threshold, pd = fd >= a.p.delete_freq_threshold;
+    const int64_t pos = r.start + i;
+    if ((ps || pi || pd) && pos >= r.cand_lo && pos <= r.cand_hi && (double)cov >= a.p.min_coverage_threshold)
+        return (uint8_t)(1 | (ps ? 2 : 0) | (pi ? 4 : 0) | (pd ? 8 : 0));
+    return 0;
+}
+
 template <bool HP>
 __global__ __launch_bounds__(PT_THREADS, HP ? 2 : 4) void k_pileup_tiles(SumArgs a) {   // 26-plane form: two workgroups per CU (<= 128 VGPRs)
     __shared__ int32_t s_cnt[HP ? (int)HL_N : (int)L_N][TILE_COLS];
@@ -382,6 +422,8 @@ __global__ __launch_bounds__(PT_THREADS, HP ? 2 : 4) void k_pileup_tiles(SumArgs
 #define PSTAMP(i)
 #endif
     const int64_t tlo = tile * TILE_COLS, thi = tlo + TILE_COLS - 1;  // global columns of this tile
+    __shared__ SiteRegion s_sreg;  // region of the tile's first column, for the flush (looked up by k_init)
+    if (tid == 0) s_sreg = site_region_load(a, a.tile_g0[tile]);
     for (int i = tid; i < (HP ? (int)HL_N : (int)L_N) * TILE_COLS; i += PT_THREADS) (&s_cnt[0][0])[i] = 0;
     for (int i = tid; i < TILE_COLS + 4; i += PT_THREADS) s_ref[i] = (i < TILE_COLS && tlo + i < a.n_cols) ? a.in.ref[tlo + i] : (uint8_t)'N';
     if (tid < 256) s_lut[tid] = (uint8_t)(sym_of(tid) | (is_acgt(tid) ? 8 : 0) | ((tid != up(tid) && is_acgt(up(tid))) ? 16 : 0) | (is_acgt(up(tid)) ? 32 : 0));
@@ -693,6 +735,9 @@ __global__ __launch_bounds__(PT_THREADS, HP ? 2 : 4) void k_pileup_tiles(SumArgs
     const int64_t NC = a.n_cols;
     int64_t ncol = NC - tlo;
     if (ncol > TILE_COLS) ncol = TILE_COLS;
+    static_assert(TILE_COLS <= PT_THREADS, "one column per thread: the site count below is a ballot");
+    int site = 0;
+    const SiteRegion sreg = s_sreg;
     if constexpr (HP) {
         for (int lc = tid; lc < ncol; lc += PT_THREADS) {
             const int64_t g = tlo + lc;
@@ -714,10 +759,14 @@ __global__ __launch_bounds__(PT_THREADS, HP ? 2 : 4) void k_pileup_tiles(SumArgs
                     for (int k = 0; k < 3; k++) dst[(int64_t)(5 + k) * NC] = s_cnt[HL_O + grp * 3 + k][SW(lc)];
                 }
             }
+            const int n_snp = s_cnt[HL_SNP][SW(lc)], n_ins = s_cnt[HL_INS][SW(lc)], n_del = s_cnt[HL_DEL][SW(lc)];
             a.cnt[(int64_t)C_COV * NC + g] = cov;
-            a.cnt[(int64_t)C_SNP * NC + g] = s_cnt[HL_SNP][SW(lc)];
-            a.cnt[(int64_t)C_INS * NC + g] = s_cnt[HL_INS][SW(lc)];
-            a.cnt[(int64_t)C_DEL * NC + g] = s_cnt[HL_DEL][SW(lc)];
+            a.cnt[(int64_t)C_SNP * NC + g] = n_snp;
+            a.cnt[(int64_t)C_INS * NC + g] = n_ins;
+            a.cnt[(int64_t)C_DEL * NC + g] = n_del;
+            const uint8_t f = site_flag(a, sreg, g, cov, n_snp, n_ins, n_del);
+            a.flags[g] = f;
+            site = f & 1;
         }
     } else {
     for (int lc = tid; lc < ncol; lc += PT_THREADS) {
@@ -738,13 +787,21 @@ __global__ __launch_bounds__(PT_THREADS, HP ? 2 : 4) void k_pileup_tiles(SumArgs
 #pragma unroll
             for (int k = 0; k < 3; k++) a.cnt[(int64_t)(C_PLANE + 8 * st + 5 + k) * NC + g] = -s_cnt[L_O + 3 * st + k][SW(lc)];
         }
+        const int n_snp = s_cnt[L_SNP][SW(lc)], n_ins = s_cnt[L_INS][SW(lc)], n_del = s_cnt[L_DEL][SW(lc)];
         a.cnt[(int64_t)C_COV * NC + g] = cov;
-        a.cnt[(int64_t)C_SNP * NC + g] = s_cnt[L_SNP][SW(lc)];
-        a.cnt[(int64_t)C_INS * NC + g] = s_cnt[L_INS][SW(lc)];
-        a.cnt[(int64_t)C_DEL * NC + g] = s_cnt[L_DEL][SW(lc)];
+        a.cnt[(int64_t)C_SNP * NC + g] = n_snp;
+        a.cnt[(int64_t)C_INS * NC + g] = n_ins;
+        a.cnt[(int64_t)C_DEL * NC + g] = n_del;
         a.cnt[(int64_t)C_RARE * NC + g] = s_cnt[L_RARE][SW(lc)];
+        const uint8_t f = site_flag(a, sreg, g, cov, n_snp, n_ins, n_del);
+        a.flags[g] = f;
+        site = f & 1;
     }
     }
+    // sites of this tile: the "block" counts the rank kernel's scan runs over are per tile (zeroed by k_init; an atomic
+    // per wave rather than a workgroup count, whose barrier would wait for the stores above)
+    const unsigned long long site_m = __ballot(site);
+    if ((tid & 63) == 0 && site_m) atomicAdd(&a.blk_cnt[tile], __popcll(site_m));
 #ifdef PV_PSTAMPS
     PSTAMP(5)  // flush
     if (tid == 0 && a.site_strbytes) {  // debug: reuse a workspace array that is written later in the pipeline
@@ -755,35 +812,6 @@ __global__ __launch_bounds__(PT_THREADS, HP ? 2 : 4) void k_pileup_tiles(SumArgs
 }
 
 // ---- K3 -------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(1024) void k_site_scan(SumArgs a) {
-    const int64_t col = (int64_t)blockIdx.x * 1024 + threadIdx.x;
-    int site = 0;
-    if (col < a.n_cols) {
-        const int g = upper_bound_i64(a.in.ref_off, a.in.n_regions + 1, col) - 1;
-        const int64_t i = col - a.in.ref_off[g];
-        const int64_t R = a.in.ref_end[g] - a.in.ref_start[g] + 1;
-        uint8_t f = 0;
-        if (g >= 0 && g < a.in.n_regions && i < R) {  // :634-646
-            const int64_t NC = a.n_cols;
-            const int cov = a.cnt[C_COV * NC + col];
-            const double cv = (double)cov > 1.0 ? (double)cov : 1.0;
-            const double fs = (double)a.cnt[C_SNP * NC + col] / cv;
-            const double fi = (double)a.cnt[C_INS * NC + col] / cv;
-            const double fd = (double)a.cnt[C_DEL * NC + col] / cv;
-            const bool ps = fs >= a.p.snp_freq_threshold, pi = fi >= a.p.insert_freq_threshold,
-                       pd = fd >= a.p.delete_freq_threshold;
-            const int64_t pos = a.in.ref_start[g] + i;
-            if ((ps || pi || pd) && pos >= a.in.cand_start[g] && pos <= a.in.cand_end[g] &&
-                (double)cov >= a.p.min_coverage_threshold)
-                f = (uint8_t)(1 | (ps ? 2 : 0) | (pi ? 4 : 0) | (pd ? 8 : 0));
-        }
-        a.flags[col] = f;
-        site = f & 1;
-    }
-    const int n = __syncthreads_count(site);
-    if (threadIdx.x == 0) a.blk_cnt[blockIdx.x] = n;
-}
-
 // Exclusive scans of the pipeline's small arrays (tiles, 1024-column blocks, sites). A thread owns SCAN_V consecutive
 // values per pass, a 1024-thread workgroup 8192. These kernels are chains of dependent memory round trips, not work,
 // so the chains are kept short:
@@ -968,7 +996,7 @@ __global__ __launch_bounds__(1024) void k_scan_tiles(SumArgs a) {
     if (threadIdx.x == 0) a.diag[D_NPAIRS] = total;
 }
 
-// sites per 1024-column block -> offsets, total -> diag[D_NSITES]
+// sites per tile -> offsets, total -> diag[D_NSITES]
 __global__ __launch_bounds__(1024) void k_scan_blocks(SumArgs a, int64_t n_blk) {
     __shared__ int64_t s_w[32];
     const int64_t total = block_excl_scan<int32_t>(a.blk_cnt, a.blk_off, n_blk, s_w);
@@ -1056,7 +1084,7 @@ __global__ __launch_bounds__(1024) void k_site_rank(SumArgs a) {
     __syncthreads();
     int woff = 0;
     for (int k = 0; k < wv; k++) woff += s_w[k];
-    const int32_t rank = a.blk_off[blockIdx.x] + woff + before;
+    const int32_t rank = a.blk_off[blockIdx.x * (1024 / TILE_COLS)] + woff + before;  // block offsets are per tile
     if (col < a.n_cols) a.site_rank[col] = rank;
     if (site && rank < a.max_sites) {
         const int64_t NC = a.n_cols;
@@ -1840,7 +1868,14 @@ __global__ __launch_bounds__(256) void k_init(SumArgs a) {
 #else
     if (i < D_NDIAG) a.diag[i] = 0;
 #endif
-    if (i < a.n_tiles) { a.tile_cnt[i] = 0; a.tile_fill[i] = 0; }
+    if (i < a.n_tiles) {
+        a.tile_cnt[i] = 0;
+        a.tile_fill[i] = 0;
+        if (a.blk_cnt) {  // (builder pipelines; the polisher's has no site lists)
+            a.blk_cnt[i] = 0;
+            a.tile_g0[i] = upper_bound_i64(a.in.ref_off, a.in.n_regions + 1, i * TILE_COLS) - 1;
+        }
+    }
 }
 
 }  // namespace
@@ -1896,8 +1931,9 @@ static int summarize_launch(pv_ctx* ctx, const pv_batch_in* in, const pv_params*
     if ((rc = pv_get(ctx, "sum.cnt", (size_t)(hp ? NCNT_HP : NCNT) * n_cols, &a.cnt))) return rc;
     if ((rc = pv_get(ctx, "sum.flags", n_cols, &a.flags))) return rc;
     if ((rc = pv_get(ctx, "sum.site_rank", n_cols, &a.site_rank))) return rc;
-    if ((rc = pv_get(ctx, "sum.blk_cnt", n_blk, &a.blk_cnt))) return rc;
-    if ((rc = pv_get(ctx, "sum.blk_off", n_blk, &a.blk_off))) return rc;
+    if ((rc = pv_get(ctx, "sum.blk_cnt", (size_t)a.n_tiles + 2, &a.blk_cnt))) return rc;   // per tile
+    if ((rc = pv_get(ctx, "sum.blk_off", (size_t)a.n_tiles + 2, &a.blk_off))) return rc;
+    if ((rc = pv_get(ctx, "sum.tile_g0", (size_t)a.n_tiles + 2, &a.tile_g0))) return rc;
     if ((rc = pv_get(ctx, "sum.site_col", max_sites, &a.site_col))) return rc;
     if ((rc = pv_get(ctx, "sum.site_region", max_sites, &a.site_region))) return rc;
     if ((rc = pv_get(ctx, "sum.site_nev", max_sites, &a.site_nev))) return rc;
@@ -1921,8 +1957,7 @@ static int summarize_launch(pv_ctx* ctx, const pv_batch_in* in, const pv_params*
         if (hp) k_pileup_tiles<true><<<(unsigned)a.n_tiles, PT_THREADS, 0, st>>>(a);
         else k_pileup_tiles<false><<<(unsigned)a.n_tiles, PT_THREADS, 0, st>>>(a);
     }
-    k_site_scan<<<(unsigned)n_blk, 1024, 0, st>>>(a);
-    k_scan_blocks<<<1, 1024, 0, st>>>(a, n_blk);
+    k_scan_blocks<<<1, 1024, 0, st>>>(a, a.n_tiles);
     k_site_rank<<<(unsigned)n_blk, 1024, 0, st>>>(a);
     k_scan_events<<<scan_chunks(a.max_sites), 1024, 0, st>>>(a);
     // per-site kernels are chains of dependent loads per wave: as many workgroups as can be resident (one site each for the
