@@ -212,9 +212,15 @@ __global__ __launch_bounds__(256) void k_cigar_scan(SumArgs a) {
     if (!skip && !a.polish && a.in.base_off[r + 1] - a.in.base_off[r] <= 0 && lane == 0) set_status(a.diag, PV_ERR_INVALID);
     int64_t ref_rel = a.in.read_pos[r] - a.in.ref_start[g];
     int64_t rd = 0;
+    // the CIGAR words of the next two 64-op trips are requested before this trip's scan: a trip is otherwise one exposed
+    // round trip (load -> scans -> stores), ~15 of them in a row for a 10 kb read
+    uint32_t w_n1 = c0 + lane < c1 ? a.in.cigar[c0 + lane] : 0u;
+    uint32_t w_n2 = c0 + 64 + lane < c1 ? a.in.cigar[c0 + 64 + lane] : 0u;
     for (int64_t cb = c0; cb < c1; cb += 64) {
         const int64_t c = cb + lane;
-        uint32_t w = c < c1 ? a.in.cigar[c] : 0u;
+        const uint32_t w = w_n1;
+        w_n1 = w_n2;
+        w_n2 = c + 128 < c1 ? a.in.cigar[c + 128] : 0u;
         const int op = w & 0xF;
         const int64_t len = c < c1 ? (int64_t)(w >> 4) : 0;
         const bool cr = (op == 0 || op == 7 || op == 8 || op == 2 || op == 3 || op == 6);
@@ -1114,8 +1120,9 @@ __device__ __forceinline__ void push_event(const SumArgs& a, int32_t s, int64_t 
 //   ops that START right behind the column and are inserts / deletes anchor on it (op_flag: counted by k_pileup_tiles);
 //   the aligned op that contains the column gives the read's base there (rare observations only, or - haplotag form - every
 //   mismatch).
-__global__ __launch_bounds__(64) void k_collect(SumArgs a) {
-    const int lane = threadIdx.x;
+constexpr int KC_WAVES = 2;  // waves per site: the benchmark's tiles hold ~70 pairs, which one wave would walk as two trips in a row
+__global__ __launch_bounds__(64 * KC_WAVES) void k_collect(SumArgs a) {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     if (a.diag[D_STATUS] != 0) return;
     int64_t n_sites = a.diag[D_NSITES];
     if (n_sites > a.max_sites) n_sites = a.max_sites;
@@ -1129,7 +1136,7 @@ __global__ __launch_bounds__(64) void k_collect(SumArgs a) {
         const int refb = a.in.ref[col];
         const int64_t t = col / TILE_COLS;
         const int32_t p0 = a.tile_off[t], np = a.tile_cnt[t];
-        for (int32_t pb = 0; pb < np; pb += 64) {
+        for (int32_t pb = 64 * wv; pb < np; pb += 64 * KC_WAVES) {
             if (pb + lane >= np) continue;
             const PairRec pr = a.pairs[p0 + pb + lane];
             if (pr.col_base != (int32_t)col_base) continue;   // a tile can hold the end of one region and the start of the next
@@ -1964,7 +1971,7 @@ static int summarize_launch(pv_ctx* ctx, const pv_batch_in* in, const pv_params*
     // benchmark's ~8 k sites per launch)
     const unsigned site_grid = (unsigned)(max_sites < 8192 ? (max_sites > 0 ? max_sites : 1) : 8192);
     const unsigned collect_grid = site_grid < 4096 ? site_grid : 4096;   // measured: 0.083 ms with 4096 workgroups, 0.095 with 8192
-    if (n_cigar > 0 && n_reads > 0) { pv_prof_scope ps(ctx, "k_collect", st); k_collect<<<collect_grid, 64, 0, st>>>(a); }
+    if (n_cigar > 0 && n_reads > 0) { pv_prof_scope ps(ctx, "k_collect", st); k_collect<<<collect_grid, 64 * KC_WAVES, 0, st>>>(a); }
     {
         pv_prof_scope ps(ctx, "k_site_alleles", st);
         const unsigned big_grid = site_grid < 1024 ? site_grid : 1024;
