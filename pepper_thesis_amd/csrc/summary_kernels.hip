@@ -1399,6 +1399,7 @@ __global__ __launch_bounds__(64) void k_site_alleles(SumArgs a) {
 // window instead of 14 and four times as many chains are in flight per CU
 constexpr int WW_THREADS = 256;
 __global__ __launch_bounds__(WW_THREADS) void k_write_windows(SumArgs a) {
+    __shared__ int32_t s_win[PV_WINDOW_BYTES];
     const int lane = threadIdx.x;
     if (a.diag[D_STATUS] != 0) return;
     int64_t n_sites = a.diag[D_NSITES];
@@ -1437,17 +1438,35 @@ __global__ __launch_bounds__(WW_THREADS) void k_write_windows(SumArgs a) {
                 }
                 int end_index = 16 + rc.len - 1;  // :885
                 if (end_index > 31) end_index = 31;
-                for (int el = lane; el < PV_WINDOW_BYTES; el += WW_THREADS) {
-                    const int row = el / PV_FEATURES, pl = el - row * PV_FEATURES;
+                // gather with the ROW running fastest across lanes: the counters are plane-major, so the lanes of a wave then read
+                // two or three planes x 33 consecutive columns (a few lines) instead of one value from each of 26 planes 6 MB
+                // apart; the finished window goes through LDS and leaves in its own (row, feature) order, coalesced
+                constexpr int WW_TRIPS = (PV_WINDOW_BYTES + WW_THREADS - 1) / WW_THREADS;
+                int raw[WW_TRIPS];
+#pragma unroll
+                for (int u = 0; u < WW_TRIPS; u++) {   // every load of the window is requested before the first is used
+                    const int t = lane + u * WW_THREADS;
+                    const int pl = t / PV_WINDOW_ROWS, row = t - pl * PV_WINDOW_ROWS;
                     const int64_t i = ci - 16 + row;
+                    const bool in = t < PV_WINDOW_BYTES && i >= 0 && i < R;  // row R of the reference's matrix exists and is all zero (:835)
+                    const int64_t c2 = col_base + (in ? i : 0);
+                    // feature -> counter plane: REF count 4 / 15, symbol planes 8..14 / 19..25; the rest is written per candidate
+                    const int plane = pl == 4 ? C_PLANE : (pl >= 8 && pl <= 14) ? C_PLANE + 1 + (pl - 8)
+                                    : pl == 15 ? C_PLANE + 8 : pl >= 19 ? C_PLANE + 8 + 1 + (pl - 19) : -1;
                     int v = 0;
-                    if (i >= 0 && i < R) {  // row R of the reference's matrix exists and is all zero (:835)
-                        const int64_t c2 = col_base + i;
-                        if (pl == 0) v = refcode(a.in.ref[c2]);
-                        else if (pl == 4) v = a.cnt[(C_PLANE + 0) * NC + c2];
-                        else if (pl >= 8 && pl <= 14) v = a.cnt[(C_PLANE + 1 + (pl - 8)) * NC + c2];
-                        else if (pl == 15) v = a.cnt[(C_PLANE + 8) * NC + c2];
-                        else if (pl >= 19) v = a.cnt[(C_PLANE + 8 + 1 + (pl - 19)) * NC + c2];
+                    if (in && plane >= 0) v = a.cnt[(int64_t)plane * NC + c2];
+                    if (in && pl == 0) v = a.in.ref[c2];
+                    raw[u] = v;
+                }
+#pragma unroll
+                for (int u = 0; u < WW_TRIPS; u++) {
+                    const int t = lane + u * WW_THREADS;
+                    if (t >= PV_WINDOW_BYTES) continue;
+                    const int pl = t / PV_WINDOW_ROWS, row = t - pl * PV_WINDOW_ROWS;
+                    const int64_t i = ci - 16 + row;
+                    int v = raw[u];
+                    if (i >= 0 && i < R) {
+                        if (pl == 0) v = refcode(v);
                         if (pl >= 11 && pl <= 24) v = v > PV_MAX_COLOR ? PV_MAX_COLOR : (v < -PV_MAX_COLOR ? -PV_MAX_COLOR : v);  // :648-653
                     }
                     if (row == 16) {  // :848-894
@@ -1471,9 +1490,15 @@ __global__ __launch_bounds__(WW_THREADS) void k_write_windows(SumArgs a) {
                         if (pl == 18) v = crev;
                         if (refvalid && (pl == 14 || pl == 25)) v = -v;
                     }
+                    s_win[row * PV_FEATURES + pl] = v;
+                }
+                __syncthreads();
+                for (int el = lane; el < PV_WINDOW_BYTES; el += WW_THREADS) {
+                    const int v = s_win[el];
                     a.out.images[k * PV_WINDOW_BYTES + el] = (int8_t)(uint8_t)(v & 0xFF);  // DataStore.py:68 wrap
                     if (a.out.images_i32) a.out.images_i32[k * PV_WINDOW_BYTES + el] = v;
                 }
+                __syncthreads();
                 if (lane == 0) {
                     a.out.region[k] = g;
                     a.out.position[k] = a.in.ref_start[g] + ci;
@@ -1496,6 +1521,7 @@ __global__ __launch_bounds__(WW_THREADS) void k_write_windows(SumArgs a) {
 // Haplotag form of K8 (region_summary_hp.cpp:943-1003): 21 rows x 48 planes around the site, every plane clamped, the
 // five overlay values of the candidate on the middle row; no deletion tail, no sign flips.
 __global__ __launch_bounds__(WW_THREADS) void k_write_windows_hp(SumArgs a) {
+    __shared__ int32_t s_win[PV_HP_WINDOW_BYTES];
     const int lane = threadIdx.x;
     if (a.diag[D_STATUS] != 0) return;
     int64_t n_sites = a.diag[D_NSITES];
@@ -1522,18 +1548,33 @@ __global__ __launch_bounds__(WW_THREADS) void k_write_windows_hp(SumArgs a) {
                 const int t = rc.type;  // 1 SNP, 2 INS, 3 DEL
                 const int v1 = t == 1 ? refcode(a.in.bases[rc.src]) : (rc.len < PV_MAX_COLOR ? rc.len : PV_MAX_COLOR);
                 const uint32_t hc = (uint32_t)rc.fwd;  // forward set 1, forward set 2, reverse set 1, reverse set 2
-                for (int el = lane; el < PV_HP_WINDOW_BYTES; el += WW_THREADS) {
-                    const int row = el / PV_HP_FEATURES, pl = el - row * PV_HP_FEATURES;
+                // row fastest across lanes, every load requested before the first is used, window out through LDS (see
+                // k_write_windows)
+                constexpr int WW_TRIPS = (PV_HP_WINDOW_BYTES + WW_THREADS - 1) / WW_THREADS;
+                int raw[WW_TRIPS];
+#pragma unroll
+                for (int u = 0; u < WW_TRIPS; u++) {
+                    const int tt = lane + u * WW_THREADS;
+                    const int pl = tt / PV_HP_WINDOW_ROWS, row = tt - pl * PV_HP_WINDOW_ROWS;
                     const int64_t i = ci - MID + row;
+                    const bool in = tt < PV_HP_WINDOW_BYTES && i >= 0 && i < R;  // row R of the reference's matrix exists and is all zero
+                    const int64_t c2 = col_base + (in ? i : 0);
+                    const int grp = (pl - 4) / 11, w = (pl - 4) - 11 * grp;  // 0 REF count, 1-3 overlays, 4-10 symbols
+                    const int plane = pl < 4 ? -1 : (w == 0 ? HC_PLANE + 8 * grp : (w >= 4 ? HC_PLANE + 8 * grp + (w - 3) : -1));
                     int v = 0;
-                    if (i >= 0 && i < R) {  // row R of the reference's matrix exists and is all zero
-                        const int64_t c2 = col_base + i;
-                        if (pl == 0) v = refcode(a.in.ref[c2]);
-                        else if (pl >= 4) {
-                            const int grp = (pl - 4) / 11, w = (pl - 4) - 11 * grp;  // 0 REF count, 1-3 overlays, 4-10 symbols
-                            if (w == 0) v = a.cnt[(int64_t)(HC_PLANE + 8 * grp) * NC + c2];
-                            else if (w >= 4) v = a.cnt[(int64_t)(HC_PLANE + 8 * grp + (w - 3)) * NC + c2];
-                        }
+                    if (in && plane >= 0) v = a.cnt[(int64_t)plane * NC + c2];
+                    if (in && pl == 0) v = a.in.ref[c2];
+                    raw[u] = v;
+                }
+#pragma unroll
+                for (int u = 0; u < WW_TRIPS; u++) {
+                    const int tt = lane + u * WW_THREADS;
+                    if (tt >= PV_HP_WINDOW_BYTES) continue;
+                    const int pl = tt / PV_HP_WINDOW_ROWS, row = tt - pl * PV_HP_WINDOW_ROWS;
+                    const int64_t i = ci - MID + row;
+                    int v = raw[u];
+                    if (i >= 0 && i < R) {
+                        if (pl == 0) v = refcode(v);
                         v = v > PV_MAX_COLOR ? PV_MAX_COLOR : (v < -PV_MAX_COLOR ? -PV_MAX_COLOR : v);  // :762-767
                     }
                     if (row == MID) {  // :970-974, :983-987, :996-1000
@@ -1543,9 +1584,15 @@ __global__ __launch_bounds__(WW_THREADS) void k_write_windows_hp(SumArgs a) {
                         if (pl == 15 + t) v = (int)((hc >> 16) & 0xFF);
                         if (pl == 37 + t) v = (int)((hc >> 24) & 0xFF);
                     }
+                    s_win[row * PV_HP_FEATURES + pl] = v;
+                }
+                __syncthreads();
+                for (int el = lane; el < PV_HP_WINDOW_BYTES; el += WW_THREADS) {
+                    const int v = s_win[el];
                     a.out.images[k * PV_HP_WINDOW_BYTES + el] = (int8_t)(uint8_t)(v & 0xFF);
                     if (a.out.images_i32) a.out.images_i32[k * PV_HP_WINDOW_BYTES + el] = v;
                 }
+                __syncthreads();
                 if (lane == 0) {
                     a.out.region[k] = g;
                     a.out.position[k] = a.in.ref_start[g] + ci;
@@ -1969,8 +2016,11 @@ static int summarize_launch(pv_ctx* ctx, const pv_batch_in* in, const pv_params*
     k_scan_events<<<scan_chunks(a.max_sites), 1024, 0, st>>>(a);
     // per-site kernels are chains of dependent loads per wave: as many workgroups as can be resident (one site each for the
     // benchmark's ~8 k sites per launch)
-    const unsigned site_grid = (unsigned)(max_sites < 8192 ? (max_sites > 0 ? max_sites : 1) : 8192);
-    const unsigned collect_grid = site_grid < 4096 ? site_grid : 4096;   // measured: 0.083 ms with 4096 workgroups, 0.095 with 8192
+    // (swept in round 2, 2048 .. 32768 workgroups: k_collect and k_write_windows are flat from 4096 / 8192 up, k_site_alleles
+    // gains 5 us at 16384)
+    const unsigned site_grid = (unsigned)(max_sites < 16384 ? (max_sites > 0 ? max_sites : 1) : 16384);
+    const unsigned collect_grid = site_grid < 4096 ? site_grid : 4096;
+    const unsigned ww_grid = site_grid < 8192 ? site_grid : 8192;   // measured: 0.083 ms with 4096 workgroups, 0.095 with 8192
     if (n_cigar > 0 && n_reads > 0) { pv_prof_scope ps(ctx, "k_collect", st); k_collect<<<collect_grid, 64 * KC_WAVES, 0, st>>>(a); }
     {
         pv_prof_scope ps(ctx, "k_site_alleles", st);
@@ -1986,8 +2036,8 @@ static int summarize_launch(pv_ctx* ctx, const pv_batch_in* in, const pv_params*
     k_scan_outputs<<<scan_chunks(a.max_sites), 1024, 0, st>>>(a);
     {
         pv_prof_scope ps(ctx, "k_write_windows", st);
-        if (hp) k_write_windows_hp<<<site_grid, WW_THREADS, 0, st>>>(a);
-        else k_write_windows<<<site_grid, WW_THREADS, 0, st>>>(a);
+        if (hp) k_write_windows_hp<<<ww_grid, WW_THREADS, 0, st>>>(a);
+        else k_write_windows<<<ww_grid, WW_THREADS, 0, st>>>(a);
     }
     PV_HIP(hipGetLastError());
     return PV_OK;
