@@ -1104,6 +1104,13 @@ __global__ __launch_bounds__(1024) void k_site_rank(SumArgs a) {
 }
 
 // ---- K5 -------------------------------------------------------------------------------------------
+// Site-indexed kernels walk the site list XCD by XCD: workgroup b runs on XCD b & 7 (round-robin dispatch), so giving
+// each XCD one contiguous eighth of the sites, in order, keeps the sites of a tile - which read the same pair records,
+// the same op ranges (the upper probes of their binary searches are the same words) and neighbouring counter columns -
+// in ONE 4 MB L2 at about the same time instead of fetching them into up to eight. Grids are multiples of 8.
+__device__ __forceinline__ int64_t xcd_chunk(int64_t n_sites) { return (n_sites + 7) >> 3; }
+__device__ __forceinline__ int64_t xcd_site(int64_t j, int64_t n_sites) { return (int64_t)(blockIdx.x & 7) * xcd_chunk(n_sites) + j; }
+
 __device__ __forceinline__ void push_event(const SumArgs& a, int32_t s, int64_t src, int32_t len, int type, bool rev,
                                            int kind, int flags) {
     const int32_t slot = atomicAdd(&a.site_fill[s], 1);
@@ -1127,7 +1134,9 @@ __global__ __launch_bounds__(64 * KC_WAVES) void k_collect(SumArgs a) {
     int64_t n_sites = a.diag[D_NSITES];
     if (n_sites > a.max_sites) n_sites = a.max_sites;
     const int64_t NC = a.n_cols;
-    for (int64_t s = blockIdx.x; s < n_sites; s += gridDim.x) {
+    for (int64_t sj = blockIdx.x >> 3; sj < xcd_chunk(n_sites); sj += gridDim.x >> 3) {
+        const int64_t s = xcd_site(sj, n_sites);
+        if (s >= n_sites) break;
         const int64_t col = a.site_col[s];
         const int g = a.site_region[s];
         const int64_t col_base = a.in.ref_off[g];
@@ -1246,7 +1255,9 @@ __global__ __launch_bounds__(64) void k_site_alleles(SumArgs a) {
     if (a.diag[D_STATUS] != 0) return;
     int64_t n_sites = a.diag[D_NSITES];
     if (n_sites > a.max_sites) n_sites = a.max_sites;
-    for (int64_t s = blockIdx.x; s < n_sites; s += gridDim.x) {
+    for (int64_t sj = blockIdx.x >> 3; sj < xcd_chunk(n_sites); sj += gridDim.x >> 3) {
+        const int64_t s = xcd_site(sj, n_sites);
+        if (s >= n_sites) break;
         if ((a.site_nev[s] + 4 > UM_SMALL) != BIG) continue;   // the other instantiation's site
         const int64_t col = a.site_col[s];
         const int64_t NC = a.n_cols;
@@ -1405,7 +1416,9 @@ __global__ __launch_bounds__(WW_THREADS) void k_write_windows(SumArgs a) {
     int64_t n_sites = a.diag[D_NSITES];
     if (n_sites > a.max_sites) n_sites = a.max_sites;
     const int64_t NC = a.n_cols;
-    for (int64_t s = blockIdx.x; s < n_sites; s += gridDim.x) {
+    for (int64_t sj = blockIdx.x >> 3; sj < xcd_chunk(n_sites); sj += gridDim.x >> 3) {
+        const int64_t s = xcd_site(sj, n_sites);
+        if (s >= n_sites) break;
         const int nemit = a.site_nemit[s];
         if (nemit == 0) continue;
         const int64_t col = a.site_col[s];
@@ -1528,7 +1541,9 @@ __global__ __launch_bounds__(WW_THREADS) void k_write_windows_hp(SumArgs a) {
     if (n_sites > a.max_sites) n_sites = a.max_sites;
     const int64_t NC = a.n_cols;
     constexpr int MID = (PV_HP_WINDOW_ROWS - 1) / 2;
-    for (int64_t s = blockIdx.x; s < n_sites; s += gridDim.x) {
+    for (int64_t sj = blockIdx.x >> 3; sj < xcd_chunk(n_sites); sj += gridDim.x >> 3) {
+        const int64_t s = xcd_site(sj, n_sites);
+        if (s >= n_sites) break;
         const int nemit = a.site_nemit[s];
         if (nemit == 0) continue;
         const int64_t col = a.site_col[s];
@@ -2018,9 +2033,9 @@ static int summarize_launch(pv_ctx* ctx, const pv_batch_in* in, const pv_params*
     // benchmark's ~8 k sites per launch)
     // (swept in round 2, 2048 .. 32768 workgroups: k_collect and k_write_windows are flat from 4096 / 8192 up, k_site_alleles
     // gains 5 us at 16384)
-    const unsigned site_grid = (unsigned)(max_sites < 16384 ? (max_sites > 0 ? max_sites : 1) : 16384);
+    const unsigned site_grid = (unsigned)(max_sites < 16384 ? (max_sites > 0 ? (max_sites + 7) / 8 * 8 : 8) : 16384);   // multiples of 8: xcd_site()
     const unsigned collect_grid = site_grid < 4096 ? site_grid : 4096;
-    const unsigned ww_grid = site_grid < 8192 ? site_grid : 8192;   // measured: 0.083 ms with 4096 workgroups, 0.095 with 8192
+    const unsigned ww_grid = site_grid < 8192 ? site_grid : 8192;
     if (n_cigar > 0 && n_reads > 0) { pv_prof_scope ps(ctx, "k_collect", st); k_collect<<<collect_grid, 64 * KC_WAVES, 0, st>>>(a); }
     {
         pv_prof_scope ps(ctx, "k_site_alleles", st);
