@@ -435,6 +435,9 @@ __global__ __launch_bounds__(PT_THREADS, HP ? 2 : 4) void k_pileup_tiles(SumArgs
     if (tid < 256) s_lut[tid] = (uint8_t)(sym_of(tid) | (is_acgt(tid) ? 8 : 0) | ((tid != up(tid) && is_acgt(up(tid))) ? 16 : 0) | (is_acgt(up(tid)) ? 32 : 0));
     const int32_t p0 = a.tile_off[tile];
     const int32_t np = a.tile_cnt[tile];
+    // quality bar as a per-byte compare: q >= qmin  <=>  high bits decide, or are equal and the low seven bits decide
+    [[maybe_unused]] const uint32_t q_low = (uint32_t)(a.qmin_snp & 0x7F) * 0x01010101u;
+    [[maybe_unused]] const bool q_hi = a.qmin_snp >= 128, q_all = a.qmin_snp <= 0, q_none = a.qmin_snp > 255;
     __syncthreads();
     for (int32_t pb = 0; pb < np; pb += PT_PB) {
         const int npb = (np - pb) < PT_PB ? (np - pb) : PT_PB;
@@ -671,49 +674,76 @@ __global__ __launch_bounds__(PT_THREADS, HP ? 2 : 4) void k_pileup_tiles(SumArgs
                     g[u].rw = (uint32_t)s_ref[lcr] | ((uint32_t)s_ref[lcr + 1] << 8) | ((uint32_t)s_ref[lcr + 2] << 16) | ((uint32_t)s_ref[lcr + 3] << 24);
                 }
             };
+            // general classification of one counted base (any byte over any reference byte), :379-423
+            auto count_general = [&](const Grp& G, int e, int st) {
+                const int base = (G.bw >> (8 * e)) & 0xFF, refb = (G.rw >> (8 * e)) & 0xFF;
+                const int lc = G.lc + e;
+                const int cb = s_lut[base];
+                const bool refvalid = (s_lut[refb] & 32) != 0;
+                const int sy = cb & 7;                                           // 1..7
+                if (refvalid && sy <= 4) {
+                    atomicAdd(&s_cnt[L_P + 4 * st + (sy - 1)][SW(lc)], 1);       // :379 + :381-391 + :396,423 in one
+                } else {
+                    atomicAdd(&s_cnt[L_X + st][SW(lc)], 1);
+                    if (refvalid) atomicAdd(&s_cnt[L_O + 3 * st + (sy - 5)][SW(lc)], 1);
+                }
+                if (e == G.last) atomicAdd(&s_cnt[L_ANC + st][SW(lc)], 1);
+                const bool mism = refb != base;                                  // raw bytes, :394
+                if (mism) atomicAdd(&s_cnt[L_SNP][SW(lc)], 1);
+                const bool rare = mism && !(refvalid && (cb & 8));
+                const bool corr = refvalid && (cb & 16);
+                if (rare || corr) atomicAdd(&s_cnt[L_RARE][SW(lc)], 1);
+            };
             auto count = [&](const Grp (&g)[PT_GPL]) {
 #pragma unroll
                 for (int u = 0; u < PT_GPL; u++) {
+                    if constexpr (HP) {  // region_summary_hp.cpp:393-463
 #pragma unroll
-                    for (int e = 0; e < 4; e++) {
-                        const int base = (g[u].bw >> (8 * e)) & 0xFF, refb = (g[u].rw >> (8 * e)) & 0xFF;
-                        const int q = (g[u].qw >> (8 * e)) & 0xFF;
-                        if (e >= g[u].nv || q < a.qmin_snp) continue;
-                        const int lc = g[u].lc + e;
-                        if constexpr (HP) {  // region_summary_hp.cpp:393-463
+                        for (int e = 0; e < 4; e++) {
+                            const int base = (g[u].bw >> (8 * e)) & 0xFF, refb = (g[u].rw >> (8 * e)) & 0xFF;
+                            const int q = (g[u].qw >> (8 * e)) & 0xFF;
+                            if (e >= g[u].nv || q < a.qmin_snp) continue;
+                            const int lc = g[u].lc + e;
                             const int st = g[u].fl & 1, cs = (g[u].fl >> 2) & 3, ss = (g[u].fl >> 4) & 3;
                             atomicAdd(&s_cnt[HL_REFC + 2 * cs + st][SW(lc)], 1);
                             if (refb != base) atomicAdd(&s_cnt[HL_SNP][SW(lc)], 1);                       // raw bytes, :406
                             else if (s_lut[refb] & 32) atomicAdd(&s_cnt[HL_M + 2 * (ss - 1) + st][SW(lc)], 1);
-                        } else {
-                        const int st = g[u].fl;
-                        // the usual base - A/C/G/T in upper case over an A/C/G/T reference (either case) - is classified
-                        // arithmetically: no table reads (two dependent LDS round trips per base) and one short masked region
-                        const unsigned tb = (unsigned)base - 0x41u, tr = ((unsigned)refb & 0xDFu) - 0x41u;
-                        const bool b_up = tb < 20u && ((0x80045u >> tb) & 1u);           // 'A' 'C' 'G' 'T': bits 0, 2, 6, 19
-                        const bool r_ok = tr < 20u && ((0x80045u >> tr) & 1u);           // A C G T a c g t
-                        if (b_up && r_ok) {
-                            const unsigned x = ((unsigned)base >> 1) & 3u;               // A 0, C 1, T 2, G 3
-                            atomicAdd(&s_cnt[L_P + 4 * st + (int)(x ^ (x >> 1))][SW(lc)], 1);   // -> A 0, C 1, G 2, T 3
-                            if (e == g[u].last) atomicAdd(&s_cnt[L_ANC + st][SW(lc)], 1);
-                            if (refb != base) atomicAdd(&s_cnt[L_SNP][SW(lc)], 1);       // raw bytes, :394 (never rare: both are A/C/G/T)
-                            continue;
                         }
-                        const int cb = s_lut[base];
-                        const bool refvalid = (s_lut[refb] & 32) != 0;
-                        const int sy = cb & 7;                                           // 1..7
-                        if (refvalid && sy <= 4) {
-                            atomicAdd(&s_cnt[L_P + 4 * st + (sy - 1)][SW(lc)], 1);       // :379 + :381-391 + :396,423 in one
-                        } else {
-                            atomicAdd(&s_cnt[L_X + st][SW(lc)], 1);
-                            if (refvalid) atomicAdd(&s_cnt[L_O + 3 * st + (sy - 5)][SW(lc)], 1);
+                    } else {
+                        // The four bases of a group are classified together, a byte per base in 32-bit operations (bit 7 of a byte =
+                        // the answer for that base), so that the usual base - A/C/G/T in upper case over an A/C/G/T reference of
+                        // either case, quality passing - costs a bit test, an address and its one ds_add; bases that are anything
+                        // else take count_general, one by one.
+                        const Grp& G = g[u];
+                        constexpr uint32_t H = 0x80808080u;
+                        auto nonzero = [](uint32_t z) { return (((z & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | z) & 0x80808080u; };
+                        const uint32_t tq = (G.qw | H) - q_low;                              // bit 7: low seven bits of q >= those of qmin
+                        uint32_t ge = q_hi ? (G.qw & tq) : (G.qw | tq);
+                        ge = q_all ? H : (q_none ? 0u : ge);
+                        const uint32_t vm = G.nv >= 4 ? H : ((H >> 8) >> (24 - 8 * (G.nv < 0 ? 0 : G.nv)));   // the group's valid bases
+                        const uint32_t ok = ge & vm;
+                        const uint32_t selb = (G.bw >> 1) & 0x03030303u;                     // A 0, C 1, T 2, G 3
+                        const uint32_t b_bad = nonzero(__builtin_amdgcn_perm(0u, 0x47544341u, selb) ^ G.bw);
+                        const uint32_t rwu = G.rw & 0xDFDFDFDFu;
+                        const uint32_t r_bad = nonzero(__builtin_amdgcn_perm(0u, 0x47544341u, (rwu >> 1) & 0x03030303u) ^ rwu);
+                        const uint32_t fast = ok & ~(b_bad | r_bad);
+                        const uint32_t slow = ok & (b_bad | r_bad);
+                        const uint32_t mism = nonzero(G.bw ^ G.rw) & fast;                   // raw bytes, :394 (never rare: both are A/C/G/T)
+                        const uint32_t pidx = selb ^ ((selb >> 1) & 0x01010101u);            // -> A 0, C 1, G 2, T 3
+                        const int st = G.fl;
+#pragma unroll
+                        for (int e = 0; e < 4; e++) {
+                            if (fast & (0x80u << (8 * e))) {
+                                const int lc = G.lc + e;
+                                atomicAdd(&s_cnt[L_P + 4 * st + (int)((pidx >> (8 * e)) & 3u)][SW(lc)], 1);
+                                if (mism & (0x80u << (8 * e))) atomicAdd(&s_cnt[L_SNP][SW(lc)], 1);
+                            }
                         }
-                        if (e == g[u].last) atomicAdd(&s_cnt[L_ANC + st][SW(lc)], 1);
-                        const bool mism = refb != base;                                  // raw bytes, :394
-                        if (mism) atomicAdd(&s_cnt[L_SNP][SW(lc)], 1);
-                        const bool rare = mism && !(refvalid && (cb & 8));
-                        const bool corr = refvalid && (cb & 16);
-                        if (rare || corr) atomicAdd(&s_cnt[L_RARE][SW(lc)], 1);
+                        if ((unsigned)G.last < 4u && ((fast >> (8 * G.last + 7)) & 1u)) atomicAdd(&s_cnt[L_ANC + st][SW(G.lc + G.last)], 1);
+                        if (slow) {
+#pragma unroll
+                            for (int e = 0; e < 4; e++)
+                                if (slow & (0x80u << (8 * e))) count_general(G, e, st);
                         }
                     }
                 }
