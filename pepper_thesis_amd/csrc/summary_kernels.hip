@@ -320,7 +320,8 @@ constexpr int PT_PB = 128;  // pairs per batch
 constexpr int PT_GPL = 2;   // groups of 4 consecutive bases per thread per trip (groups strided by the block size)
 // counters of a tile live in LDS with the column index swizzled so that the 64 lanes of a wave, which hold columns
 // c, c+4, c+8, ... for the same group element, hit 64 consecutive banks
-#define SW(lc) ((((lc) & 3) << 7) | ((lc) >> 2))
+// (= ((lc & 3) << 7) | (lc >> 2) for 0 <= lc < 512, as one multiply-add and one bit-field extract: lc * 513 = lc | lc << 9)
+#define SW(lc) ((int)((((unsigned)(lc) * 513u) >> 2) & 511u))
 static_assert(TILE_COLS == 512, "SW() assumes 512-column tiles");
 
 __device__ __forceinline__ int block_incl_scan512(int v, int* s_wsum, int tid) {
@@ -731,15 +732,20 @@ __global__ __launch_bounds__(PT_THREADS, HP ? 2 : 4) void k_pileup_tiles(SumArgs
                         const uint32_t mism = nonzero(G.bw ^ G.rw) & fast;                   // raw bytes, :394 (never rare: both are A/C/G/T)
                         const uint32_t pidx = selb ^ ((selb >> 1) & 0x01010101u);            // -> A 0, C 1, G 2, T 3
                         const int st = G.fl;
+                        // no branches: a base that does not count adds ZERO (SW() keeps any column inside the plane, the plane
+                        // index is two bits of the byte), which costs the LDS nothing it was not already doing - some lane of
+                        // the wave nearly always counts - and saves the exec-mask bookkeeping per base
 #pragma unroll
                         for (int e = 0; e < 4; e++) {
-                            if (fast & (0x80u << (8 * e))) {
-                                const int lc = G.lc + e;
-                                atomicAdd(&s_cnt[L_P + 4 * st + (int)((pidx >> (8 * e)) & 3u)][SW(lc)], 1);
-                                if (mism & (0x80u << (8 * e))) atomicAdd(&s_cnt[L_SNP][SW(lc)], 1);
-                            }
+                            const int sw = SW(G.lc + e);
+                            atomicAdd(&s_cnt[L_P + 4 * st + (int)((pidx >> (8 * e)) & 3u)][sw], (int)((fast >> (8 * e + 7)) & 1u));
+                            atomicAdd(&s_cnt[L_SNP][sw], (int)((mism >> (8 * e + 7)) & 1u));
                         }
-                        if ((unsigned)G.last < 4u && ((fast >> (8 * G.last + 7)) & 1u)) atomicAdd(&s_cnt[L_ANC + st][SW(G.lc + G.last)], 1);
+                        {
+                            const unsigned la = (unsigned)G.last < 4u ? (unsigned)G.last : 0u;
+                            const int inc = (unsigned)G.last < 4u ? (int)((fast >> (8 * la + 7)) & 1u) : 0;
+                            atomicAdd(&s_cnt[L_ANC + st][SW(G.lc + (int)la)], inc);
+                        }
                         if (slow) {
 #pragma unroll
                             for (int e = 0; e < 4; e++)
