@@ -402,18 +402,22 @@ __device__ __forceinline__ uint8_t site_flag(const SumArgs& a, const SiteRegion&
 template <bool HP>
 __global__ __launch_bounds__(PT_THREADS, HP ? 2 : 4) void k_pileup_tiles(SumArgs a) {   // 26-plane form: two workgroups per CU (<= 128 VGPRs)
     __shared__ int32_t s_cnt[HP ? (int)HL_N : (int)L_N][TILE_COLS];
-    __shared__ uint8_t s_ref[TILE_COLS + 4];  // the tile's reference bytes (+4: a padded group may look past the tile)
+    __shared__ __attribute__((aligned(4))) uint8_t s_ref[TILE_COLS + 8];  // the tile's reference bytes (+8: a padded group may look past the tile, and is read as two words)
     __shared__ uint8_t s_lut[256];           // byte class: bits0-2 plane symbol 1..7, 8 = upper ACGT, 16 = lower acgt, 32 = valid reference
     __shared__ uint16_t s_blk[PT_THREADS * (TILE_COLS + 4) / 64 + 2];  // op that owns the first slot of every 64-slot block
     // per-op staging (one op batch)
     __shared__ int32_t s_pref[PT_THREADS];   // inclusive prefix of the in-tile aligned bases, every op padded to whole groups of 4
-    __shared__ int32_t s_iend[PT_THREADS];   // one past the op's last in-tile base offset
-    __shared__ int32_t s_col0[PT_THREADS];   // global column of op offset 0
-    __shared__ int64_t s_base[PT_THREADS];   // global base index of op offset 0
-    __shared__ int32_t s_i0[PT_THREADS];     // i = j + s_i0
-    __shared__ int32_t s_meta[PT_THREADS];   // len-1
-    __shared__ uint8_t s_opfl[PT_THREADS];   // bit0 rev, bit1 anchor_next
-    __shared__ uint8_t s_opair[PT_THREADS];  // pair slot of the op (for seq_end)
+    // what the expansion needs of an op, as one 32-byte record (two ds_read_b128 per group instead of nine scalar reads):
+    struct OpSt {
+        int32_t i0s;     // i = j + i0s: offset in the op of slot j
+        int32_t iend;    // one past the op's last in-tile base offset
+        int32_t lcoff;   // tile-local column of op offset 0
+        int32_t meta;    // len - 1
+        int32_t base_lo, base_hi;  // global base index of op offset 0
+        int32_t bleft;   // bases from there to the end of the read's sequence (saturated)
+        int32_t fl;      // bit0 rev, bit1 anchor_next, haplotag form: bits 2-5
+    };
+    __shared__ __attribute__((aligned(16))) OpSt s_op[PT_THREADS];
     // per-pair staging (one pair batch)
     __shared__ int32_t p_off[PT_PB + 1];     // exclusive prefix of op counts
     __shared__ int32_t p_oplo[PT_PB], p_colbase[PT_PB], p_R[PT_PB], p_clast[PT_PB], p_reflen[PT_PB], p_rev[PT_PB];
@@ -432,7 +436,7 @@ __global__ __launch_bounds__(PT_THREADS, HP ? 2 : 4) void k_pileup_tiles(SumArgs
     __shared__ SiteRegion s_sreg;  // region of the tile's first column, for the flush (looked up by k_init)
     if (tid == 0) s_sreg = site_region_load(a, a.tile_g0[tile]);
     for (int i = tid; i < (HP ? (int)HL_N : (int)L_N) * TILE_COLS; i += PT_THREADS) (&s_cnt[0][0])[i] = 0;
-    for (int i = tid; i < TILE_COLS + 4; i += PT_THREADS) s_ref[i] = (i < TILE_COLS && tlo + i < a.n_cols) ? a.in.ref[tlo + i] : (uint8_t)'N';
+    for (int i = tid; i < TILE_COLS + 8; i += PT_THREADS) s_ref[i] = (i < TILE_COLS && tlo + i < a.n_cols) ? a.in.ref[tlo + i] : (uint8_t)'N';
     if (tid < 256) s_lut[tid] = (uint8_t)(sym_of(tid) | (is_acgt(tid) ? 8 : 0) | ((tid != up(tid) && is_acgt(up(tid))) ? 16 : 0) | (is_acgt(up(tid)) ? 32 : 0));
     const int32_t p0 = a.tile_off[tile];
     const int32_t np = a.tile_cnt[tile];
@@ -624,13 +628,21 @@ __global__ __launch_bounds__(PT_THREADS, HP ? 2 : 4) void k_pileup_tiles(SumArgs
             const int32_t effp = (eff + 3) & ~3;
             const int32_t incl = block_incl_scan512(effp, s_wsum, tid);
             s_pref[tid] = incl;
-            s_col0[tid] = col_base + ref_rel;
-            s_base[tid] = (k < total_ops ? p_base0[pslot] : 0) + rd;
-            s_i0[tid] = i0 - (incl - effp);
-            s_iend[tid] = i0 + eff;
-            s_meta[tid] = len - 1;
-            s_opfl[tid] = (uint8_t)((rev ? 1 : 0) | (anchor_next ? 2 : 0) | (HP ? hpbits << 2 : 0));
-            s_opair[tid] = (uint8_t)pslot;
+            {
+                const int64_t base = (k < total_ops ? p_base0[pslot] : 0) + rd;
+                int64_t bleft = (k < total_ops ? p_seqend[pslot] : 0) - base;
+                bleft = bleft > 0x7fffffff ? 0x7fffffff : (bleft < -0x7fffffff ? -0x7fffffff : bleft);
+                OpSt o;
+                o.i0s = i0 - (incl - effp);
+                o.iend = i0 + eff;
+                o.lcoff = (int32_t)((int64_t)col_base + ref_rel - tlo);
+                o.meta = len - 1;
+                o.base_lo = (int32_t)(uint32_t)base;
+                o.base_hi = (int32_t)(base >> 32);
+                o.bleft = (int32_t)bleft;
+                o.fl = (rev ? 1 : 0) | (anchor_next ? 2 : 0) | (HP ? hpbits << 2 : 0);
+                s_op[tid] = o;
+            }
             for (int32_t bb = (incl - effp + 63) >> 6; (bb << 6) < incl; bb++) s_blk[bb] = (uint16_t)tid;  // blocks starting inside this op
             __syncthreads();
             const int32_t total = s_pref[PT_THREADS - 1];
@@ -646,18 +658,19 @@ __global__ __launch_bounds__(PT_THREADS, HP ? 2 : 4) void k_pileup_tiles(SumArgs
                     const bool ok = j < total;
                     int owc = ok ? s_blk[j >> 6] : 0;  // owner of the block's first slot, then a short probe
                     while (ok && s_pref[owc] <= j) owc++;
-                    const int32_t i = j + s_i0[owc];
-                    int nv = s_iend[owc] - i;          // valid bases of the group (the rest is padding)
+                    const OpSt o = s_op[owc];
+                    const int32_t i = j + o.i0s;
+                    int nv = o.iend - i;               // valid bases of the group (the rest is padding)
                     nv = ok ? (nv > 4 ? 4 : nv) : 0;
-                    const int64_t bi = s_base[owc] + i;
-                    const int64_t left = p_seqend[s_opair[owc]] - bi;
+                    const int64_t bi = (int64_t)(((uint64_t)(uint32_t)o.base_hi << 32) | (uint32_t)o.base_lo) + i;
+                    const int64_t left = (int64_t)o.bleft - i;
                     if (nv > 0 && nv > left) { set_status(a.diag, PV_ERR_INVALID); nv = left > 0 ? (int)left : 0; }
-                    const int lc = (int)((int64_t)s_col0[owc] + i - tlo);
+                    const int lc = o.lcoff + i;
                     g[u].lc = lc;
                     g[u].nv = nv;
-                    const int f = s_opfl[owc];
+                    const int f = o.fl;
                     g[u].fl = HP ? f : (f & 1);
-                    g[u].last = (f & 2) ? s_meta[owc] - i : -1;  // group position of the op's last base, if that base anchors an indel
+                    g[u].last = (f & 2) ? o.meta - i : -1;  // group position of the op's last base, if that base anchors an indel
                     uint32_t b4 = 0, q4 = 0;
                     if (nv > 0) {
                         if (bi + 4 <= a.n_bases) {  // unaligned dword loads
@@ -671,8 +684,9 @@ __global__ __launch_bounds__(PT_THREADS, HP ? 2 : 4) void k_pileup_tiles(SumArgs
                         }
                     }
                     g[u].bw = b4; g[u].qw = q4;
-                    const int lcr = nv > 0 ? lc : 0;
-                    g[u].rw = (uint32_t)s_ref[lcr] | ((uint32_t)s_ref[lcr + 1] << 8) | ((uint32_t)s_ref[lcr + 2] << 16) | ((uint32_t)s_ref[lcr + 3] << 24);
+                    const int lcr = nv > 0 ? lc : 0;   // four reference bytes from lcr on: two aligned words, shifted together
+                    const uint32_t* rwp = reinterpret_cast<const uint32_t*>(s_ref) + (lcr >> 2);
+                    g[u].rw = __builtin_amdgcn_alignbyte(rwp[1], rwp[0], (unsigned)lcr & 3u);
                 }
             };
             // general classification of one counted base (any byte over any reference byte), :379-423
