@@ -512,32 +512,75 @@ __global__ __launch_bounds__(PT_THREADS, HP ? 2 : 4) void k_pileup_tiles(SumArgs
                 if (chi > p_R[pslot] - 1) chi = p_R[pslot] - 1;
             }
             [[maybe_unused]] const int so = L_O + (rev ? 3 : 0);
-            // (1) indel ops; an op belongs to the tile that owns its anchor column
-            if constexpr (HP) {
-                const int st = rev ? 1 : 0, ss = hpbits >> 2;
-                if (active && op == PV_CIGAR_IN) {  // region_summary_hp.cpp:469-553
-                    const int64_t anchor = (int64_t)ref_rel - 1;
-                    if (anchor >= clo && anchor <= chi && rd >= 1) {
-                        const int lc = (int)(col_base + anchor - tlo);
-                        const int64_t start = p_base0[pslot] + rd;  // first inserted base; the allele starts one base earlier
-                        if (start + len > p_seqend[pslot]) {
-                            set_status(a.diag, PV_ERR_INVALID);
+            // (0) an insert anchored in this tile: the qualities of its anchor base and its inserted bases (bytes [start, start + L),
+            // start = the base before the insert, L = len + 1) are REQUESTED here and - haplotag form - used behind the scans and the
+            // staging below: the one HBM round trip of this phase that nothing used to cover
+            bool ins_here = false, ins_long = false;   // (start and column are recomputed when used: the kernel sits at its register cap)
+            uint32_t ins_qlo = 0, ins_qhi = 0;
+            if (active && op == PV_CIGAR_IN) {  // region_summary.cpp:431-490 / region_summary_hp.cpp:469-553
+                const int64_t anchor = (int64_t)ref_rel - 1;
+                if (anchor >= clo && anchor <= chi && rd >= 1) {
+                    const int64_t ins_start = p_base0[pslot] + rd - 1;
+                    const int64_t L = (int64_t)len + 1;
+                    if (ins_start + L > p_seqend[pslot]) {
+                        set_status(a.diag, PV_ERR_INVALID);
+                    } else {
+                        ins_here = true;
+                        if (L <= 8 && ins_start + 8 <= a.n_bases) {  // the usual short insert: ONE round trip instead of L dependent ones
+                            ins_qlo = *reinterpret_cast<const uint32_t*>(a.in.quals + ins_start);
+                            ins_qhi = *reinterpret_cast<const uint32_t*>(a.in.quals + ins_start + 4);
                         } else {
-                            int64_t qs = 0;
-                            for (int64_t i = 0; i < len; i++) qs += a.in.quals[start + i];  // inserted bases only, :482-484
-                            const bool qok = (double)qs >= a.p.min_indel_baseq * (double)len;
-                            if (!qok && (double)a.in.quals[start - 1] >= a.p.min_snp_baseq) atomicAdd(&s_cnt[HL_COVD][SW(lc)], 1);
-                            if (2 + (int64_t)len <= PV_MAX_ALLELE_KEY && qok) {
-                                if (is_acgt(up(s_ref[lc]))) {
-                                    if (ss & 1) atomicAdd(&s_cnt[HL_O + (0 + st) * 3 + 0][SW(lc)], 1);
-                                    if (ss & 2) atomicAdd(&s_cnt[HL_O + (2 + st) * 3 + 0][SW(lc)], 1);
-                                }
-                                atomicAdd(&s_cnt[HL_INS][SW(lc)], 1);
-                                a.op_flag[c] = 1;
-                            }
+                            ins_long = true;
                         }
                     }
-                } else if (active && op == PV_CIGAR_DEL) {  // :556-649
+                }
+            }
+            auto ins_use = [&]() {
+                if (!ins_here) return;
+                const int64_t L = (int64_t)len + 1;
+                int64_t qs_all = 0;   // anchor base + inserted bases
+                int q0;               // the anchor base
+                if (!ins_long) {
+                    uint32_t lo = ins_qlo, hi = ins_qhi;
+                    if (L <= 4) { hi = 0; if (L < 4) lo &= (1u << (8 * (int)L)) - 1u; }
+                    else if (L < 8) hi &= (1u << (8 * ((int)L - 4))) - 1u;
+                    q0 = (int)(lo & 0xFF);
+                    qs_all = (int64_t)__builtin_amdgcn_sad_u8(lo, 0u, __builtin_amdgcn_sad_u8(hi, 0u, 0u));
+                } else {
+                    const int64_t ins_start = p_base0[pslot] + rd - 1;
+                    for (int64_t i = 0; i < L; i++) qs_all += a.in.quals[ins_start + i];
+                    q0 = a.in.quals[ins_start];
+                }
+                const int lc = (int)((int64_t)col_base + ref_rel - 1 - tlo);
+                if constexpr (HP) {
+                    const int st = rev ? 1 : 0, ss = hpbits >> 2;
+                    const bool qok = (double)(qs_all - q0) >= a.p.min_indel_baseq * (double)len;   // inserted bases only, :482-484
+                    if (!qok && (double)q0 >= a.p.min_snp_baseq) atomicAdd(&s_cnt[HL_COVD][SW(lc)], 1);
+                    if (2 + (int64_t)len <= PV_MAX_ALLELE_KEY && qok) {
+                        if (is_acgt(up(s_ref[lc]))) {
+                            if (ss & 1) atomicAdd(&s_cnt[HL_O + (0 + st) * 3 + 0][SW(lc)], 1);
+                            if (ss & 2) atomicAdd(&s_cnt[HL_O + (2 + st) * 3 + 0][SW(lc)], 1);
+                        }
+                        atomicAdd(&s_cnt[HL_INS][SW(lc)], 1);
+                        a.op_flag[c] = 1;
+                    }
+                } else {
+                    const bool qok = (double)qs_all >= a.p.min_indel_baseq * (double)L;
+                    if (qok && (double)q0 < a.p.min_snp_baseq) atomicAdd(&s_cnt[L_COVI][SW(lc)], 1);  // :453
+                    if (1 + L <= PV_MAX_ALLELE_KEY && qok) {
+                        if (is_acgt(up(s_ref[lc]))) atomicAdd(&s_cnt[so + 0][SW(lc)], 1);
+                        atomicAdd(&s_cnt[L_INS][SW(lc)], 1);
+                        a.op_flag[c] = 1;
+                    }
+                }
+            };
+            // The 26-plane form sits at its 128-register cap (two more live values spill): it uses the words at once, as before;
+            // the haplotag form (one workgroup per CU, 256 registers) uses them behind the scans.
+            if constexpr (!HP) ins_use();
+            // (1) delete ops; an op belongs to the tile that owns its anchor column
+            if constexpr (HP) {
+                const int st = rev ? 1 : 0, ss = hpbits >> 2;
+                if (active && op == PV_CIGAR_DEL) {  // :556-649
                     const int64_t anchor = (int64_t)ref_rel - 1;
                     if (anchor >= clo && anchor <= chi) {
                         const int lc = (int)(col_base + anchor - tlo);
@@ -563,38 +606,7 @@ __global__ __launch_bounds__(PT_THREADS, HP ? 2 : 4) void k_pileup_tiles(SumArgs
                     }
                 }
             } else {
-            if (active && op == PV_CIGAR_IN) {  // :431-490
-                const int64_t anchor = (int64_t)ref_rel - 1;
-                if (anchor >= clo && anchor <= chi && rd >= 1) {
-                    const int lc = (int)(col_base + anchor - tlo);
-                    const int64_t start = p_base0[pslot] + rd - 1;
-                    const int64_t L = (int64_t)len + 1;
-                    if (start + L > p_seqend[pslot]) {
-                        set_status(a.diag, PV_ERR_INVALID);
-                    } else {
-                        int64_t qs = 0;
-                        int q0;
-                        if (L <= 8 && start + 8 <= a.n_bases) {  // the usual short insert: ONE round trip instead of L dependent ones
-                            uint32_t lo = *reinterpret_cast<const uint32_t*>(a.in.quals + start);
-                            uint32_t hi = *reinterpret_cast<const uint32_t*>(a.in.quals + start + 4);
-                            if (L <= 4) { hi = 0; if (L < 4) lo &= (1u << (8 * (int)L)) - 1u; }
-                            else if (L < 8) hi &= (1u << (8 * ((int)L - 4))) - 1u;
-                            q0 = (int)(lo & 0xFF);
-                            qs = (int64_t)__builtin_amdgcn_sad_u8(lo, 0u, __builtin_amdgcn_sad_u8(hi, 0u, 0u));
-                        } else {
-                            for (int64_t i = 0; i < L; i++) qs += a.in.quals[start + i];
-                            q0 = a.in.quals[start];
-                        }
-                        const bool qok = (double)qs >= a.p.min_indel_baseq * (double)L;
-                        if (qok && (double)q0 < a.p.min_snp_baseq) atomicAdd(&s_cnt[L_COVI][SW(lc)], 1);  // :453
-                        if (1 + L <= PV_MAX_ALLELE_KEY && qok) {
-                            if (is_acgt(up(s_ref[lc]))) atomicAdd(&s_cnt[so + 0][SW(lc)], 1);
-                            atomicAdd(&s_cnt[L_INS][SW(lc)], 1);
-                            a.op_flag[c] = 1;
-                        }
-                    }
-                }
-            } else if (active && op == PV_CIGAR_DEL) {  // :491-555
+            if (active && op == PV_CIGAR_DEL) {  // :491-555
                 const int64_t anchor = (int64_t)ref_rel - 1;
                 if (anchor >= clo && anchor <= chi) {
                     const int lc = (int)(col_base + anchor - tlo);
@@ -646,6 +658,7 @@ __global__ __launch_bounds__(PT_THREADS, HP ? 2 : 4) void k_pileup_tiles(SumArgs
             for (int32_t bb = (incl - effp + 63) >> 6; (bb << 6) < incl; bb++) s_blk[bb] = (uint16_t)tid;  // blocks starting inside this op
             __syncthreads();
             const int32_t total = s_pref[PT_THREADS - 1];
+            if constexpr (HP) ins_use();   // (0, continued) the insert's qualities have arrived by now
             PSTAMP(2)  // scan + staging + barrier
             // ---- expansion: PT_GPL groups of 4 consecutive bases per thread per trip; the owner lookups and the loads of
             // trip t+1 are issued before trip t is counted, so the HBM round trip of the bases hides behind the ds_adds ----
