@@ -212,15 +212,11 @@ __global__ __launch_bounds__(256) void k_cigar_scan(SumArgs a) {
     if (!skip && !a.polish && a.in.base_off[r + 1] - a.in.base_off[r] <= 0 && lane == 0) set_status(a.diag, PV_ERR_INVALID);
     int64_t ref_rel = a.in.read_pos[r] - a.in.ref_start[g];
     int64_t rd = 0;
-    // the CIGAR words of the next two 64-op trips are requested before this trip's scan: a trip is otherwise one exposed
-    // round trip (load -> scans -> stores), ~15 of them in a row for a 10 kb read
-    uint32_t w_n1 = c0 + lane < c1 ? a.in.cigar[c0 + lane] : 0u;
-    uint32_t w_n2 = c0 + 64 + lane < c1 ? a.in.cigar[c0 + 64 + lane] : 0u;
-    for (int64_t cb = c0; cb < c1; cb += 64) {
+    // Two trips of 64 ops per loop pass, each with its own CIGAR-word register that is reloaded (for two trips on) right
+    // after its trip has used it: the words are requested about one and a half trips ahead and no copy between registers
+    // makes the wave wait for a load it has just issued (a rotating pair did: s_waitcnt vmcnt(0) at every loop end).
+    auto trip = [&](const uint32_t w, const int64_t cb) {
         const int64_t c = cb + lane;
-        const uint32_t w = w_n1;
-        w_n1 = w_n2;
-        w_n2 = c + 128 < c1 ? a.in.cigar[c + 128] : 0u;
         const int op = w & 0xF;
         const int64_t len = c < c1 ? (int64_t)(w >> 4) : 0;
         const bool cr = (op == 0 || op == 7 || op == 8 || op == 2 || op == 3 || op == 6);
@@ -248,6 +244,15 @@ __global__ __launch_bounds__(256) void k_cigar_scan(SumArgs a) {
         }
         ref_rel += last_lane(ir);
         rd += last_lane(iq);
+    };
+    auto fetch = [&](int64_t cb) -> uint32_t { return cb + lane < c1 ? a.in.cigar[cb + lane] : 0u; };
+    uint32_t w_a = fetch(c0), w_b = fetch(c0 + 64);
+    for (int64_t cb = c0; cb < c1; cb += 128) {
+        trip(w_a, cb);
+        w_a = fetch(cb + 128);
+        if (cb + 64 >= c1) break;
+        trip(w_b, cb + 64);
+        w_b = fetch(cb + 192);
     }
     // Column span that this read can touch: every effect of populate_summary_matrix lies between the
     // column before its first position (an insert anchored at pos-1 after a leading soft clip) and its
