@@ -19,7 +19,7 @@
 //   k_pileup_tiles   workgroup per tile: counters in LDS, aligned bases dealt to lanes in padded groups of 4
 //   (site flags: frequency thresholds per column, per-tile site counts - in the flush of k_pileup_tiles)
 //   k_scan_*         single-block exclusive scans (tiny arrays)
-//   k_site_rank      column -> site rank, site list, per-site event bucket sizes
+//   k_site_rank      site columns -> site list (rank = tile offset + rank inside the 1024-column block), per-site event bucket sizes
 //   k_collect        wave per site, lane per overlapping read: the read's ops at that column by binary search; allele events
 //   k_site_alleles   wave per site: dedupe + order alleles like std::set<std::string>, filters
 //   k_write_windows  wave per site: gather 33x26, clamp, overlays, int8 cast, metadata, keys
@@ -97,7 +97,6 @@ struct SumArgs {
     int32_t qmin_snp;    // smallest integer quality q with (double)q >= min_snp_baseq (exact: q is an integer)
     int32_t* cnt;
     uint8_t* flags;
-    int32_t* site_rank;
     int32_t* blk_cnt;
     int32_t* blk_off;
     int32_t* site_col;
@@ -267,26 +266,73 @@ __global__ __launch_bounds__(256) void k_cigar_scan(SumArgs a) {
     for (int32_t t = t0 + lane; t <= t1; t += 64) atomicAdd(&a.tile_cnt[t], 1);
 }
 
-// One wave per read, one lane per overlapped tile: claim a slot in the tile's pair list and record the
-// op range [op_lo, op_hi) of the read that can touch the tile (binary searches over the per-op start
-// columns; an op starting one column past the tile may still anchor an indel on the tile's last column).
+// One wave per read: claim a slot in the pair list of every tile the read overlaps and record the op range [op_lo, op_hi)
+// of the read that can touch the tile (an op starting one column past the tile may still anchor an indel on the tile's last
+// column). The ranges come from ONE coalesced pass over the read's per-op start columns: an op whose start column and its
+// predecessor's lie on different sides of a tile boundary is that boundary's lower / upper bound (start columns ascend), so
+// each lane looks at its op and its left neighbour's and writes the boundaries between them to a per-wave LDS table. That was
+// two binary searches per (read, tile) lane - ~20 dependent scattered probes - and 31 us per 16 regions; reads over more
+// than TF_CAP tiles (regions beyond 130 kb) still search.
+constexpr int TF_CAP = 256;
 __global__ __launch_bounds__(256) void k_tile_fill(SumArgs a) {
-    const int lane = threadIdx.x & 63;
-    const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    __shared__ int32_t s_lo[4][TF_CAP + 1], s_hi[4][TF_CAP + 1];   // per wave: lower / upper bound of the boundaries of tiles t0 .. t1 + 1
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int64_t r = (int64_t)blockIdx.x * 4 + wv;
     if (r >= a.n_reads || a.diag[D_STATUS] != 0) return;
     const int32_t t0 = a.read_t0[r], t1 = a.read_t1[r];
     if (t1 < t0) return;
     const int g = a.read_region[r];
     const int64_t cb0 = a.in.ref_off[g];
     const int32_t c0 = (int32_t)a.in.cigar_off[r], c1 = (int32_t)a.in.cigar_off[r + 1];
+    const int nb = t1 - t0 + 2;   // boundaries: first columns of tiles t0 .. t1 + 1
+    const bool table = nb <= TF_CAP + 1;
+    if (table) {
+        for (int i = lane; i < nb; i += 64) { s_lo[wv][i] = c1; s_hi[wv][i] = c1; }   // no op at or behind the boundary
+        auto fetch = [&](int32_t cb) -> int32_t { return cb + lane < c1 ? a.op_ref[cb + lane] : OP_INACTIVE; };
+        int32_t carry = -0x7fffffff - 1;   // "start column" of the op before the first
+        auto trip = [&](const int32_t x, const int32_t cb) {
+            const int32_t c = cb + lane;
+            int32_t p = __builtin_amdgcn_update_dpp(0, x, 0x138, 0xf, 0xf, false);   // wave_shr:1: the left neighbour's start column
+            if (lane == 0) p = carry;
+            if (c < c1 && p != x) {
+                // boundaries b_t = t * TILE_COLS - cb0 (region-relative), t0 <= t <= t1 + 1
+                const int64_t pp = (int64_t)p + cb0, xx = (int64_t)x + cb0;
+                int64_t lo_a = (pp >> 9) + 1, lo_b = xx >> 9;                    // lower bound: p < b_t <= x
+                int64_t hi_a = (pp + 511) >> 9, hi_b = ((xx + 511) >> 9) - 1;    // upper bound: p <= b_t < x
+                static_assert(TILE_COLS == 512, ">> 9");
+                if (lo_a < t0) lo_a = t0;
+                if (hi_a < t0) hi_a = t0;
+                if (lo_b > (int64_t)t1 + 1) lo_b = (int64_t)t1 + 1;
+                if (hi_b > (int64_t)t1 + 1) hi_b = (int64_t)t1 + 1;
+                for (int64_t t = lo_a; t <= lo_b; t++) s_lo[wv][t - t0] = c;
+                for (int64_t t = hi_a; t <= hi_b; t++) s_hi[wv][t - t0] = c;
+            }
+            carry = __builtin_amdgcn_readlane(x, 63);
+        };
+        int32_t x_a = fetch(c0), x_b = fetch(c0 + 64);   // (two trips per pass, registers reloaded after use: see k_cigar_scan)
+        for (int32_t cb = c0; cb < c1; cb += 128) {
+            trip(x_a, cb);
+            x_a = fetch(cb + 128);
+            if (cb + 64 >= c1) break;
+            trip(x_b, cb + 64);
+            x_b = fetch(cb + 192);
+        }
+    }
     for (int32_t t = t0 + lane; t <= t1; t += 64) {
-        const int64_t tlo = (int64_t)t * TILE_COLS - cb0, thi = tlo + TILE_COLS - 1;  // region-relative columns
-        int32_t lo = c0, hi = c1;  // first op with op_ref >= tlo
-        while (lo < hi) { const int32_t mid = (lo + hi) >> 1; if ((int64_t)a.op_ref[mid] < tlo) lo = mid + 1; else hi = mid; }
-        int32_t op_lo = lo > c0 ? lo - 1 : c0;
-        lo = op_lo; hi = c1;  // first op with op_ref > thi + 1
-        while (lo < hi) { const int32_t mid = (lo + hi) >> 1; if ((int64_t)a.op_ref[mid] <= thi + 1) lo = mid + 1; else hi = mid; }
-        const int32_t op_hi = lo;
+        int32_t op_lo, op_hi;
+        if (table) {
+            const int32_t lower = s_lo[wv][t - t0];                 // first op with op_ref >= first column of tile t
+            op_lo = lower > c0 ? lower - 1 : c0;
+            op_hi = s_hi[wv][t + 1 - t0];                           // first op with op_ref > first column of tile t + 1
+        } else {
+            const int64_t tlo = (int64_t)t * TILE_COLS - cb0, thi = tlo + TILE_COLS - 1;  // region-relative columns
+            int32_t lo = c0, hi = c1;  // first op with op_ref >= tlo
+            while (lo < hi) { const int32_t mid = (lo + hi) >> 1; if ((int64_t)a.op_ref[mid] < tlo) lo = mid + 1; else hi = mid; }
+            op_lo = lo > c0 ? lo - 1 : c0;
+            lo = op_lo; hi = c1;  // first op with op_ref > thi + 1
+            while (lo < hi) { const int32_t mid = (lo + hi) >> 1; if ((int64_t)a.op_ref[mid] <= thi + 1) lo = mid + 1; else hi = mid; }
+            op_hi = lo;
+        }
         const int32_t slot = a.tile_off[t] + atomicAdd(&a.tile_fill[t], 1);
         PairRec pr;
         pr.read = (int32_t)r; pr.op_lo = op_lo; pr.op_hi = op_hi; pr.col_base = (int32_t)cb0;
@@ -1159,7 +1205,6 @@ __global__ __launch_bounds__(1024) void k_site_rank(SumArgs a) {
     int woff = 0;
     for (int k = 0; k < wv; k++) woff += s_w[k];
     const int32_t rank = a.blk_off[blockIdx.x * (1024 / TILE_COLS)] + woff + before;  // block offsets are per tile
-    if (col < a.n_cols) a.site_rank[col] = rank;
     if (site && rank < a.max_sites) {
         const int64_t NC = a.n_cols;
         a.site_col[rank] = (int32_t)col;
@@ -2067,7 +2112,6 @@ static int summarize_launch(pv_ctx* ctx, const pv_batch_in* in, const pv_params*
     if ((rc = pv_get(ctx, "sum.pairs", max_pairs, &a.pairs))) return rc;
     if ((rc = pv_get(ctx, "sum.cnt", (size_t)(hp ? NCNT_HP : NCNT) * n_cols, &a.cnt))) return rc;
     if ((rc = pv_get(ctx, "sum.flags", n_cols, &a.flags))) return rc;
-    if ((rc = pv_get(ctx, "sum.site_rank", n_cols, &a.site_rank))) return rc;
     if ((rc = pv_get(ctx, "sum.blk_cnt", (size_t)a.n_tiles + 2, &a.blk_cnt))) return rc;   // per tile
     if ((rc = pv_get(ctx, "sum.blk_off", (size_t)a.n_tiles + 2, &a.blk_off))) return rc;
     if ((rc = pv_get(ctx, "sum.tile_g0", (size_t)a.n_tiles + 2, &a.tile_g0))) return rc;
