@@ -168,3 +168,28 @@ def test_long_indels_and_padded_reference(hip_ctx, oracle_lib):
         P = PRESETS[preset]
         o = hip_ctx.summarize(b, P, True)
         assert_summary_equal(o, summary_as_expected(oracle_lib.summarize(b, P, True)), preset)
+
+
+@pytest.mark.parametrize("min_q", [0.0, 0.5, 1.0, 17.0, 126.5, 127.0, 128.0, 128.5, 200.0, 255.0, 255.5, 300.0])
+def test_quality_bar_anywhere_in_the_byte_range(hip_ctx, oracle_lib, min_q):
+    """k_pileup_tiles compares four quality bytes at a time (high bit decides, else the low seven bits): every position of
+    the bar relative to 128 and to the ends of the byte range, qualities over all of 0..255, odd bytes among the bases"""
+    from dataclasses import replace
+    from pepper_thesis_amd.batch import Read, Region
+    rng = np.random.default_rng(int(min_q * 2) + 7)
+    R = 700
+    ref = rng.choice(np.frombuffer(b"ACGTacgtN", np.uint8), size=R, p=[.22, .22, .22, .22, .02, .02, .02, .02, .04]).astype(np.uint8)
+    reads = []
+    for i in range(50):
+        start = int(rng.integers(0, 200))
+        n = int(rng.integers(200, R - start))
+        seq = ref[start:start + n].copy()
+        seq[(seq >= 97)] -= 32                                       # reads mostly upper case
+        flip = rng.random(n) < 0.08
+        seq[flip] = rng.choice(np.frombuffer(b"ACGTacgtN*RY", np.uint8), size=int(flip.sum()))
+        quals = rng.integers(0, 256, size=n).astype(np.uint8)
+        reads.append(Read.make(start, "%dM" % n, seq.tobytes(), quals, i % 2 == 0, 60))
+    b = pack_regions([Region(0, R - 1, ref.tobytes(), reads)])
+    P = replace(PRESETS["ont_r9_guppy5_sup"], min_snp_baseq=min_q)
+    o = hip_ctx.summarize(b, P, True)
+    assert_summary_equal(o, summary_as_expected(oracle_lib.summarize(b, P, True)), "min_snp_baseq %g" % min_q)
