@@ -411,6 +411,15 @@ enum {
     HL_SNP = 27, HL_INS = 28, HL_DEL = 29, HL_N = 30
 };
 
+// Four bytes at a time: bit 7 of a result byte is set where the byte is NOT one of A/C/G/T (swar_not_acgt_upper) or not one of
+// A/C/G/T/a/c/g/t (swar_not_acgt): two bits of the byte index a four-entry v_perm_b32 table of the expected letters, and what
+// differs from it is non-zero
+__device__ __forceinline__ uint32_t swar_nonzero(uint32_t z) { return (((z & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | z) & 0x80808080u; }
+__device__ __forceinline__ uint32_t swar_not_acgt_upper(uint32_t w) {
+    return swar_nonzero(__builtin_amdgcn_perm(0u, 0x47544341u, (w >> 1) & 0x03030303u) ^ w);   // index (b >> 1) & 3: A 0, C 1, T 2, G 3
+}
+__device__ __forceinline__ uint32_t swar_not_acgt(uint32_t w) { return swar_not_acgt_upper(w & 0xDFDFDFDFu); }
+
 // Site flag of one column from its four counters: frequency thresholds of :634-646 (bit 0 site, bits 1-3 which of the
 // SNP / insert / delete thresholds passed). Runs in the flush of k_pileup_tiles, where the counters still sit in LDS
 // (it was a kernel of its own, k_site_scan, re-reading four planes: 16 us per 1.6 M columns, mostly round trips).
@@ -453,7 +462,7 @@ __device__ __forceinline__ uint8_t site_flag(const SumArgs& a, const SiteRegion&
 template <bool HP>
 __global__ __launch_bounds__(PT_THREADS, HP ? 2 : 4) void k_pileup_tiles(SumArgs a) {   // 26-plane form: two workgroups per CU (<= 128 VGPRs)
     __shared__ int32_t s_cnt[HP ? (int)HL_N : (int)L_N][TILE_COLS];
-    __shared__ __attribute__((aligned(4))) uint8_t s_ref[TILE_COLS + 8];  // the tile's reference bytes (+8: a padded group may look past the tile, and is read as two words)
+    __shared__ __attribute__((aligned(4))) uint8_t s_ref[TILE_COLS + 16];  // the tile's reference bytes (+16: groups of 4 / 8 columns are read as two / three aligned words from any column of the tile)
     __shared__ uint8_t s_lut[256];           // byte class: bits0-2 plane symbol 1..7, 8 = upper ACGT, 16 = lower acgt, 32 = valid reference
     __shared__ uint16_t s_blk[PT_THREADS * (TILE_COLS + 4) / 64 + 2];  // op that owns the first slot of every 64-slot block
     // per-op staging (one op batch)
@@ -487,7 +496,7 @@ __global__ __launch_bounds__(PT_THREADS, HP ? 2 : 4) void k_pileup_tiles(SumArgs
     __shared__ SiteRegion s_sreg;  // region of the tile's first column, for the flush (looked up by k_init)
     if (tid == 0) s_sreg = site_region_load(a, a.tile_g0[tile]);
     for (int i = tid; i < (HP ? (int)HL_N : (int)L_N) * TILE_COLS; i += PT_THREADS) (&s_cnt[0][0])[i] = 0;
-    for (int i = tid; i < TILE_COLS + 8; i += PT_THREADS) s_ref[i] = (i < TILE_COLS && tlo + i < a.n_cols) ? a.in.ref[tlo + i] : (uint8_t)'N';
+    for (int i = tid; i < TILE_COLS + 16; i += PT_THREADS) s_ref[i] = (i < TILE_COLS && tlo + i < a.n_cols) ? a.in.ref[tlo + i] : (uint8_t)'N';
     if (tid < 256) s_lut[tid] = (uint8_t)(sym_of(tid) | (is_acgt(tid) ? 8 : 0) | ((tid != up(tid) && is_acgt(up(tid))) ? 16 : 0) | (is_acgt(up(tid)) ? 32 : 0));
     const int32_t p0 = a.tile_off[tile];
     const int32_t np = a.tile_cnt[tile];
@@ -540,7 +549,6 @@ __global__ __launch_bounds__(PT_THREADS, HP ? 2 : 4) void k_pileup_tiles(SumArgs
             int32_t c = 0;
             int64_t clo = 0, chi = -1;
             const OpWords ow = ow_next;
-            if (ob + PT_THREADS < total_ops) ow_next = op_fetch(k + PT_THREADS);
             if (k < total_ops) {
                 pslot = ow.pslot;
                 c = ow.c;
@@ -627,7 +635,10 @@ __global__ __launch_bounds__(PT_THREADS, HP ? 2 : 4) void k_pileup_tiles(SumArgs
             };
             // The 26-plane form sits at its 128-register cap (two more live values spill): it uses the words at once, as before;
             // the haplotag form (one workgroup per CU, 256 registers) uses them behind the scans.
-            if constexpr (!HP) ins_use();
+            // the next batch's op words are requested BEHIND the insert's qualities (so that waiting for those leaves these in
+            // flight) and ahead of the delete bookkeeping, which is LDS work: its time and the pair lookup of the prefetch cover
+            // most of the qualities' round trip before the 26-plane form uses them
+            if (ob + PT_THREADS < total_ops) ow_next = op_fetch(k + PT_THREADS);
             // (1) delete ops; an op belongs to the tile that owns its anchor column
             if constexpr (HP) {
                 const int st = rev ? 1 : 0, ss = hpbits >> 2;
@@ -648,11 +659,19 @@ __global__ __launch_bounds__(PT_THREADS, HP ? 2 : 4) void k_pileup_tiles(SumArgs
                     }
                     int64_t i0 = clo - ref_rel; if (i0 < 0) i0 = 0;
                     int64_t i1 = chi + 1 - ref_rel; if (i1 > len) i1 = len;
-                    for (int64_t i = i0; i < i1; i++) {  // :631-647
-                        const int lc2 = (int)((int64_t)col_base + ref_rel + i - tlo);
-                        if (is_acgt(up(s_ref[lc2]))) {
-                            if (ss & 1) atomicAdd(&s_cnt[HL_O + (0 + st) * 3 + 2][SW(lc2)], 1);
-                            if (ss & 2) atomicAdd(&s_cnt[HL_O + (2 + st) * 3 + 2][SW(lc2)], 1);
+                    for (int64_t i = i0; i < i1; i += 8) {  // :631-647, eight deleted columns per pass (see the 26-plane form)
+                        const int lcb = (int)((int64_t)col_base + ref_rel + i - tlo);
+                        const int n = (int)(i1 - i < 8 ? i1 - i : 8);
+                        const uint32_t* wp = reinterpret_cast<const uint32_t*>(s_ref) + (lcb >> 2);
+                        const uint32_t w0 = wp[0], w1 = wp[1], w2 = wp[2];
+                        const uint32_t bad0 = swar_not_acgt(__builtin_amdgcn_alignbyte(w1, w0, (unsigned)lcb & 3u));
+                        const uint32_t bad1 = swar_not_acgt(__builtin_amdgcn_alignbyte(w2, w1, (unsigned)lcb & 3u));
+#pragma unroll
+                        for (int e = 0; e < 8; e++) {
+                            const int inc = e < n ? (int)((((e < 4 ? bad0 : bad1) >> (8 * (e & 3) + 7)) & 1u) ^ 1u) : 0;
+                            const int sw = SW(lcb + e);
+                            atomicAdd(&s_cnt[HL_O + (0 + st) * 3 + 2][sw], (ss & 1) ? inc : 0);
+                            atomicAdd(&s_cnt[HL_O + (2 + st) * 3 + 2][sw], (ss & 2) ? inc : 0);
                         }
                     }
                 }
@@ -671,12 +690,26 @@ __global__ __launch_bounds__(PT_THREADS, HP ? 2 : 4) void k_pileup_tiles(SumArgs
                 }
                 int64_t i0 = clo - ref_rel; if (i0 < 0) i0 = 0;
                 int64_t i1 = chi + 1 - ref_rel; if (i1 > len) i1 = len;
-                for (int64_t i = i0; i < i1; i++) {  // :542-552
-                    const int lc2 = (int)((int64_t)col_base + ref_rel + i - tlo);
-                    if (is_acgt(up(s_ref[lc2]))) atomicAdd(&s_cnt[so + 2][SW(lc2)], 1);
+                // :542-552, the '*' plane of the deleted columns inside the tile where the reference is A/C/G/T. Eight columns per
+                // pass: their reference bytes arrive as three aligned words and are tested together, and the adds (ZERO where a
+                // column does not count; SW() keeps any column inside the plane) follow each other with no read between them -
+                // a column at a time was a chain of dependent LDS round trips, the longest part of this phase
+                for (int64_t i = i0; i < i1; i += 8) {
+                    const int lcb = (int)((int64_t)col_base + ref_rel + i - tlo);
+                    const int n = (int)(i1 - i < 8 ? i1 - i : 8);
+                    const uint32_t* wp = reinterpret_cast<const uint32_t*>(s_ref) + (lcb >> 2);
+                    const uint32_t w0 = wp[0], w1 = wp[1], w2 = wp[2];
+                    const uint32_t bad0 = swar_not_acgt(__builtin_amdgcn_alignbyte(w1, w0, (unsigned)lcb & 3u));
+                    const uint32_t bad1 = swar_not_acgt(__builtin_amdgcn_alignbyte(w2, w1, (unsigned)lcb & 3u));
+#pragma unroll
+                    for (int e = 0; e < 8; e++) {
+                        const int inc = e < n ? (int)((((e < 4 ? bad0 : bad1) >> (8 * (e & 3) + 7)) & 1u) ^ 1u) : 0;
+                        atomicAdd(&s_cnt[so + 2][SW(lcb + e)], inc);
+                    }
                 }
             }
             }
+            if constexpr (!HP) ins_use();
             // (2) aligned bases of the batch's M/=/X ops, clipped to tile and region
             PSTAMP(1)  // op lookup + indel ops
             const bool is_m = active && (op == PV_CIGAR_MATCH || op == PV_CIGAR_EQUAL || op == PV_CIGAR_DIFF);
@@ -795,19 +828,17 @@ __global__ __launch_bounds__(PT_THREADS, HP ? 2 : 4) void k_pileup_tiles(SumArgs
                         // else take count_general, one by one.
                         const Grp& G = g[u];
                         constexpr uint32_t H = 0x80808080u;
-                        auto nonzero = [](uint32_t z) { return (((z & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | z) & 0x80808080u; };
                         const uint32_t tq = (G.qw | H) - q_low;                              // bit 7: low seven bits of q >= those of qmin
                         uint32_t ge = q_hi ? (G.qw & tq) : (G.qw | tq);
                         ge = q_all ? H : (q_none ? 0u : ge);
                         const uint32_t vm = G.nv >= 4 ? H : ((H >> 8) >> (24 - 8 * (G.nv < 0 ? 0 : G.nv)));   // the group's valid bases
                         const uint32_t ok = ge & vm;
                         const uint32_t selb = (G.bw >> 1) & 0x03030303u;                     // A 0, C 1, T 2, G 3
-                        const uint32_t b_bad = nonzero(__builtin_amdgcn_perm(0u, 0x47544341u, selb) ^ G.bw);
-                        const uint32_t rwu = G.rw & 0xDFDFDFDFu;
-                        const uint32_t r_bad = nonzero(__builtin_amdgcn_perm(0u, 0x47544341u, (rwu >> 1) & 0x03030303u) ^ rwu);
+                        const uint32_t b_bad = swar_not_acgt_upper(G.bw);
+                        const uint32_t r_bad = swar_not_acgt(G.rw);
                         const uint32_t fast = ok & ~(b_bad | r_bad);
                         const uint32_t slow = ok & (b_bad | r_bad);
-                        const uint32_t mism = nonzero(G.bw ^ G.rw) & fast;                   // raw bytes, :394 (never rare: both are A/C/G/T)
+                        const uint32_t mism = swar_nonzero(G.bw ^ G.rw) & fast;                   // raw bytes, :394 (never rare: both are A/C/G/T)
                         const uint32_t pidx = selb ^ ((selb >> 1) & 0x01010101u);            // -> A 0, C 1, G 2, T 3
                         const int st = G.fl;
                         // no branches: a base that does not count adds ZERO (SW() keeps any column inside the plane, the plane
