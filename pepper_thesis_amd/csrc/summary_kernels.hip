@@ -480,6 +480,8 @@ __global__ __launch_bounds__(PT_THREADS, HP ? 2 : 4) void k_pileup_tiles(SumArgs
     __shared__ __attribute__((aligned(16))) OpSt s_op[PT_THREADS];
     // per-pair staging (one pair batch)
     __shared__ int32_t p_off[PT_PB + 1];     // exclusive prefix of op counts
+    constexpr int PB_BLK = 768;              // 32-op blocks of a pair batch with an owner entry (24 k ops; beyond: binary search)
+    __shared__ uint8_t p_blk[PB_BLK];
     __shared__ int32_t p_oplo[PT_PB], p_colbase[PT_PB], p_R[PT_PB], p_clast[PT_PB], p_reflen[PT_PB], p_rev[PT_PB];
     __shared__ int64_t p_base0[PT_PB], p_seqend[PT_PB];
     __shared__ int32_t s_wsum[PT_THREADS / 64];
@@ -515,7 +517,11 @@ __global__ __launch_bounds__(PT_THREADS, HP ? 2 : 4) void k_pileup_tiles(SumArgs
             p_reflen[tid] = pr.ref_len; p_rev[tid] = pr.rev; p_base0[tid] = pr.base0; p_seqend[tid] = pr.seq_end;
         }
         const int incl_ops = block_incl_scan512(nops, s_wsum, tid);
-        if (tid < npb) p_off[tid + 1] = incl_ops;
+        if (tid < npb) {
+            p_off[tid + 1] = incl_ops;
+            // pair that owns the first op of every 32-op block that starts inside this pair's range (op -> pair lookups start there)
+            for (int bb = (incl_ops - nops + 31) >> 5; (bb << 5) < incl_ops && bb < PB_BLK; bb++) p_blk[bb] = (uint8_t)tid;
+        }
         if (tid == 0) p_off[0] = 0;
         __syncthreads();
         const int total_ops = p_off[npb];
@@ -527,8 +533,15 @@ __global__ __launch_bounds__(PT_THREADS, HP ? 2 : 4) void k_pileup_tiles(SumArgs
             OpWords o;
             o.pslot = 0; o.c = 0; o.c_last = 0; o.rr = OP_INACTIVE; o.rdv = 0; o.w = 15u; o.wn = 15u;
             if (kk < total_ops) {
-                int lo = 0, hi = npb;  // last pair slot with p_off[slot] <= kk
-                while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (p_off[mid] <= kk) lo = mid; else hi = mid; }
+                int lo;  // last pair slot with p_off[slot] <= kk: the owner of the op's 32-op block, then a short walk
+                if ((kk >> 5) < PB_BLK) {
+                    lo = p_blk[kk >> 5];
+                    while (p_off[lo + 1] <= kk) lo++;
+                } else {
+                    int hi = npb;
+                    lo = 0;
+                    while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (p_off[mid] <= kk) lo = mid; else hi = mid; }
+                }
                 o.pslot = lo;
                 o.c = p_oplo[lo] + (kk - p_off[lo]);
                 o.c_last = p_clast[lo];
