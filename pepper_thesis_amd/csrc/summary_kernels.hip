@@ -375,15 +375,19 @@ constexpr int PT_GPL = 2;   // groups of 4 consecutive bases per thread per trip
 #define SW(lc) ((int)((((unsigned)(lc) * 513u) >> 2) & 511u))
 static_assert(TILE_COLS == 512, "SW() assumes 512-column tiles");
 
-__device__ __forceinline__ int block_incl_scan512(int v, int* s_wsum, int tid) {
+// (s_wsum: two sets of wave totals used in turn - `turn` counts the calls - so that one barrier per call is enough: a set is
+// written again two calls later, and every thread has passed the barrier of the call in between only after all of them have
+// read this one)
+__device__ __forceinline__ int block_incl_scan512(int v, int* s_wsum, int tid, int& turn) {
     const int lane = tid & 63, wv = tid >> 6;
+    int* ws = s_wsum + (turn & 1) * (PT_THREADS / 64);
+    turn++;
     const int inc = wave_incl_scan32(v, lane);
-    if (lane == 63) s_wsum[wv] = inc;
+    if (lane == 63) ws[wv] = inc;
     __syncthreads();
     int off = 0;
 #pragma unroll
-    for (int k = 0; k < PT_THREADS / 64; k++) off += (k < wv) ? s_wsum[k] : 0;
-    __syncthreads();
+    for (int k = 0; k < PT_THREADS / 64; k++) off += (k < wv) ? ws[k] : 0;
     return inc + off;
 }
 
@@ -484,7 +488,8 @@ __global__ __launch_bounds__(PT_THREADS, HP ? 2 : 4) void k_pileup_tiles(SumArgs
     __shared__ uint8_t p_blk[PB_BLK];
     __shared__ int32_t p_oplo[PT_PB], p_colbase[PT_PB], p_R[PT_PB], p_clast[PT_PB], p_reflen[PT_PB], p_rev[PT_PB];
     __shared__ int64_t p_base0[PT_PB], p_seqend[PT_PB];
-    __shared__ int32_t s_wsum[PT_THREADS / 64];
+    __shared__ int32_t s_wsum[2 * (PT_THREADS / 64)];
+    int scan_turn = 0;
     const int tid = threadIdx.x;
     const int64_t tile = blockIdx.x;
 #ifdef PV_PSTAMPS
@@ -516,7 +521,7 @@ __global__ __launch_bounds__(PT_THREADS, HP ? 2 : 4) void k_pileup_tiles(SumArgs
             p_oplo[tid] = pr.op_lo; p_colbase[tid] = pr.col_base; p_R[tid] = pr.R; p_clast[tid] = pr.c_last;
             p_reflen[tid] = pr.ref_len; p_rev[tid] = pr.rev; p_base0[tid] = pr.base0; p_seqend[tid] = pr.seq_end;
         }
-        const int incl_ops = block_incl_scan512(nops, s_wsum, tid);
+        const int incl_ops = block_incl_scan512(nops, s_wsum, tid, scan_turn);
         if (tid < npb) {
             p_off[tid + 1] = incl_ops;
             // pair that owns the first op of every 32-op block that starts inside this pair's range (op -> pair lookups start there)
@@ -735,7 +740,7 @@ __global__ __launch_bounds__(PT_THREADS, HP ? 2 : 4) void k_pileup_tiles(SumArgs
             // Slots: every op's in-tile bases are padded to whole groups of 4 slots, so that a GROUP never straddles two ops:
             // one owner lookup, one dword load of bases and one of qualities serve 4 consecutive bases / columns.
             const int32_t effp = (eff + 3) & ~3;
-            const int32_t incl = block_incl_scan512(effp, s_wsum, tid);
+            const int32_t incl = block_incl_scan512(effp, s_wsum, tid, scan_turn);
             s_pref[tid] = incl;
             {
                 const int64_t base = (k < total_ops ? p_base0[pslot] : 0) + rd;
@@ -1807,7 +1812,8 @@ __global__ __launch_bounds__(PT_THREADS) void k_polish_tiles(SumArgs a) {
     __shared__ int32_t p_off[PT_PB + 1];
     __shared__ int32_t p_oplo[PT_PB], p_colbase[PT_PB], p_R[PT_PB], p_rev[PT_PB];
     __shared__ int64_t p_base0[PT_PB], p_seqend[PT_PB];
-    __shared__ int32_t s_wsum[PT_THREADS / 64];
+    __shared__ int32_t s_wsum[2 * (PT_THREADS / 64)];
+    int scan_turn = 0;
     const int tid = threadIdx.x;
     const int64_t tile = blockIdx.x;
     const int64_t tlo = tile * TILE_COLS, thi = tlo + TILE_COLS - 1;
@@ -1825,7 +1831,7 @@ __global__ __launch_bounds__(PT_THREADS) void k_polish_tiles(SumArgs a) {
             p_oplo[tid] = pr.op_lo; p_colbase[tid] = pr.col_base; p_R[tid] = pr.R;
             p_rev[tid] = pr.rev; p_base0[tid] = pr.base0; p_seqend[tid] = pr.seq_end;
         }
-        const int incl_ops = block_incl_scan512(nops, s_wsum, tid);
+        const int incl_ops = block_incl_scan512(nops, s_wsum, tid, scan_turn);
         if (tid < npb) p_off[tid + 1] = incl_ops;
         if (tid == 0) p_off[0] = 0;
         __syncthreads();
@@ -1885,7 +1891,7 @@ __global__ __launch_bounds__(PT_THREADS) void k_polish_tiles(SumArgs a) {
                 if (hi > lo) { i0 = (int32_t)lo; eff = (int32_t)(hi - lo); }
             }
             const int32_t effp = (eff + 3) & ~3;  // groups of 4 slots never straddle two ops (see k_pileup_tiles)
-            const int32_t incl = block_incl_scan512(effp, s_wsum, tid);
+            const int32_t incl = block_incl_scan512(effp, s_wsum, tid, scan_turn);
             s_pref[tid] = incl;
             s_col0[tid] = col_base + ref_rel;
             s_base[tid] = (k < total_ops ? p_base0[pslot] : 0) + rd;
