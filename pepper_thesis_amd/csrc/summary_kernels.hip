@@ -468,7 +468,9 @@ __global__ __launch_bounds__(PT_THREADS, HP ? 2 : 4) void k_pileup_tiles(SumArgs
     __shared__ int32_t s_cnt[HP ? (int)HL_N : (int)L_N][TILE_COLS];
     __shared__ __attribute__((aligned(4))) uint8_t s_ref[TILE_COLS + 16];  // the tile's reference bytes (+16: groups of 4 / 8 columns are read as two / three aligned words from any column of the tile)
     __shared__ uint8_t s_lut[256];           // byte class: bits0-2 plane symbol 1..7, 8 = upper ACGT, 16 = lower acgt, 32 = valid reference
-    __shared__ uint16_t s_blk[PT_THREADS * (TILE_COLS + 4) / 64 + 2];  // op that owns the first slot of every 64-slot block
+    constexpr int SB_N = 2048;               // 16-slot blocks with an owner entry (32 k slots per op batch; beyond: a search)
+    __shared__ uint16_t s_blk[SB_N];         // op that owns the first slot of every 16-slot block: a padded op is ~12 slots, so the
+                                             // walk from there is one step or none (64-slot blocks: two or three dependent reads)
     // per-op staging (one op batch)
     __shared__ int32_t s_pref[PT_THREADS];   // inclusive prefix of the in-tile aligned bases, every op padded to whole groups of 4
     // what the expansion needs of an op, as one 32-byte record (two ds_read_b128 per group instead of nine scalar reads):
@@ -757,7 +759,7 @@ __global__ __launch_bounds__(PT_THREADS, HP ? 2 : 4) void k_pileup_tiles(SumArgs
                 o.fl = (rev ? 1 : 0) | (anchor_next ? 2 : 0) | (HP ? hpbits << 2 : 0);
                 s_op[tid] = o;
             }
-            for (int32_t bb = (incl - effp + 63) >> 6; (bb << 6) < incl; bb++) s_blk[bb] = (uint16_t)tid;  // blocks starting inside this op
+            for (int32_t bb = (incl - effp + 15) >> 4; (bb << 4) < incl && bb < SB_N; bb++) s_blk[bb] = (uint16_t)tid;  // blocks starting inside this op
             __syncthreads();
             const int32_t total = s_pref[PT_THREADS - 1];
             if constexpr (HP) ins_use();   // (0, continued) the insert's qualities have arrived by now
@@ -771,8 +773,16 @@ __global__ __launch_bounds__(PT_THREADS, HP ? 2 : 4) void k_pileup_tiles(SumArgs
                     // consecutive lanes take consecutive groups: the dword loads of a wave cover 256 consecutive bytes of a run
                     const int32_t j = jb + (u * PT_THREADS + tid) * 4;
                     const bool ok = j < total;
-                    int owc = ok ? s_blk[j >> 6] : 0;  // owner of the block's first slot, then a short probe
-                    while (ok && s_pref[owc] <= j) owc++;
+                    int owc = 0;                       // owner of the block's first slot, then a short probe
+                    if (ok) {
+                        if ((j >> 4) < SB_N) {
+                            owc = s_blk[j >> 4];
+                        } else {                       // first op whose inclusive prefix exceeds j
+                            int hi = PT_THREADS - 1;
+                            while (owc < hi) { const int mid = (owc + hi) >> 1; if (s_pref[mid] <= j) owc = mid + 1; else hi = mid; }
+                        }
+                        while (s_pref[owc] <= j) owc++;
+                    }
                     const OpSt o = s_op[owc];
                     const int32_t i = j + o.i0s;
                     int nv = o.iend - i;               // valid bases of the group (the rest is padding)
