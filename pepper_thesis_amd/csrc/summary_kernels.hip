@@ -837,30 +837,32 @@ __global__ __launch_bounds__(PT_THREADS, HP ? 2 : 4) void k_pileup_tiles(SumArgs
             auto count = [&](const Grp (&g)[PT_GPL]) {
 #pragma unroll
                 for (int u = 0; u < PT_GPL; u++) {
-                    if constexpr (HP) {  // region_summary_hp.cpp:393-463
+                    // quality bar and the group's valid bases, a byte per base (bit 7 = counts)
+                    constexpr uint32_t H = 0x80808080u;
+                    const Grp& G = g[u];
+                    const uint32_t tq = (G.qw | H) - q_low;                              // bit 7: low seven bits of q >= those of qmin
+                    uint32_t ge = q_hi ? (G.qw & tq) : (G.qw | tq);
+                    ge = q_all ? H : (q_none ? 0u : ge);
+                    const uint32_t vm = G.nv >= 4 ? H : ((H >> 8) >> (24 - 8 * (G.nv < 0 ? 0 : G.nv)));   // the group's valid bases
+                    const uint32_t ok = ge & vm;
+                    if constexpr (HP) {  // region_summary_hp.cpp:393-463: a counted base adds to its count-set class and to either the
+                        // SNP counter (raw bytes differ, :406) or - over a valid reference - its symbol-set class; branch-free like the
+                        // 26-plane form (a base that does not count adds zero)
+                        const uint32_t differs = swar_nonzero(G.bw ^ G.rw);
+                        const uint32_t second = ok & (differs | ~swar_not_acgt(G.rw));
+                        const int st = G.fl & 1, cs = (G.fl >> 2) & 3, ss = (G.fl >> 4) & 3;
 #pragma unroll
                         for (int e = 0; e < 4; e++) {
-                            const int base = (g[u].bw >> (8 * e)) & 0xFF, refb = (g[u].rw >> (8 * e)) & 0xFF;
-                            const int q = (g[u].qw >> (8 * e)) & 0xFF;
-                            if (e >= g[u].nv || q < a.qmin_snp) continue;
-                            const int lc = g[u].lc + e;
-                            const int st = g[u].fl & 1, cs = (g[u].fl >> 2) & 3, ss = (g[u].fl >> 4) & 3;
-                            atomicAdd(&s_cnt[HL_REFC + 2 * cs + st][SW(lc)], 1);
-                            if (refb != base) atomicAdd(&s_cnt[HL_SNP][SW(lc)], 1);                       // raw bytes, :406
-                            else if (s_lut[refb] & 32) atomicAdd(&s_cnt[HL_M + 2 * (ss - 1) + st][SW(lc)], 1);
+                            const int sw = SW(G.lc + e);
+                            atomicAdd(&s_cnt[HL_REFC + 2 * cs + st][sw], (int)((ok >> (8 * e + 7)) & 1u));
+                            const bool mm = ((differs >> (8 * e + 7)) & 1u) != 0;
+                            atomicAdd(&s_cnt[mm ? (int)HL_SNP : HL_M + 2 * (ss - 1) + st][sw], (int)((second >> (8 * e + 7)) & 1u));
                         }
                     } else {
                         // The four bases of a group are classified together, a byte per base in 32-bit operations (bit 7 of a byte =
                         // the answer for that base), so that the usual base - A/C/G/T in upper case over an A/C/G/T reference of
                         // either case, quality passing - costs a bit test, an address and its one ds_add; bases that are anything
                         // else take count_general, one by one.
-                        const Grp& G = g[u];
-                        constexpr uint32_t H = 0x80808080u;
-                        const uint32_t tq = (G.qw | H) - q_low;                              // bit 7: low seven bits of q >= those of qmin
-                        uint32_t ge = q_hi ? (G.qw & tq) : (G.qw | tq);
-                        ge = q_all ? H : (q_none ? 0u : ge);
-                        const uint32_t vm = G.nv >= 4 ? H : ((H >> 8) >> (24 - 8 * (G.nv < 0 ? 0 : G.nv)));   // the group's valid bases
-                        const uint32_t ok = ge & vm;
                         const uint32_t selb = (G.bw >> 1) & 0x03030303u;                     // A 0, C 1, T 2, G 3
                         const uint32_t b_bad = swar_not_acgt_upper(G.bw);
                         const uint32_t r_bad = swar_not_acgt(G.rw);

@@ -111,3 +111,28 @@ def test_host_mirror_class(hip_ctx, oracle_lib):
     res = gen.generate_summary(reg.reads, 1, 1, 0.10, 0.15, 0.15, 3, 0.10, 0.10, 2, False, reg.ref_start, reg.ref_end, 20, 48, False)
     assert len(res) == 1 and res[0].contig == "chr20" and res[0].position == 40 and res[0].candidates == ["1T"]
     assert res[0].image_matrix.shape == (21, 48) and res[0].image_matrix[10].tolist() == HP_KNOWN_ROW
+
+
+@pytest.mark.parametrize("min_q", [0.0, 1.0, 17.0, 127.0, 128.0, 128.5, 200.0, 255.0, 300.0])
+def test_quality_bar_anywhere_in_the_byte_range(hip_ctx, oracle_lib, min_q):
+    """the tile kernel compares four quality bytes at a time: every position of the bar relative to 128 and the ends of the byte
+    range, qualities over all of 0..255, odd bytes among bases and reference, every haplotag"""
+    from dataclasses import replace
+    from pepper_thesis_amd.batch import Read, Region
+    rng = np.random.default_rng(int(min_q * 2) + 11)
+    R = 700
+    ref = rng.choice(np.frombuffer(b"ACGTacgtN", np.uint8), size=R, p=[.22, .22, .22, .22, .02, .02, .02, .02, .04]).astype(np.uint8)
+    reads = []
+    for i in range(50):
+        start = int(rng.integers(0, 200))
+        n = int(rng.integers(200, R - start))
+        seq = ref[start:start + n].copy()
+        seq[(seq >= 97)] -= 32
+        flip = rng.random(n) < 0.08
+        seq[flip] = rng.choice(np.frombuffer(b"ACGTacgtN*RY", np.uint8), size=int(flip.sum()))
+        quals = rng.integers(0, 256, size=n).astype(np.uint8)
+        reads.append(Read.make(start, "%dM" % n, seq.tobytes(), quals, i % 2 == 0, 60, hp_tag=int(rng.choice(cases.HP_TAG_CHOICES))))
+    b = pack_regions([Region(0, R - 1, ref.tobytes(), reads)])
+    P = replace(hp_params(PRESETS["ont_r9_guppy5_sup"]), min_snp_baseq=min_q)
+    o = hip_ctx.summarize_hp(b, P, True)
+    assert_summary_equal(o, summary_as_expected(oracle_lib.summarize_hp(b, P, True)), "min_snp_baseq %g" % min_q)
