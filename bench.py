@@ -538,6 +538,14 @@ def main(argv=None):
     for i in range(12):
         ctx.summarize_dev(dbatches[i % NBATCH], P, douts[0], stream=s_build.cuda_stream)
     prof_builder = ctx.profile_end()
+    # the same 12 launch chains without the per-kernel events (two events per kernel put a few microseconds between kernels)
+    eb0, eb1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    eb0.record(s_build)
+    for i in range(12):
+        ctx.summarize_dev(dbatches[i % NBATCH], P, douts[0], stream=s_build.cuda_stream)
+    eb1.record(s_build)
+    eb1.synchronize()
+    builder_chain_ms = eb0.elapsed_time(eb1) / 12
     n_windows_region = n_out_batch[0]
     for g, nc in enumerate(wchains):
         group(g, nc)
@@ -548,6 +556,12 @@ def main(argv=None):
         group(g)
     drain()
     est_step = (time.perf_counter() - t0) / (2 * CALLERS)
+    # per-kernel breakdown of the chain (untimed: every kernel bracketed by events; the timed region brackets the decoder only)
+    ctx.profile_begin()
+    for g in range(2):
+        group(g)
+    drain()
+    prof_all = ctx.profile_end()
     if dist is not None:
         t_est = torch.tensor([est_step], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(t_est, op=dist.ReduceOp.MAX)   # every rank must choose the same repeat count
@@ -583,7 +597,7 @@ def main(argv=None):
         exchange(probs_holder["t"].view(-1, 3))
         dist.barrier()
     torch.cuda.synchronize()
-    ctx.profile_begin()
+    ctx.profile_begin(only="k_lstm_layer_dec")   # the roofline kernel's launch durations, live over the timed region
     t0 = time.perf_counter()
     chain_ev[0].record(s_rnn)
     for g in range(n_chains):
@@ -643,13 +657,18 @@ def main(argv=None):
                          "launch_ms": dec_launch_ms, "launches": dec_n, "windows_per_launch": CALLERS * BATCH,
                          "flop_per_launch": flop_per_launch},
             "roofline_builder": {"bound": "hbm", "kernel": "summary pipeline (k_cigar_scan .. k_write_windows), %d regions/launch" % CALLERS,
-                                 "achieved": alg_bytes / (sum_ms / max(sum_n, 1) / 1e3) / 1e9 if sum_ms > 0 else 0.0,
+                                 "achieved": alg_bytes / (builder_chain_ms / 1e3) / 1e9,
                                  "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                                 "frac": (alg_bytes / (sum_ms / max(sum_n, 1) / 1e3) / 1e9 / PEAK_HBM_GBS) if sum_ms > 0 else 0.0,
-                                 "traffic": traffic.get("builder"), "launch_ms": sum_ms / max(sum_n, 1),
-                                 "k_pileup_ms": pile_ms / max(pile_n, 1), "measured": "in isolation, before the timed region",
+                                 "frac": alg_bytes / (builder_chain_ms / 1e3) / 1e9 / PEAK_HBM_GBS,
+                                 "traffic": traffic.get("builder"), "launch_ms": builder_chain_ms,
+                                 "launch_ms_with_kernel_events": sum_ms / max(sum_n, 1),
+                                 "k_pileup_ms": pile_ms / max(pile_n, 1),
+                                 "measured": "in isolation, before the timed region: 12 launch chains back to back (launch_ms), and the "
+                                             "same with every kernel bracketed by events (launch_ms_with_kernel_events, k_pileup_ms)",
                                  "algorithmic_bytes_per_launch": alg_bytes},
-            "kernel_ms": {k: v[0] / max(v[1], 1) for k, v in prof.items()},
+            "kernel_ms": dict({k: v[0] / max(v[1], 1) for k, v in prof_all.items()},
+                              **{k: v[0] / max(v[1], 1) for k, v in prof.items()}),
+            "kernel_ms_note": "k_lstm_layer_dec: HIP events over the timed region; the others: two untimed chains with every kernel bracketed",
             "rnn_model_tflops": FLOP_PER_WINDOW * value / 1e12,
         }
         secondary = world == 1

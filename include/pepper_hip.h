@@ -302,6 +302,9 @@ int pv_debug_gemm_bf16x3(pv_ctx* ctx, const float* A, const float* W, const floa
  * synchronises the device and returns the number of distinct kernels; names_buf receives their names
  * ('\n'-separated), ms_sum[i] / counts[i] the summed duration and launch count of kernel i. */
 int pv_profile_begin(pv_ctx* ctx);
+/* The same, for the kernels whose profile name starts with `prefix` only (NULL or "": all). Two events per launch put a few
+ * microseconds between kernels, so a timed region that needs one kernel's launch durations brackets that kernel alone. */
+int pv_profile_begin_only(pv_ctx* ctx, const char* prefix);
 int pv_profile_end(pv_ctx* ctx, char* names_buf, int buf_len, float* ms_sum, int* counts, int max_kernels);
 
 /* Small batches run in "split" kernel forms whose workgroups swap hidden state every time step (pv_rnn_forward_p1* up to

@@ -175,6 +175,7 @@ SYMBOLS = [
     ("pv_debug_gemm_bf16x3", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int,
                                         C.c_void_p, C.POINTER(C.c_float)]),
     ("pv_profile_begin", C.c_int, [C.c_void_p]),
+    ("pv_profile_begin_only", C.c_int, [C.c_void_p, C.c_char_p]),
     ("pv_profile_end", C.c_int, [C.c_void_p, C.c_char_p, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_int), C.c_int]),
     ("pv_rnn_exchange_timeouts", C.c_int, [C.c_void_p]),
     ("pv_graph_begin", C.c_int, [C.c_void_p, C.c_void_p]),

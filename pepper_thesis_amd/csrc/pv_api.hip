@@ -68,8 +68,15 @@ extern "C" int pv_profile_begin(pv_ctx* c) {
     PV_CHECK(c, PV_ERR_INVALID, "null context");
     for (auto& r : c->prof.recs) { c->prof.pool.push_back(r.a); c->prof.pool.push_back(r.b); }
     c->prof.recs.clear();
+    c->prof.only.clear();
     c->prof.on = true;
     return PV_OK;
+}
+
+extern "C" int pv_profile_begin_only(pv_ctx* c, const char* prefix) {
+    int rc = pv_profile_begin(c);
+    if (rc == PV_OK && prefix) c->prof.only = prefix;
+    return rc;
 }
 
 // Synchronises the context's stream, then aggregates the event-bracketed launches by kernel name.

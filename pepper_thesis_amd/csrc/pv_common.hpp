@@ -78,6 +78,7 @@ struct pv_arena {
 // Optional per-kernel timing with HIP events recorded on the launch stream (bench.py's roofline leg).
 struct pv_prof {
     bool on = false;
+    std::string only;   // non-empty: bracket only kernels whose profile name starts with this
     struct rec { const char* name; hipEvent_t a, b; };
     std::vector<rec> recs;
     std::vector<hipEvent_t> pool;
@@ -109,6 +110,7 @@ struct pv_ctx {
 struct pv_prof_scope {
     pv_ctx* c; hipStream_t st; size_t idx; bool on;
     pv_prof_scope(pv_ctx* c_, const char* name, hipStream_t st_) : c(c_), st(st_), idx(0), on(c_->prof.on) {
+        if (on && !c->prof.only.empty() && strncmp(name, c->prof.only.c_str(), c->prof.only.size()) != 0) on = false;
         if (!on) return;
         pv_prof::rec r; r.name = name; r.a = c->prof.take(); r.b = c->prof.take();
         (void)hipEventRecord(r.a, st);

@@ -236,8 +236,13 @@ class Context:
             self.handle, C.byref(dbatch.c), dbatch.n_reads, dbatch.n_bases, dbatch.n_cigar, dbatch.n_ref_bytes,
             dout.seq_length, dout.seq_overlap, C.byref(dout.c), dout.counts.data_ptr(), stream or None))
 
-    def profile_begin(self):
-        _ffi.check(self.lib.pv_profile_begin(self.handle))
+    def profile_begin(self, only: str = None):
+        """bracket every kernel launch of this context with HIP events (only: just the kernels whose profile name starts
+        with it - two events per launch put a few microseconds between kernels)"""
+        if only:
+            _ffi.check(self.lib.pv_profile_begin_only(self.handle, only.encode()))
+        else:
+            _ffi.check(self.lib.pv_profile_begin(self.handle))
 
     def profile_end(self) -> dict:
         """-> {kernel name: (total ms, launches)} measured with HIP events on the launch stream"""
