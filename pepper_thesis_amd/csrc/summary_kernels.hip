@@ -71,11 +71,22 @@ struct AlleleRec {  // 32 B
     int32_t pad2;
 };
 
-struct PairRec {  // 48 B: everything a tile workgroup needs to walk one (read, tile) pair
+constexpr int SUB_COLS = 64;                      // k_collect's sub-tile index: op offsets at every 64th column of the tile
+constexpr int SUB_N = TILE_COLS / SUB_COLS;       // 8
+struct PairRec {  // 64 B: everything a tile workgroup needs to walk one (read, tile) pair
     int32_t read, op_lo, op_hi, col_base;
     int32_t R, c_last, ref_len, rev;   // rev: bit0 strand; haplotag builder: bits 1-2 count sets, bits 3-4 symbol sets
     int64_t base0, seq_end;
+    // byte k of subw, k = 0 .. SUB_N: (first op that starts at or behind column 64 k of the tile) - op_lo, saturated at 255; byte
+    // SUB_N + 1: 1 when the index is there. A site at column c of the tile searches ops [op_lo + sub[c / 64], op_lo + sub[c / 64 + 1]]
+    // only (~11 ops in one or two cache lines instead of ~90 in seven scattered probes).
+    uint32_t subw[4];
+    __device__ __forceinline__ int sub(int k) const {
+        const uint32_t w = k < 4 ? subw[0] : (k < 8 ? subw[1] : subw[2]);
+        return (int)((w >> (8 * (k & 3))) & 0xFFu);
+    }
 };
+static_assert(sizeof(PairRec) == 64, "PairRec layout");
 
 struct SumArgs {
     pv_batch_in in;
@@ -275,7 +286,12 @@ __global__ __launch_bounds__(256) void k_cigar_scan(SumArgs a) {
 // than TF_CAP tiles (regions beyond 130 kb) still search.
 constexpr int TF_CAP = 256;
 __global__ __launch_bounds__(256) void k_tile_fill(SumArgs a) {
-    __shared__ int32_t s_lo[4][TF_CAP + 1], s_hi[4][TF_CAP + 1];   // per wave: lower / upper bound of the boundaries of tiles t0 .. t1 + 1
+    // per wave: lower bound of every 64-column boundary from the first column of tile t0 to that of tile t1 + 1, upper bound of
+    // the tile boundaries
+    // (16-bit op offsets from the read's first op: 18 KB per workgroup, so that eight of them still fit a CU; a read with more
+    // than 65535 ops - or over more than TF_CAP tiles - takes the searches and leaves no sub-tile index)
+    __shared__ uint16_t s_lo[4][TF_CAP * SUB_N + 2];
+    __shared__ int32_t s_hi[4][TF_CAP + 1];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int64_t r = (int64_t)blockIdx.x * 4 + wv;
     if (r >= a.n_reads || a.diag[D_STATUS] != 0) return;
@@ -285,9 +301,10 @@ __global__ __launch_bounds__(256) void k_tile_fill(SumArgs a) {
     const int64_t cb0 = a.in.ref_off[g];
     const int32_t c0 = (int32_t)a.in.cigar_off[r], c1 = (int32_t)a.in.cigar_off[r + 1];
     const int nb = t1 - t0 + 2;   // boundaries: first columns of tiles t0 .. t1 + 1
-    const bool table = nb <= TF_CAP + 1;
+    const bool table = nb <= TF_CAP + 1 && c1 - c0 <= 65535;
     if (table) {
-        for (int i = lane; i < nb; i += 64) { s_lo[wv][i] = c1; s_hi[wv][i] = c1; }   // no op at or behind the boundary
+        for (int i = lane; i < nb; i += 64) s_hi[wv][i] = c1;                         // no op behind the boundary
+        for (int i = lane; i < (nb - 1) * SUB_N + 1; i += 64) s_lo[wv][i] = (uint16_t)(c1 - c0);   // no op at or behind the boundary
         auto fetch = [&](int32_t cb) -> int32_t { return cb + lane < c1 ? a.op_ref[cb + lane] : OP_INACTIVE; };
         int32_t carry = -0x7fffffff - 1;   // "start column" of the op before the first
         auto trip = [&](const int32_t x, const int32_t cb) {
@@ -297,14 +314,17 @@ __global__ __launch_bounds__(256) void k_tile_fill(SumArgs a) {
             if (c < c1 && p != x) {
                 // boundaries b_t = t * TILE_COLS - cb0 (region-relative), t0 <= t <= t1 + 1
                 const int64_t pp = (int64_t)p + cb0, xx = (int64_t)x + cb0;
-                int64_t lo_a = (pp >> 9) + 1, lo_b = xx >> 9;                    // lower bound: p < b_t <= x
-                int64_t hi_a = (pp + 511) >> 9, hi_b = ((xx + 511) >> 9) - 1;    // upper bound: p <= b_t < x
-                static_assert(TILE_COLS == 512, ">> 9");
-                if (lo_a < t0) lo_a = t0;
+                // lower bound of the 64-column boundaries u (column 64 u, counted from the first column of tile t0): p < b_u <= x
+                const int64_t org = (int64_t)t0 * TILE_COLS;
+                int64_t lo_a = ((pp - org) >> 6) + 1, lo_b = (xx - org) >> 6;
+                int64_t hi_a = (pp + 511) >> 9, hi_b = ((xx + 511) >> 9) - 1;    // upper bound of the tile boundaries: p <= b_t < x
+                static_assert(TILE_COLS == 512 && SUB_COLS == 64, ">> 9, >> 6");
+                const int64_t u_last = (int64_t)(nb - 1) * SUB_N;
+                if (lo_a < 0) lo_a = 0;
                 if (hi_a < t0) hi_a = t0;
-                if (lo_b > (int64_t)t1 + 1) lo_b = (int64_t)t1 + 1;
+                if (lo_b > u_last) lo_b = u_last;
                 if (hi_b > (int64_t)t1 + 1) hi_b = (int64_t)t1 + 1;
-                for (int64_t t = lo_a; t <= lo_b; t++) s_lo[wv][t - t0] = c;
+                for (int64_t u = lo_a; u <= lo_b; u++) s_lo[wv][u] = (uint16_t)(c - c0);
                 for (int64_t t = hi_a; t <= hi_b; t++) s_hi[wv][t - t0] = c;
             }
             carry = __builtin_amdgcn_readlane(x, 63);
@@ -320,10 +340,19 @@ __global__ __launch_bounds__(256) void k_tile_fill(SumArgs a) {
     }
     for (int32_t t = t0 + lane; t <= t1; t += 64) {
         int32_t op_lo, op_hi;
+        PairRec pr;
+        pr.subw[0] = pr.subw[1] = pr.subw[2] = pr.subw[3] = 0u;
         if (table) {
-            const int32_t lower = s_lo[wv][t - t0];                 // first op with op_ref >= first column of tile t
+            const uint16_t* lo_t = &s_lo[wv][(t - t0) * SUB_N];
+            const int32_t lower = c0 + lo_t[0];                     // first op with op_ref >= first column of tile t
             op_lo = lower > c0 ? lower - 1 : c0;
             op_hi = s_hi[wv][t + 1 - t0];                           // first op with op_ref > first column of tile t + 1
+#pragma unroll
+            for (int k = 0; k <= SUB_N; k++) {
+                const int32_t d = c0 + (int32_t)lo_t[k] - op_lo;
+                pr.subw[k >> 2] |= (uint32_t)(d > 255 ? 255 : d) << (8 * (k & 3));
+            }
+            pr.subw[(SUB_N + 1) >> 2] |= 1u << (8 * ((SUB_N + 1) & 3));
         } else {
             const int64_t tlo = (int64_t)t * TILE_COLS - cb0, thi = tlo + TILE_COLS - 1;  // region-relative columns
             int32_t lo = c0, hi = c1;  // first op with op_ref >= tlo
@@ -334,7 +363,6 @@ __global__ __launch_bounds__(256) void k_tile_fill(SumArgs a) {
             op_hi = lo;
         }
         const int32_t slot = a.tile_off[t] + atomicAdd(&a.tile_fill[t], 1);
-        PairRec pr;
         pr.read = (int32_t)r; pr.op_lo = op_lo; pr.op_hi = op_hi; pr.col_base = (int32_t)cb0;
         pr.R = (int32_t)(a.in.ref_end[g] - a.in.ref_start[g] + 1);
         pr.c_last = c1 - 1;
@@ -1318,6 +1346,7 @@ __global__ __launch_bounds__(64 * KC_WAVES) void k_collect(SumArgs a) {
         const bool need_base = a.cnt[(a.hp ? C_SNP : C_RARE) * NC + col] != 0;
         const int refb = a.in.ref[col];
         const int64_t t = col / TILE_COLS;
+        const int sub_k = (int)(col - t * TILE_COLS) / SUB_COLS;
         const int32_t p0 = a.tile_off[t], np = a.tile_cnt[t];
         for (int32_t pb = 64 * wv; pb < np; pb += 64 * KC_WAVES) {
             if (pb + lane >= np) continue;
@@ -1326,8 +1355,15 @@ __global__ __launch_bounds__(64 * KC_WAVES) void k_collect(SumArgs a) {
             const bool rev = (pr.rev & 1) != 0;
             int obs = 1;  // flags of an allele observation
             if (a.hp) obs |= ((pr.rev >> 1) & 3) << 2;         // count sets of the read (k_tile_fill)
-            // first op of the pair's range that starts behind the column
+            // first op of the pair's range that starts behind the column; the pair's sub-tile index narrows the range to the ops
+            // between the 64-column boundaries around the site (every op before the first starts before the boundary at or before
+            // the column, no op from the second on starts at or before the column)
             int32_t lo = pr.op_lo, hi = pr.op_hi;
+            if (pr.sub(SUB_N + 1)) {
+                lo += pr.sub(sub_k);
+                const int s1 = pr.sub(sub_k + 1);
+                if (s1 < 255 && pr.op_lo + s1 < hi) hi = pr.op_lo + s1;
+            }
             while (lo < hi) { const int32_t mid = (lo + hi) >> 1; if (a.op_ref[mid] <= col_rel) lo = mid + 1; else hi = mid; }
             const int32_t f = lo;
             for (int32_t o = f; o < pr.op_hi; o++) {            // inserts / deletes anchored on the column
