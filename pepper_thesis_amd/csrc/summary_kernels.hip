@@ -88,6 +88,18 @@ struct PairRec {  // 64 B: everything a tile workgroup needs to walk one (read, 
 };
 static_assert(sizeof(PairRec) == 64, "PairRec layout");
 
+// What the per-site kernels need to know of a site before they can request anything else, as ONE 48-byte record written by
+// k_site_rank: they are chains of dependent round trips at full occupancy (~3 us each under that load), and column -> region
+// -> region geometry / tile range was two of those levels in each of them.
+struct SiteHdr {
+    int32_t col, col_base, R, g;      // global column, first column and length of its region, region
+    int32_t p0, np, cov, flags;       // pair list of its tile, coverage, flags: bits 0-7 reference byte, bit 8: base observations wanted
+                                      // (rare ones, or - haplotag form - SNP ones, were counted), bits 16-23: the site flag
+    int64_t ref_start;                // of its region
+    int32_t nev, pad;
+};
+static_assert(sizeof(SiteHdr) == 48, "SiteHdr layout");
+
 struct SumArgs {
     pv_batch_in in;
     pv_params p;
@@ -134,6 +146,7 @@ struct SumArgs {
     int32_t seq_len, seq_step;  // chunk length, chunk length - overlap
     int32_t* pcnt;        // [PC_N][n_cols] plane-major: 10 features, coverage, longest insert
     int32_t* tile_g0;     // [n_tiles] region of each tile's first column
+    SiteHdr* site_hdr;    // [max_sites]
     int32_t* ins_blk;     // [n_blk] insert rows per 1024-column block
     int32_t* ins_blkoff;  // [n_blk] exclusive scan
     int32_t* ins_off;     // [n_cols + 1] insert rows before every column
@@ -1296,12 +1309,25 @@ __global__ __launch_bounds__(1024) void k_site_rank(SumArgs a) {
     const int32_t rank = a.blk_off[blockIdx.x * (1024 / TILE_COLS)] + woff + before;  // block offsets are per tile
     if (site && rank < a.max_sites) {
         const int64_t NC = a.n_cols;
+        const int g = upper_bound_i64(a.in.ref_off, a.in.n_regions + 1, col) - 1;
         a.site_col[rank] = (int32_t)col;
-        a.site_region[rank] = upper_bound_i64(a.in.ref_off, a.in.n_regions + 1, col) - 1;
+        a.site_region[rank] = g;
         // events a site will receive: every insert / delete observation, and either the rare SNP observations (the
         // common ones are read off the symbol planes) or, in the haplotag form, every SNP observation
-        a.site_nev[rank] = a.cnt[C_INS * NC + col] + a.cnt[C_DEL * NC + col] + a.cnt[(a.hp ? C_SNP : C_RARE) * NC + col];
+        const int n_base = a.cnt[(a.hp ? C_SNP : C_RARE) * NC + col];
+        const int nev = a.cnt[C_INS * NC + col] + a.cnt[C_DEL * NC + col] + n_base;
+        a.site_nev[rank] = nev;
         a.site_fill[rank] = 0;
+        SiteHdr h;
+        h.col = (int32_t)col; h.col_base = (int32_t)a.in.ref_off[g]; h.g = g;
+        h.ref_start = a.in.ref_start[g];
+        h.R = (int32_t)(a.in.ref_end[g] - h.ref_start + 1);
+        const int64_t t = col / TILE_COLS;
+        h.p0 = a.tile_off[t]; h.np = a.tile_cnt[t];
+        h.cov = a.cnt[C_COV * NC + col];
+        h.flags = (int32_t)a.in.ref[col] | (n_base != 0 ? 256 : 0) | (f << 16);
+        h.nev = nev; h.pad = 0;
+        a.site_hdr[rank] = h;
     }
 }
 
@@ -1335,19 +1361,17 @@ __global__ __launch_bounds__(64 * KC_WAVES) void k_collect(SumArgs a) {
     if (a.diag[D_STATUS] != 0) return;
     int64_t n_sites = a.diag[D_NSITES];
     if (n_sites > a.max_sites) n_sites = a.max_sites;
-    const int64_t NC = a.n_cols;
     for (int64_t sj = blockIdx.x >> 3; sj < xcd_chunk(n_sites); sj += gridDim.x >> 3) {
         const int64_t s = xcd_site(sj, n_sites);
         if (s >= n_sites) break;
-        const int64_t col = a.site_col[s];
-        const int g = a.site_region[s];
-        const int64_t col_base = a.in.ref_off[g];
+        const SiteHdr h = a.site_hdr[s];
+        const int64_t col = h.col;
+        const int64_t col_base = h.col_base;
         const int32_t col_rel = (int32_t)(col - col_base);
-        const bool need_base = a.cnt[(a.hp ? C_SNP : C_RARE) * NC + col] != 0;
-        const int refb = a.in.ref[col];
-        const int64_t t = col / TILE_COLS;
-        const int sub_k = (int)(col - t * TILE_COLS) / SUB_COLS;
-        const int32_t p0 = a.tile_off[t], np = a.tile_cnt[t];
+        const bool need_base = (h.flags & 256) != 0;
+        const int refb = h.flags & 0xFF;
+        const int sub_k = (int)(col & (TILE_COLS - 1)) / SUB_COLS;
+        const int32_t p0 = h.p0, np = h.np;
         for (int32_t pb = 64 * wv; pb < np; pb += 64 * KC_WAVES) {
             if (pb + lane >= np) continue;
             const PairRec pr = a.pairs[p0 + pb + lane];
@@ -1468,13 +1492,14 @@ __global__ __launch_bounds__(64) void k_site_alleles(SumArgs a) {
     for (int64_t sj = blockIdx.x >> 3; sj < xcd_chunk(n_sites); sj += gridDim.x >> 3) {
         const int64_t s = xcd_site(sj, n_sites);
         if (s >= n_sites) break;
-        if ((a.site_nev[s] + 4 > UM_SMALL) != BIG) continue;   // the other instantiation's site
-        const int64_t col = a.site_col[s];
+        const SiteHdr h = a.site_hdr[s];
+        if ((h.nev + 4 > UM_SMALL) != BIG) continue;   // the other instantiation's site
+        const int64_t col = h.col;
         const int64_t NC = a.n_cols;
-        const int f = a.flags[col];
-        const int cov = a.cnt[C_COV * NC + col];
+        const int f = (h.flags >> 16) & 0xFF;
+        const int cov = h.cov;
         const int depth = cov < PV_MAX_COLOR ? cov : PV_MAX_COLOR;  // :682
-        const int refraw = a.in.ref[col];
+        const int refraw = h.flags & 0xFF;
         const bool refvalid = is_acgt(up(refraw));
         __syncthreads();
         // slots 0..3: SNP alleles whose counts are the (negated, un-clamped) A/C/G/T planes
@@ -1631,14 +1656,15 @@ __global__ __launch_bounds__(WW_THREADS) void k_write_windows(SumArgs a) {
         if (s >= n_sites) break;
         const int nemit = a.site_nemit[s];
         if (nemit == 0) continue;
-        const int64_t col = a.site_col[s];
-        const int g = a.site_region[s];
-        const int64_t col_base = a.in.ref_off[g];
-        const int64_t R = a.in.ref_end[g] - a.in.ref_start[g] + 1;
+        const SiteHdr h = a.site_hdr[s];
+        const int64_t col = h.col;
+        const int g = h.g;
+        const int64_t col_base = h.col_base;
+        const int64_t R = h.R;
         const int64_t ci = col - col_base;
-        const int cov = a.cnt[C_COV * NC + col];
+        const int cov = h.cov;
         const int depth = cov < PV_MAX_COLOR ? cov : PV_MAX_COLOR;
-        const int refraw = a.in.ref[col];
+        const int refraw = h.flags & 0xFF;
         const bool refvalid = is_acgt(up(refraw));
         const int64_t recbase = (int64_t)a.site_evoff[s] + 4 * s;
         int64_t so = a.site_stroff[s];
@@ -1724,7 +1750,7 @@ __global__ __launch_bounds__(WW_THREADS) void k_write_windows(SumArgs a) {
                 __syncthreads();
                 if (lane == 0) {
                     a.out.region[k] = g;
-                    a.out.position[k] = a.in.ref_start[g] + ci;
+                    a.out.position[k] = h.ref_start + ci;
                     a.out.depth[k] = (uint8_t)depth;
                     a.out.cand_freq[k] = (uint8_t)(rc.total < PV_MAX_COLOR ? rc.total : PV_MAX_COLOR);
                     a.out.cand_off[k] = so;
@@ -1756,12 +1782,13 @@ __global__ __launch_bounds__(WW_THREADS) void k_write_windows_hp(SumArgs a) {
         if (s >= n_sites) break;
         const int nemit = a.site_nemit[s];
         if (nemit == 0) continue;
-        const int64_t col = a.site_col[s];
-        const int g = a.site_region[s];
-        const int64_t col_base = a.in.ref_off[g];
-        const int64_t R = a.in.ref_end[g] - a.in.ref_start[g] + 1;
+        const SiteHdr h = a.site_hdr[s];
+        const int64_t col = h.col;
+        const int g = h.g;
+        const int64_t col_base = h.col_base;
+        const int64_t R = h.R;
         const int64_t ci = col - col_base;
-        const int cov = a.cnt[C_COV * NC + col];
+        const int cov = h.cov;
         const int depth = cov < PV_MAX_COLOR ? cov : PV_MAX_COLOR;
         const int64_t recbase = (int64_t)a.site_evoff[s] + 4 * s;
         int64_t so = a.site_stroff[s];
@@ -1820,7 +1847,7 @@ __global__ __launch_bounds__(WW_THREADS) void k_write_windows_hp(SumArgs a) {
                 __syncthreads();
                 if (lane == 0) {
                     a.out.region[k] = g;
-                    a.out.position[k] = a.in.ref_start[g] + ci;
+                    a.out.position[k] = h.ref_start + ci;
                     a.out.depth[k] = (uint8_t)depth;
                     a.out.cand_freq[k] = (uint8_t)(rc.total < PV_MAX_COLOR ? rc.total : PV_MAX_COLOR);
                     a.out.cand_off[k] = so;
@@ -2214,6 +2241,7 @@ static int summarize_launch(pv_ctx* ctx, const pv_batch_in* in, const pv_params*
     if ((rc = pv_get(ctx, "sum.blk_off", (size_t)a.n_tiles + 2, &a.blk_off))) return rc;
     if ((rc = pv_get(ctx, "sum.tile_g0", (size_t)a.n_tiles + 2, &a.tile_g0))) return rc;
     if ((rc = pv_get(ctx, "sum.site_col", max_sites, &a.site_col))) return rc;
+    if ((rc = pv_get(ctx, "sum.site_hdr", max_sites, &a.site_hdr))) return rc;
     if ((rc = pv_get(ctx, "sum.site_region", max_sites, &a.site_region))) return rc;
     if ((rc = pv_get(ctx, "sum.site_nev", max_sites, &a.site_nev))) return rc;
     if ((rc = pv_get(ctx, "sum.site_evoff", max_sites, &a.site_evoff))) return rc;
