@@ -46,7 +46,7 @@ constexpr int UM_SMALL = 96; // table of the k_site_alleles instantiation for si
 constexpr int TILE_COLS = 512;  // columns per pileup tile (one workgroup accumulates a tile in LDS)
 
 enum { D_SPARE = 8 };
-enum { D_NSITES = 0, D_NEVENTS = 1, D_NOUT = 2, D_STRBYTES = 3, D_STATUS = 4, D_NPAIRS = 5, D_NINS = 6, D_NROWS = 7, D_NCHUNKS = 8, D_NDIAG = 10 };
+enum { D_NSITES = 0, D_NEVENTS = 1, D_NOUT = 2, D_STRBYTES = 3, D_STATUS = 4, D_NPAIRS = 5, D_NINS = 6, D_NROWS = 7, D_NCHUNKS = 8, D_NBIG = 9, D_NDIAG = 10 };
 
 struct Event {  // 16 B
     int64_t src;  // index into bases (kind 1) or ref (kind 2)
@@ -121,7 +121,6 @@ struct SumArgs {
     int32_t* cnt;
     uint8_t* flags;
     int32_t* blk_cnt;
-    int32_t* blk_off;
     int32_t* site_col;
     int32_t* site_region;
     int32_t* site_nev;
@@ -147,6 +146,7 @@ struct SumArgs {
     int32_t* pcnt;        // [PC_N][n_cols] plane-major: 10 features, coverage, longest insert
     int32_t* tile_g0;     // [n_tiles] region of each tile's first column
     SiteHdr* site_hdr;    // [max_sites]
+    int32_t* big_sites;   // [max_sites] ranks of the sites whose events need the large allele table (diag[D_NBIG] of them)
     int32_t* ins_blk;     // [n_blk] insert rows per 1024-column block
     int32_t* ins_blkoff;  // [n_blk] exclusive scan
     int32_t* ins_off;     // [n_cols + 1] insert rows before every column
@@ -1218,12 +1218,6 @@ __global__ __launch_bounds__(1024) void k_scan_tiles(SumArgs a) {
     if (threadIdx.x == 0) a.diag[D_NPAIRS] = total;
 }
 
-// sites per tile -> offsets, total -> diag[D_NSITES]
-__global__ __launch_bounds__(1024) void k_scan_blocks(SumArgs a, int64_t n_blk) {
-    __shared__ int64_t s_w[32];
-    const int64_t total = block_excl_scan<int32_t>(a.blk_cnt, a.blk_off, n_blk, s_w);
-    if (threadIdx.x == 0) a.diag[D_NSITES] = total;
-}
 
 // events per site -> offsets, total -> diag[D_NEVENTS]; site / event workspace limits. Grid: scan_chunks(max_sites).
 __global__ __launch_bounds__(1024) void k_scan_events(SumArgs a) {
@@ -1295,18 +1289,31 @@ __global__ __launch_bounds__(1024) void k_scan_i32(const int32_t* in, int32_t* o
 }
 
 __global__ __launch_bounds__(1024) void k_site_rank(SumArgs a) {
-    __shared__ int32_t s_w[16];
+    __shared__ int32_t s_w[16], s_p[16];
     const int64_t col = (int64_t)blockIdx.x * 1024 + threadIdx.x;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int f = col < a.n_cols ? a.flags[col] : 0;
+    // sites before this block = the per-tile counts (k_pileup_tiles) of the tiles before it, added up here (at most 3 k values,
+    // three coalesced loads per thread) instead of by a scan kernel of its own in front of this one
+    const int64_t tiles_before = (int64_t)blockIdx.x * (1024 / TILE_COLS);
+    int part = 0;
+    for (int64_t i = threadIdx.x; i < tiles_before; i += 1024) part += a.blk_cnt[i];
+    const int pinc = wave_incl_scan32(part, lane);
     const int site = f & 1;
     const unsigned long long m = __ballot(site);
     const int before = __popcll(m & ((1ull << lane) - 1ull));
     if (lane == 0) s_w[wv] = __popcll(m);
+    if (lane == 63) s_p[wv] = pinc;
     __syncthreads();
-    int woff = 0;
-    for (int k = 0; k < wv; k++) woff += s_w[k];
-    const int32_t rank = a.blk_off[blockIdx.x * (1024 / TILE_COLS)] + woff + before;  // block offsets are per tile
+    int woff = 0, own = 0, base = 0;
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+        woff += k < wv ? s_w[k] : 0;
+        own += s_w[k];
+        base += s_p[k];
+    }
+    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) a.diag[D_NSITES] = (int64_t)base + own;   // the last block knows the total
+    const int32_t rank = base + woff + before;
     if (site && rank < a.max_sites) {
         const int64_t NC = a.n_cols;
         const int g = upper_bound_i64(a.in.ref_off, a.in.n_regions + 1, col) - 1;
@@ -1328,6 +1335,8 @@ __global__ __launch_bounds__(1024) void k_site_rank(SumArgs a) {
         h.flags = (int32_t)a.in.ref[col] | (n_base != 0 ? 256 : 0) | (f << 16);
         h.nev = nev; h.pad = 0;
         a.site_hdr[rank] = h;
+        // the few sites whose events exceed the small allele table are listed for the large-table launch of k_site_alleles
+        if (nev + 4 > UM_SMALL) a.big_sites[atomicAdd((unsigned long long*)&a.diag[D_NBIG], 1ull)] = rank;
     }
 }
 
@@ -1489,9 +1498,10 @@ __global__ __launch_bounds__(64) void k_site_alleles(SumArgs a) {
     if (a.diag[D_STATUS] != 0) return;
     int64_t n_sites = a.diag[D_NSITES];
     if (n_sites > a.max_sites) n_sites = a.max_sites;
-    for (int64_t sj = blockIdx.x >> 3; sj < xcd_chunk(n_sites); sj += gridDim.x >> 3) {
-        const int64_t s = xcd_site(sj, n_sites);
-        if (s >= n_sites) break;
+    const int64_t n_big = BIG ? a.diag[D_NBIG] : 0;
+    for (int64_t sj = BIG ? blockIdx.x : blockIdx.x >> 3; sj < (BIG ? n_big : xcd_chunk(n_sites)); sj += BIG ? gridDim.x : gridDim.x >> 3) {
+        const int64_t s = BIG ? a.big_sites[sj] : xcd_site(sj, n_sites);
+        if (s >= n_sites) { if (BIG) continue; else break; }
         const SiteHdr h = a.site_hdr[s];
         if ((h.nev + 4 > UM_SMALL) != BIG) continue;   // the other instantiation's site
         const int64_t col = h.col;
@@ -2238,10 +2248,10 @@ static int summarize_launch(pv_ctx* ctx, const pv_batch_in* in, const pv_params*
     if ((rc = pv_get(ctx, "sum.cnt", (size_t)(hp ? NCNT_HP : NCNT) * n_cols, &a.cnt))) return rc;
     if ((rc = pv_get(ctx, "sum.flags", n_cols, &a.flags))) return rc;
     if ((rc = pv_get(ctx, "sum.blk_cnt", (size_t)a.n_tiles + 2, &a.blk_cnt))) return rc;   // per tile
-    if ((rc = pv_get(ctx, "sum.blk_off", (size_t)a.n_tiles + 2, &a.blk_off))) return rc;
     if ((rc = pv_get(ctx, "sum.tile_g0", (size_t)a.n_tiles + 2, &a.tile_g0))) return rc;
     if ((rc = pv_get(ctx, "sum.site_col", max_sites, &a.site_col))) return rc;
     if ((rc = pv_get(ctx, "sum.site_hdr", max_sites, &a.site_hdr))) return rc;
+    if ((rc = pv_get(ctx, "sum.big_sites", max_sites, &a.big_sites))) return rc;
     if ((rc = pv_get(ctx, "sum.site_region", max_sites, &a.site_region))) return rc;
     if ((rc = pv_get(ctx, "sum.site_nev", max_sites, &a.site_nev))) return rc;
     if ((rc = pv_get(ctx, "sum.site_evoff", max_sites, &a.site_evoff))) return rc;
@@ -2264,7 +2274,6 @@ static int summarize_launch(pv_ctx* ctx, const pv_batch_in* in, const pv_params*
         if (hp) k_pileup_tiles<true><<<(unsigned)a.n_tiles, PT_THREADS, 0, st>>>(a);
         else k_pileup_tiles<false><<<(unsigned)a.n_tiles, PT_THREADS, 0, st>>>(a);
     }
-    k_scan_blocks<<<1, 1024, 0, st>>>(a, a.n_tiles);
     k_site_rank<<<(unsigned)n_blk, 1024, 0, st>>>(a);
     k_scan_events<<<scan_chunks(a.max_sites), 1024, 0, st>>>(a);
     // per-site kernels are chains of dependent loads per wave: as many workgroups as can be resident (one site each for the
