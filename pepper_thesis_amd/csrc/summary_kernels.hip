@@ -1348,13 +1348,14 @@ __global__ __launch_bounds__(1024) void k_site_rank(SumArgs a) {
 __device__ __forceinline__ int64_t xcd_chunk(int64_t n_sites) { return (n_sites + 7) >> 3; }
 __device__ __forceinline__ int64_t xcd_site(int64_t j, int64_t n_sites) { return (int64_t)(blockIdx.x & 7) * xcd_chunk(n_sites) + j; }
 
-__device__ __forceinline__ void push_event(const SumArgs& a, int32_t s, int64_t src, int32_t len, int type, bool rev,
-                                           int kind, int flags) {
+// (nev, evoff: the site's bucket size and offset, read once per site by the caller)
+__device__ __forceinline__ void push_event(const SumArgs& a, int32_t s, int32_t nev, int64_t evoff, int64_t src, int32_t len,
+                                           int type, bool rev, int kind, int flags) {
     const int32_t slot = atomicAdd(&a.site_fill[s], 1);
-    if (slot >= a.site_nev[s]) { set_status(a.diag, PV_ERR_INVALID); return; }  // cannot happen: exact bucket sizes
+    if (slot >= nev) { set_status(a.diag, PV_ERR_INVALID); return; }  // cannot happen: exact bucket sizes
     Event e;
     e.src = src; e.len = len; e.type = (uint8_t)type; e.rev = rev ? 1 : 0; e.kind = (uint8_t)kind; e.flags = (uint8_t)flags;
-    a.ev[(int64_t)a.site_evoff[s] + slot] = e;
+    a.ev[evoff + slot] = e;
 }
 
 // One WAVE per SITE, one lane per (read, tile) pair of the site's tile: the allele observations a read contributes at that
@@ -1374,6 +1375,7 @@ __global__ __launch_bounds__(64 * KC_WAVES) void k_collect(SumArgs a) {
         const int64_t s = xcd_site(sj, n_sites);
         if (s >= n_sites) break;
         const SiteHdr h = a.site_hdr[s];
+        const int64_t evoff = a.site_evoff[s];
         const int64_t col = h.col;
         const int64_t col_base = h.col_base;
         const int32_t col_rel = (int32_t)(col - col_base);
@@ -1405,11 +1407,11 @@ __global__ __launch_bounds__(64 * KC_WAVES) void k_collect(SumArgs a) {
                 const int op = w & 0xF;
                 const int32_t len = (int32_t)(w >> 4);
                 if (op == PV_CIGAR_IN) {
-                    if (a.op_flag[o]) push_event(a, (int32_t)s, pr.base0 + a.op_rd[o] - 1, len + 1, 2, rev, 1, obs);
+                    if (a.op_flag[o]) push_event(a, (int32_t)s, h.nev, evoff, pr.base0 + a.op_rd[o] - 1, len + 1, 2, rev, 1, obs);
                 } else if (op == PV_CIGAR_DEL) {
                     int64_t L = (int64_t)len + 1;
                     if ((int64_t)col_rel + L > pr.ref_len) L = pr.ref_len - col_rel;
-                    if (a.op_flag[o]) push_event(a, (int32_t)s, col, (int32_t)L, 3, rev, 2, obs);
+                    if (a.op_flag[o]) push_event(a, (int32_t)s, h.nev, evoff, col, (int32_t)L, 3, rev, 2, obs);
                 }
             }
             if (!need_base) continue;
@@ -1429,13 +1431,13 @@ __global__ __launch_bounds__(64 * KC_WAVES) void k_collect(SumArgs a) {
                 const int base = a.in.bases[bi];
                 if (!((double)a.in.quals[bi] >= a.p.min_snp_baseq)) break;
                 if (a.hp) {  // every mismatch (raw bytes, region_summary_hp.cpp:406) is an allele observation
-                    if (refb != base) push_event(a, (int32_t)s, bi, 1, 1, rev, 1, obs);
+                    if (refb != base) push_event(a, (int32_t)s, h.nev, evoff, bi, 1, 1, rev, 1, obs);
                     break;
                 }
                 const bool refvalid = is_acgt(up(refb));
                 const bool rare = (refb != base) && !(refvalid && is_acgt(base));
                 const bool corr = refvalid && base != up(base) && is_acgt(up(base));
-                if (rare || corr) push_event(a, (int32_t)s, bi, 1, 1, rev, 1, (rare ? 1 : 0) | (corr ? 2 : 0));
+                if (rare || corr) push_event(a, (int32_t)s, h.nev, evoff, bi, 1, 1, rev, 1, (rare ? 1 : 0) | (corr ? 2 : 0));
                 break;
             }
         }
@@ -1503,6 +1505,7 @@ __global__ __launch_bounds__(64) void k_site_alleles(SumArgs a) {
         const int64_t s = BIG ? a.big_sites[sj] : xcd_site(sj, n_sites);
         if (s >= n_sites) { if (BIG) continue; else break; }
         const SiteHdr h = a.site_hdr[s];
+        const int64_t eoff = a.site_evoff[s];          // (requested together with the header)
         if ((h.nev + 4 > UM_SMALL) != BIG) continue;   // the other instantiation's site
         const int64_t col = h.col;
         const int64_t NC = a.n_cols;
@@ -1524,8 +1527,7 @@ __global__ __launch_bounds__(64) void k_site_alleles(SumArgs a) {
         }
         if (lane == 0) s_nU = HP ? 0 : 4;
         __syncthreads();
-        const int nev = a.site_nev[s];
-        const int64_t eoff = a.site_evoff[s];
+        const int nev = h.nev;
         for (int eb = 0; eb < nev; eb += 64) {
             const bool have = eb + lane < nev;
             Event e;
@@ -1664,9 +1666,12 @@ __global__ __launch_bounds__(WW_THREADS) void k_write_windows(SumArgs a) {
     for (int64_t sj = blockIdx.x >> 3; sj < xcd_chunk(n_sites); sj += gridDim.x >> 3) {
         const int64_t s = xcd_site(sj, n_sites);
         if (s >= n_sites) break;
+        // (everything a site's windows start from is requested at once, also for the two sites in three that emit nothing:
+        // one round trip instead of two for those that do)
         const int nemit = a.site_nemit[s];
-        if (nemit == 0) continue;
         const SiteHdr h = a.site_hdr[s];
+        const int64_t evoff_s = a.site_evoff[s], stroff_s = a.site_stroff[s], outoff_s = a.site_outoff[s];
+        if (nemit == 0) continue;
         const int64_t col = h.col;
         const int g = h.g;
         const int64_t col_base = h.col_base;
@@ -1676,11 +1681,11 @@ __global__ __launch_bounds__(WW_THREADS) void k_write_windows(SumArgs a) {
         const int depth = cov < PV_MAX_COLOR ? cov : PV_MAX_COLOR;
         const int refraw = h.flags & 0xFF;
         const bool refvalid = is_acgt(up(refraw));
-        const int64_t recbase = (int64_t)a.site_evoff[s] + 4 * s;
-        int64_t so = a.site_stroff[s];
+        const int64_t recbase = evoff_s + 4 * s;
+        int64_t so = stroff_s;
         for (int e = 0; e < nemit; e++) {
             const AlleleRec rc = a.rec[recbase + e];
-            const int64_t k = (int64_t)a.site_outoff[s] + e;
+            const int64_t k = outoff_s + e;
             const int64_t send = so + 1 + rc.len;
             if (k < a.out.capacity && send <= a.out.str_capacity) {
                 const int cfwd = rc.fwd < PV_MAX_COLOR ? rc.fwd : PV_MAX_COLOR;
@@ -1790,9 +1795,12 @@ __global__ __launch_bounds__(WW_THREADS) void k_write_windows_hp(SumArgs a) {
     for (int64_t sj = blockIdx.x >> 3; sj < xcd_chunk(n_sites); sj += gridDim.x >> 3) {
         const int64_t s = xcd_site(sj, n_sites);
         if (s >= n_sites) break;
+        // (everything a site's windows start from is requested at once, also for the two sites in three that emit nothing:
+        // one round trip instead of two for those that do)
         const int nemit = a.site_nemit[s];
-        if (nemit == 0) continue;
         const SiteHdr h = a.site_hdr[s];
+        const int64_t evoff_s = a.site_evoff[s], stroff_s = a.site_stroff[s], outoff_s = a.site_outoff[s];
+        if (nemit == 0) continue;
         const int64_t col = h.col;
         const int g = h.g;
         const int64_t col_base = h.col_base;
@@ -1800,11 +1808,11 @@ __global__ __launch_bounds__(WW_THREADS) void k_write_windows_hp(SumArgs a) {
         const int64_t ci = col - col_base;
         const int cov = h.cov;
         const int depth = cov < PV_MAX_COLOR ? cov : PV_MAX_COLOR;
-        const int64_t recbase = (int64_t)a.site_evoff[s] + 4 * s;
-        int64_t so = a.site_stroff[s];
+        const int64_t recbase = evoff_s + 4 * s;
+        int64_t so = stroff_s;
         for (int e = 0; e < nemit; e++) {
             const AlleleRec rc = a.rec[recbase + e];
-            const int64_t k = (int64_t)a.site_outoff[s] + e;
+            const int64_t k = outoff_s + e;
             const int64_t send = so + 1 + rc.len;
             if (k < a.out.capacity && send <= a.out.str_capacity) {
                 const int t = rc.type;  // 1 SNP, 2 INS, 3 DEL
