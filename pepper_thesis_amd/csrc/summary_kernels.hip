@@ -1316,7 +1316,8 @@ __global__ __launch_bounds__(1024) void k_site_rank(SumArgs a) {
     const int32_t rank = base + woff + before;
     if (site && rank < a.max_sites) {
         const int64_t NC = a.n_cols;
-        const int g = upper_bound_i64(a.in.ref_off, a.in.n_regions + 1, col) - 1;
+        int g = a.tile_g0[col / TILE_COLS];   // region of the tile's first column (k_init), then forwards: two dependent loads, not five
+        while (g + 1 <= a.in.n_regions && a.in.ref_off[g + 1] <= col) g++;
         a.site_col[rank] = (int32_t)col;
         a.site_region[rank] = g;
         // events a site will receive: every insert / delete observation, and either the rare SNP observations (the
