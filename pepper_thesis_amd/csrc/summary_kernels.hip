@@ -183,6 +183,20 @@ __device__ __forceinline__ int upper_bound_i64(const int64_t* a, int n, int64_t 
     }
     return lo;
 }
+// The same answer (number of entries <= v) for the short ascending offset tables of a batch (regions + 1 entries) in ONE round
+// trip: every entry is requested at once and compared, instead of five dependent probes. wave_: v uniform over the wave, an
+// entry per lane; thread_: independent loads in a short loop. Longer tables take the search.
+__device__ __forceinline__ int wave_count_le(const int64_t* a, int n, int64_t v, int lane) {
+    if (n > 64) return upper_bound_i64(a, n, v);
+    const bool le = lane < n && a[lane] <= v;
+    return __popcll(__ballot(le));
+}
+__device__ __forceinline__ int thread_count_le(const int64_t* a, int n, int64_t v) {
+    if (n > 32) return upper_bound_i64(a, n, v);
+    int c = 0;
+    for (int i = 0; i < n; i++) c += a[i] <= v ? 1 : 0;
+    return c;
+}
 
 __device__ __forceinline__ int64_t last_lane(int64_t v) {   // lane 63's value in every lane (scalar reads, no LDS permute)
     const unsigned lo = __builtin_amdgcn_readlane((unsigned)v, 63), hi = __builtin_amdgcn_readlane((unsigned)((uint64_t)v >> 32), 63);
@@ -227,7 +241,7 @@ __global__ __launch_bounds__(256) void k_cigar_scan(SumArgs a) {
     const int lane = threadIdx.x & 63;
     const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (r >= a.n_reads) return;
-    const int g = upper_bound_i64(a.in.read_off, a.in.n_regions + 1, r) - 1;
+    const int g = wave_count_le(a.in.read_off, a.in.n_regions + 1, r, lane) - 1;
     if (lane == 0) a.read_region[r] = g;
     const int64_t c0 = a.in.cigar_off[r], c1 = a.in.cigar_off[r + 1];
     const bool skip = a.in.read_mapq[r] == 0;  // :619
@@ -2199,7 +2213,7 @@ __global__ __launch_bounds__(256) void k_init(SumArgs a) {
         a.tile_fill[i] = 0;
         if (a.blk_cnt) {  // (builder pipelines; the polisher's has no site lists)
             a.blk_cnt[i] = 0;
-            a.tile_g0[i] = upper_bound_i64(a.in.ref_off, a.in.n_regions + 1, i * TILE_COLS) - 1;
+            a.tile_g0[i] = thread_count_le(a.in.ref_off, a.in.n_regions + 1, i * TILE_COLS) - 1;
         }
     }
 }
