@@ -65,19 +65,6 @@ __device__ __forceinline__ void split8_store(float x, __amdgpu_buffer_rsrc_t r, 
     __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(unsigned short, lo), r, voff, soff + 16u, 0);
 }
 __device__ __forceinline__ unsigned split8_off(unsigned k) { return (k >> 3) * 32u + (k & 7u) * 2u; }
-// The same store for a wave whose lanes 2i, 2i + 1 hold elements k (even), k + 1 of one row: the pair swaps its (hi, lo) words
-// and the even lane writes {hi(k), hi(k+1)}, the odd lane {lo(k), lo(k+1)} - one 4-byte store per lane instead of two 2-byte
-// ones (the 2-byte form cost the encoder 0.24 ms per 8192 windows against its fp32-output form).
-// voff_pair = split8_pair_voff(voff of the lane's own element, lane).
-__device__ __forceinline__ unsigned split8_pair_voff(unsigned voff, int lane) { return (lane & 1) ? voff - 2u + 16u : voff; }
-__device__ __forceinline__ void split8_store_pair(float x, __amdgpu_buffer_rsrc_t r, unsigned voff_pair, unsigned soff, int lane) {
-    const __bf16 hi = (__bf16)x;
-    const __bf16 lo = (__bf16)(x - (float)hi);
-    const unsigned own = (unsigned)__builtin_bit_cast(unsigned short, hi) | ((unsigned)__builtin_bit_cast(unsigned short, lo) << 16);
-    const unsigned oth = (unsigned)__builtin_amdgcn_update_dpp(0, (int)own, 0xB1, 0xf, 0xf, false);   // quad_perm [1,0,3,2]: the partner's
-    const unsigned val = (lane & 1) ? ((oth >> 16) | (own & 0xffff0000u)) : ((own & 0xffffu) | (oth << 16));
-    __builtin_amdgcn_raw_buffer_store_b32(val, r, voff_pair, soff, 0);
-}
 
 // ---- weight-fragment rings ------------------------------------------------------------------------------------------
 // The B operand (packed weights, one f32x4 per lane per gate tile per k-block of 8) comes from L2, ~1 us away, while a
@@ -276,7 +263,7 @@ __global__ __launch_bounds__(512, 2) void k_lstm_layer(LstmArgs a) {
     };
     const unsigned h_l = (unsigned)(lane_row<TR>(lane) * LDH + unit0);                      // lane part of the h tile offset
     const unsigned og_l = (unsigned)((lane_row<TR>(lane) * T_STEPS * 2 * H + unit0) * 4);   // lane part of the output byte offset
-    const unsigned sg_l = split8_pair_voff((unsigned)(lane_row<TR>(lane) * 2 * H * 4) + split8_off((unsigned)unit0), lane);  // same for the split8 rows (unit0 + 16 adds two groups); lane pairs hold units 2i, 2i + 1
+    const unsigned sg_l = (unsigned)(lane_row<TR>(lane) * 2 * H * 4) + split8_off((unsigned)unit0);  // same for the split8 rows (unit0 + 16 adds two groups)
     x_load(dir ? T_STEPS - 1 : 0);
     x_store();
     __syncthreads();
@@ -310,7 +297,7 @@ __global__ __launch_bounds__(512, 2) void k_lstm_layer(LstmArgs a) {
             const unsigned o_s = (unsigned)((t * 2 * H + dir * H + elem_row<TR>(e) * T_STEPS * 2 * H + elem_unit<TR>(e)) * 4);
             if (a.out) PV_OSTORE(h, osr, og_l, o_s);
             if (a.out_split)   // row (t, b), element dir*H + unit
-                split8_store_pair(h, ssr, sg_l, (unsigned)(((size_t)t * a.Bp + elem_row<TR>(e)) * 2 * H * 4 + split8_off(dir * H + elem_unit<TR>(e))), lane);
+                split8_store(h, ssr, sg_l, (unsigned)(((size_t)t * a.Bp + elem_row<TR>(e)) * 2 * H * 4 + split8_off(dir * H + elem_unit<TR>(e))));
         }
         lds_barrier();  // everyone is done reading xbuf / hbuf[cur]; hbuf[nxt] is complete (LDS only: mfma_tiles.hpp)
         if (s + 1 < T_STEPS) {
@@ -1010,7 +997,7 @@ __global__ __launch_bounds__(512, 2) void k_lstm_rec_g(RecArgs a) {
     const unsigned gl_l = (unsigned)(((lane >> 5) * 2048 + (lane & 31)) * 16);  // quad h of a group of 8 rows, this lane's column
     const unsigned og_l = (unsigned)((4 * (lane >> 5) * T_STEPS * 2 * H + (lane & 31)) * 4);
     const __amdgpu_buffer_rsrc_t ssr = make_rsrc(a.out_split + (size_t)b0 * T_STEPS * 2 * H * 4);
-    const unsigned sg_l = split8_pair_voff((unsigned)(4 * (lane >> 5) * T_STEPS * 2 * H * 4) + split8_off((unsigned)(lane & 31)), lane);
+    const unsigned sg_l = (unsigned)(4 * (lane >> 5) * T_STEPS * 2 * H * 4) + split8_off((unsigned)(lane & 31));
     __syncthreads();
     for (int s = 0; s < T_STEPS; s++) {
         const int t = dir ? (T_STEPS - 1 - s) : s;
@@ -1045,7 +1032,7 @@ __global__ __launch_bounds__(512, 2) void k_lstm_rec_g(RecArgs a) {
             const unsigned o_s = (unsigned)((t * 2 * H + dir * H + UW * wv + rr * T_STEPS * 2 * H) * 4);
             if (a.out) buf_store1_nt(h, osr, og_l, o_s);
             // row b, element k = t*512 + dir*256 + unit: flattened [t][512] = K index of linear_1
-            split8_store_pair(h, ssr, sg_l, (unsigned)(rr * T_STEPS * 2 * H * 4) + split8_off((unsigned)(t * 2 * H + dir * H + UW * wv)), lane);
+            split8_store(h, ssr, sg_l, (unsigned)(rr * T_STEPS * 2 * H * 4) + split8_off((unsigned)(t * 2 * H + dir * H + UW * wv)));
         }
         lds_barrier();
     }
