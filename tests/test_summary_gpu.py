@@ -193,3 +193,84 @@ def test_quality_bar_anywhere_in_the_byte_range(hip_ctx, oracle_lib, min_q):
     P = replace(PRESETS["ont_r9_guppy5_sup"], min_snp_baseq=min_q)
     o = hip_ctx.summarize(b, P, True)
     assert_summary_equal(o, summary_as_expected(oracle_lib.summarize(b, P, True)), "min_snp_baseq %g" % min_q)
+
+
+def _mutated(ref, rng, rate):
+    seq = ref.copy()
+    flip = rng.random(len(seq)) < rate
+    seq[flip] = np.frombuffer(b"ACGT", np.uint8)[(np.searchsorted(np.frombuffer(b"ACGT", np.uint8), seq[flip]) + 1) % 4]
+    return seq
+
+
+def test_read_over_more_than_256_tiles_takes_the_search_path(hip_ctx, oracle_lib):
+    """k_tile_fill keeps a per-wave table of a read's tile boundaries for up to 256 tiles; a read over more of them (a region
+    beyond 131 kb) finds its op ranges by binary search and carries no sub-tile index (k_collect then searches the whole range)"""
+    from pepper_thesis_amd.batch import Read, Region
+    rng = np.random.default_rng(41)
+    R = 140_000
+    ref = rng.choice(np.frombuffer(b"ACGT", np.uint8), size=R).astype(np.uint8)
+    reads = []
+    for i in range(8):
+        if i < 4:   # one op over 270 tiles
+            reads.append(Read.make(200, "%dM" % (R - 1000), _mutated(ref[200:R - 800], rng, 0.002).tobytes(), 25, i % 2 == 0))
+        else:       # many ops over 270 tiles: 900M 1I 900M 2D ...
+            cig, seq, pos = [], [], 300
+            while pos + 2000 < R - 500:
+                cig.append("900M1I900M2D")
+                seq.append(_mutated(ref[pos:pos + 900], rng, 0.002).tobytes() + b"A" + _mutated(ref[pos + 900:pos + 1800], rng, 0.002).tobytes())
+                pos += 1802
+            reads.append(Read.make(300, "".join(cig), b"".join(seq), 25, i % 2 == 0))
+    b = pack_regions([Region(0, R - 1, ref.tobytes(), reads)])
+    P = PRESETS["ont_r9_guppy5_sup"]
+    o = hip_ctx.summarize(b, P, True)
+    assert_summary_equal(o, summary_as_expected(oracle_lib.summarize(b, P, True)), "270 tiles")
+    assert len(o) > 100
+
+
+def test_read_with_more_than_65535_ops(hip_ctx, oracle_lib):
+    """the tile-boundary table holds 16-bit op offsets: a read with more ops than that takes the search path as well"""
+    from pepper_thesis_amd.batch import Read, Region
+    rng = np.random.default_rng(43)
+    n_units = 34_000                       # 1M1D x 34 000 = 68 000 ops over 68 000 columns
+    R = 2 * n_units + 400
+    ref = rng.choice(np.frombuffer(b"ACGT", np.uint8), size=R).astype(np.uint8)
+    reads = []
+    for i in range(5):
+        seq = ref[100:100 + 2 * n_units:2].copy()      # the bases under the M ops
+        seq = _mutated(seq, rng, 0.01)
+        reads.append(Read.make(100, "1M1D" * n_units, seq.tobytes(), 25, i % 2 == 0))
+    for i in range(5):                                  # ordinary reads over the same columns
+        reads.append(Read.make(50, "%dM" % (R - 100), _mutated(ref[50:R - 50], rng, 0.01).tobytes(), 25, i % 2 == 1))
+    b = pack_regions([Region(0, R - 1, ref.tobytes(), reads)])
+    P = PRESETS["ont_r9_guppy5_sup"]
+    o = hip_ctx.summarize(b, P, True)
+    assert_summary_equal(o, summary_as_expected(oracle_lib.summarize(b, P, True)), "68 k ops")
+    assert len(o) > 100
+
+
+def test_op_batches_beyond_the_lookup_tables(hip_ctx, oracle_lib):
+    """k_pileup_tiles finds an op's pair / a slot's op through owner tables of fixed size (24 k ops per pair batch, 32 k base slots
+    per op batch) and searches beyond them: (a) 140 reads that are one long match each (512 slots per op), (b) 140 reads with
+    an op on nearly every column (over 100 k ops in a pair batch)"""
+    from pepper_thesis_amd.batch import Read, Region
+    rng = np.random.default_rng(47)
+    R = 1500
+    ref = rng.choice(np.frombuffer(b"ACGT", np.uint8), size=R).astype(np.uint8)
+    P = PRESETS["ont_r9_guppy5_sup"]
+    alt = _mutated(ref, rng, 0.02)          # shared differences -> sites
+    reads = [Read.make(0, "%dM" % R, _mutated(alt, rng, 0.01).tobytes(), 25, i % 2 == 0) for i in range(140)]
+    b = pack_regions([Region(0, R - 1, ref.tobytes(), reads)])
+    o = hip_ctx.summarize(b, P, True)
+    assert_summary_equal(o, summary_as_expected(oracle_lib.summarize(b, P, True)), "long matches")
+    assert len(o) > 10
+    reads = []
+    for i in range(140):
+        n_units = (R - 20) // 2
+        seq = bytearray()
+        for u in range(n_units):            # 1M1I1M: two reference bases, three read bases
+            seq += bytes([int(alt[10 + 2 * u]), ord("ACGT"[(u + (i & 1)) % 4]), int(alt[11 + 2 * u])])
+        reads.append(Read.make(10, "1M1I1M" * n_units, bytes(seq), 25, i % 2 == 0))
+    b = pack_regions([Region(0, R - 1, ref.tobytes(), reads)])
+    o = hip_ctx.summarize(b, P, True)
+    assert_summary_equal(o, summary_as_expected(oracle_lib.summarize(b, P, True)), "dense ops")
+    assert len(o) > 10
