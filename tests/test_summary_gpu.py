@@ -274,3 +274,27 @@ def test_op_batches_beyond_the_lookup_tables(hip_ctx, oracle_lib):
     o = hip_ctx.summarize(b, P, True)
     assert_summary_equal(o, summary_as_expected(oracle_lib.summarize(b, P, True)), "dense ops")
     assert len(o) > 10
+
+
+def test_more_than_8192_tiles_in_a_batch(hip_ctx, oracle_lib):
+    """the tile scan is one workgroup looping over 8192-entry passes: 4.4 M columns are 8 594 tiles (two passes)"""
+    from pepper_thesis_amd.batch import Read, Region
+    rng = np.random.default_rng(53)
+    regs = []
+    for g in range(44):
+        R = 100_000
+        ref = rng.choice(np.frombuffer(b"ACGT", np.uint8), size=R).astype(np.uint8)
+        start = int(rng.integers(1000, R - 3000))
+        alt = _mutated(ref[start:start + 1500], rng, 0.02)
+        reads = [Read.make(start, "1500M", _mutated(alt, rng, 0.005).tobytes(), 25, i % 2 == 0) for i in range(6)]
+        regs.append(Region(g * 1_000_000, g * 1_000_000 + R - 1, ref.tobytes(),
+                           [Read.make(g * 1_000_000 + r.pos, r.cigar, r.bases, r.quals, r.is_reverse, r.mapq) for r in reads]))
+    b = pack_regions(regs)
+    assert (b.ref.shape[0] + 511) // 512 > 8192
+    P = PRESETS["ont_r9_guppy5_sup"]
+    o = hip_ctx.summarize(b, P, False)
+    e = oracle_lib.summarize(b, P, False)
+    assert len(o) == len(e) > 100
+    np.testing.assert_array_equal(o.images, e.images)
+    np.testing.assert_array_equal(o.position, e.position)
+    assert o.candidates == e.candidates
