@@ -270,6 +270,11 @@ def test_op_batches_beyond_the_lookup_tables(hip_ctx, oracle_lib):
         for u in range(n_units):            # 1M1I1M: two reference bases, three read bases
             seq += bytes([int(alt[10 + 2 * u]), ord("ACGT"[(u + (i & 1)) % 4]), int(alt[11 + 2 * u])])
         reads.append(Read.make(10, "1M1I1M" * n_units, bytes(seq), 25, i % 2 == 0))
+    # ... and reads with 300 one-base inserts in a row (more than 255 ops inside 64 columns: the sub-tile index of their pair
+    # records saturates)
+    for i in range(6):
+        seq = alt[40:340].tobytes() + b"ACGT" * 75 + alt[340:900].tobytes()
+        reads.append(Read.make(40, "300M" + "1I" * 300 + "560M", seq, 25, i % 2 == 0))
     b = pack_regions([Region(0, R - 1, ref.tobytes(), reads)])
     o = hip_ctx.summarize(b, P, True)
     assert_summary_equal(o, summary_as_expected(oracle_lib.summarize(b, P, True)), "dense ops")
