@@ -423,7 +423,7 @@ __global__ __launch_bounds__(256) void k_tile_fill(SumArgs a) {
 //                 so lanes stay busy whatever the CIGAR run lengths are and bytes are read coalesced.
 constexpr int PT_THREADS = 512;
 constexpr int PT_PB = 128;  // pairs per batch
-constexpr int PT_GPL = 2;   // groups of 4 consecutive bases per thread per trip (groups strided by the block size)
+constexpr int PT_GPL = 1;   // groups of 4 consecutive bases per thread per trip (groups strided by the block size)
 // counters of a tile live in LDS with the column index swizzled so that the 64 lanes of a wave, which hold columns
 // c, c+4, c+8, ... for the same group element, hit 64 consecutive banks
 // (= ((lc & 3) << 7) | (lc >> 2) for 0 <= lc < 512, as one multiply-add and one bit-field extract: lc * 513 = lc | lc << 9)
