@@ -286,9 +286,16 @@ int pv_comm_create(pv_ctx* ctx, const char* id128, int rank, int world, pv_comm*
 void pv_comm_destroy(pv_comm* comm);
 /* Every rank passes its n_rows rows of row_bytes bytes (DEVICE memory). counts_out [world] (host, optional) receives the
  * per-rank row counts on every rank when the call returns; on `dst` the rows arrive rank-major in d_recv (DEVICE, capacity
- * recv_capacity_rows rows) asynchronously on `stream`; other ranks may pass NULL for d_recv. */
+ * recv_capacity_rows rows) asynchronously on `stream`; other ranks may pass NULL for d_recv.
+ * The capacity test is COLLECTIVE: the counts are all-gathered together with the destination's capacity, so when the rows do
+ * not fit EVERY rank returns PV_ERR_CAPACITY (counts_out filled) before any send or receive is posted - no rank is left
+ * waiting for a partner that gave up. A destination that passes NULL for d_recv announces capacity 0. */
 int pv_gather(pv_ctx* ctx, pv_comm* comm, const void* d_send, int64_t n_rows, int row_bytes, void* d_recv,
               int64_t recv_capacity_rows, int64_t* counts_out, int dst, void* stream);
+
+/* The count exchange alone (one all-gather of an int64 per rank): lets the destination size its receive buffer for ragged
+ * ranks before pv_gather. counts_out [world] on every rank. */
+int pv_gather_counts(pv_ctx* ctx, pv_comm* comm, int64_t n_rows, int64_t* counts_out, void* stream);
 
 /* Diagnostic (tests, tuning): C = A . W^T + bias through the 3-term split-bf16 MFMA GEMM of PV_DTYPE_BF16_INPUT_GEMM alone.
  * HOST pointers, fp32 row-major A [M,K], W [N,K], bias [N] or NULL; C [splits][M][N] row-major (quads = 0) or [M/4][N][4]

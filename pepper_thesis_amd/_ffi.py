@@ -172,6 +172,7 @@ SYMBOLS = [
     ("pv_comm_create", C.c_int, [C.c_void_p, C.c_char_p, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
     ("pv_comm_destroy", None, [C.c_void_p]),
     ("pv_gather", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_int64, C.POINTER(C.c_int64), C.c_int, C.c_void_p]),
+    ("pv_gather_counts", C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.POINTER(C.c_int64), C.c_void_p]),
     ("pv_debug_gemm_bf16x3", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int,
                                         C.c_void_p, C.POINTER(C.c_float)]),
     ("pv_profile_begin", C.c_int, [C.c_void_p]),

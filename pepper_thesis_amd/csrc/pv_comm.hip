@@ -14,6 +14,8 @@
 
 #include <dlfcn.h>
 
+#include <mutex>
+
 namespace {
 
 typedef struct { char internal[128]; } nccl_uid;
@@ -33,17 +35,19 @@ struct Rccl {
     const char* (*GetErrorString)(int) = nullptr;
 };
 
-Rccl* rccl() {
-    static Rccl r;
-    static bool tried = false;
-    if (tried) return r.h ? &r : nullptr;
-    tried = true;
+char g_dlerr[256] = "symbol missing";
+
+void rccl_open(Rccl& r) {
     const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
     for (const char* n : names) {
         r.h = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
         if (r.h) break;
     }
-    if (!r.h) return nullptr;
+    if (!r.h) {
+        const char* e = dlerror();  // one call: a second one returns NULL
+        if (e) snprintf(g_dlerr, sizeof g_dlerr, "%s", e);
+        return;
+    }
 #define PV_SYM(field, sym) r.field = (decltype(r.field))dlsym(r.h, sym)
     PV_SYM(GetUniqueId, "ncclGetUniqueId"); PV_SYM(CommInitRank, "ncclCommInitRank"); PV_SYM(CommDestroy, "ncclCommDestroy");
     PV_SYM(AllGather, "ncclAllGather"); PV_SYM(Send, "ncclSend"); PV_SYM(Recv, "ncclRecv");
@@ -52,9 +56,15 @@ Rccl* rccl() {
     if (!r.GetUniqueId || !r.CommInitRank || !r.CommDestroy || !r.AllGather || !r.Send || !r.Recv || !r.GroupStart || !r.GroupEnd) {
         dlclose(r.h);
         r.h = nullptr;
-        return nullptr;
     }
-    return &r;
+}
+
+// contexts may create communicators from several threads: the library is opened exactly once
+Rccl* rccl() {
+    static Rccl r;
+    static std::once_flag once;
+    std::call_once(once, [] { rccl_open(r); });
+    return r.h ? &r : nullptr;
 }
 
 }  // namespace
@@ -62,8 +72,8 @@ Rccl* rccl() {
 struct pv_comm {
     nccl_comm comm = nullptr;
     int rank = 0, world = 1;
-    int64_t* d_counts = nullptr;  // [world + 1]: slot world holds this rank's own count
-    int64_t* h_counts = nullptr;  // pinned [world]
+    int64_t* d_counts = nullptr;  // [2 * world + 2] pairs {rows, receive capacity (dst only, else -1)}: the last pair is this rank's own
+    int64_t* h_counts = nullptr;  // pinned [2 * world + 2]
 };
 
 #define PV_NCCL(call)                                                                                                  \
@@ -78,7 +88,7 @@ struct pv_comm {
 extern "C" int pv_comm_unique_id(pv_ctx* ctx, char* id128) {
     PV_CHECK(ctx && id128, PV_ERR_INVALID, "null argument");
     Rccl* R = rccl();
-    PV_CHECK(R, PV_ERR_STATE, "RCCL (librccl.so.1) could not be loaded: %s", dlerror() ? dlerror() : "symbol missing");
+    PV_CHECK(R, PV_ERR_STATE, "RCCL (librccl.so.1) could not be loaded: %s", g_dlerr);
     PV_HIP(hipSetDevice(ctx->device));
     nccl_uid u;
     PV_NCCL(R->GetUniqueId(&u));
@@ -101,8 +111,9 @@ extern "C" int pv_comm_create(pv_ctx* ctx, const char* id128, int rank, int worl
         delete c;
         return PV_ERR_HIP;
     }
-    if (hipMalloc((void**)&c->d_counts, (size_t)(world + 1) * sizeof(int64_t)) != hipSuccess ||
-        hipHostMalloc((void**)&c->h_counts, (size_t)world * sizeof(int64_t), hipHostMallocDefault) != hipSuccess) {
+    if (hipMalloc((void**)&c->d_counts, (size_t)(2 * world + 2) * sizeof(int64_t)) != hipSuccess ||
+        hipHostMalloc((void**)&c->h_counts, (size_t)(2 * world + 2) * sizeof(int64_t), hipHostMallocDefault) != hipSuccess) {
+        pv_comm_destroy(c);  // frees the communicator and whichever buffer did get allocated
         pv_set_error("pv_comm_create: allocation failed");
         return PV_ERR_HIP;
     }
@@ -119,6 +130,22 @@ extern "C" void pv_comm_destroy(pv_comm* c) {
     delete c;
 }
 
+extern "C" int pv_gather_counts(pv_ctx* ctx, pv_comm* c, int64_t n_rows, int64_t* counts_out, void* stream) {
+    PV_CHECK(ctx && c && n_rows >= 0 && counts_out, PV_ERR_INVALID, "bad argument");
+    Rccl* R = rccl();
+    PV_CHECK(R, PV_ERR_STATE, "RCCL (librccl.so.1) could not be loaded");
+    PV_HIP(hipSetDevice(ctx->device));
+    hipStream_t st = pv_pick_stream(ctx, stream);
+    int64_t* mine = c->h_counts + 2 * c->world;
+    mine[0] = n_rows;
+    PV_HIP(hipMemcpyAsync(c->d_counts + 2 * c->world, mine, sizeof(int64_t), hipMemcpyHostToDevice, st));
+    PV_NCCL(R->AllGather(c->d_counts + 2 * c->world, c->d_counts, 1, NCCL_INT64, c->comm, st));
+    PV_HIP(hipMemcpyAsync(c->h_counts, c->d_counts, (size_t)c->world * sizeof(int64_t), hipMemcpyDeviceToHost, st));
+    PV_HIP(hipStreamSynchronize(st));
+    for (int r = 0; r < c->world; r++) counts_out[r] = c->h_counts[r];
+    return PV_OK;
+}
+
 extern "C" int pv_gather(pv_ctx* ctx, pv_comm* c, const void* d_send, int64_t n_rows, int row_bytes, void* d_recv,
                          int64_t recv_capacity_rows, int64_t* counts_out, int dst, void* stream) {
     PV_CHECK(ctx && c && n_rows >= 0 && row_bytes > 0 && dst >= 0 && dst < c->world, PV_ERR_INVALID, "bad argument");
@@ -127,41 +154,52 @@ extern "C" int pv_gather(pv_ctx* ctx, pv_comm* c, const void* d_send, int64_t n_
     PV_CHECK(R, PV_ERR_STATE, "RCCL (librccl.so.1) could not be loaded");
     PV_HIP(hipSetDevice(ctx->device));
     hipStream_t st = pv_pick_stream(ctx, stream);
-    // 1. every rank learns every count
-    PV_HIP(hipMemcpyAsync(c->d_counts + c->world, &n_rows, sizeof(int64_t), hipMemcpyHostToDevice, st));
-    PV_NCCL(R->AllGather(c->d_counts + c->world, c->d_counts, 1, NCCL_INT64, c->comm, st));
-    PV_HIP(hipMemcpyAsync(c->h_counts, c->d_counts, (size_t)c->world * sizeof(int64_t), hipMemcpyDeviceToHost, st));
+    // 1. every rank learns every row count AND the destination's capacity, so that all ranks take the same decision before
+    //    anybody is committed to a send (a destination that bails out alone would leave its peers blocked in ncclSend)
+    int64_t* mine = c->h_counts + 2 * c->world;
+    mine[0] = n_rows;
+    mine[1] = c->rank == dst ? (d_recv ? recv_capacity_rows : (int64_t)0) : (int64_t)-1;
+    PV_HIP(hipMemcpyAsync(c->d_counts + 2 * c->world, mine, 2 * sizeof(int64_t), hipMemcpyHostToDevice, st));
+    PV_NCCL(R->AllGather(c->d_counts + 2 * c->world, c->d_counts, 2, NCCL_INT64, c->comm, st));
+    PV_HIP(hipMemcpyAsync(c->h_counts, c->d_counts, (size_t)(2 * c->world) * sizeof(int64_t), hipMemcpyDeviceToHost, st));
     PV_HIP(hipStreamSynchronize(st));
     int64_t total = 0;
     for (int r = 0; r < c->world; r++) {
-        if (counts_out) counts_out[r] = c->h_counts[r];
-        total += c->h_counts[r];
+        if (counts_out) counts_out[r] = c->h_counts[2 * r];
+        total += c->h_counts[2 * r];
     }
-    if (c->rank == dst) {
-        PV_CHECK(total == 0 || d_recv, PV_ERR_INVALID, "null receive buffer on the destination rank");
-        if (total > recv_capacity_rows) {
-            pv_set_error("pv_gather: %lld rows arrive, the receive buffer holds %lld", (long long)total, (long long)recv_capacity_rows);
-            // the peers are already committed to their sends: receive into nothing is not possible, so fail before the group
-            return PV_ERR_CAPACITY;
-        }
+    const int64_t cap = c->h_counts[2 * dst + 1];
+    if (total > cap) {  // the same verdict on every rank: nobody sends, nobody waits
+        pv_set_error("pv_gather: %lld rows arrive, the receive buffer of rank %d holds %lld", (long long)total, dst, (long long)cap);
+        return PV_ERR_CAPACITY;
     }
-    // 2. payload: point-to-point to dst, rank-major
+    // 2. payload: point-to-point to dst, rank-major. Once the group is open it is always closed again: a failing call inside
+    //    is remembered, the remaining calls are skipped and GroupEnd still runs.
     PV_NCCL(R->GroupStart());
+    int bad = 0;
+    const char* what = "";
     if (c->rank == dst) {
         int64_t off = 0;
-        for (int r = 0; r < c->world; r++) {
-            const size_t nb = (size_t)c->h_counts[r] * (size_t)row_bytes;
+        for (int r = 0; r < c->world && !bad; r++) {
+            const size_t nb = (size_t)c->h_counts[2 * r] * (size_t)row_bytes;
             char* to = (char*)d_recv + (size_t)off * (size_t)row_bytes;
             if (r == dst) {
-                if (nb) PV_HIP(hipMemcpyAsync(to, d_send, nb, hipMemcpyDeviceToDevice, st));
+                if (nb && hipMemcpyAsync(to, d_send, nb, hipMemcpyDeviceToDevice, st) != hipSuccess) { bad = -1; what = "hipMemcpyAsync"; }
             } else if (nb) {
-                PV_NCCL(R->Recv(to, nb, NCCL_CHAR, r, c->comm, st));
+                bad = R->Recv(to, nb, NCCL_CHAR, r, c->comm, st);
+                what = "ncclRecv";
             }
-            off += c->h_counts[r];
+            off += c->h_counts[2 * r];
         }
     } else if (n_rows) {
-        PV_NCCL(R->Send(d_send, (size_t)n_rows * (size_t)row_bytes, NCCL_CHAR, dst, c->comm, st));
+        bad = R->Send(d_send, (size_t)n_rows * (size_t)row_bytes, NCCL_CHAR, dst, c->comm, st);
+        what = "ncclSend";
     }
-    PV_NCCL(R->GroupEnd());
+    const int end = R->GroupEnd();
+    if (bad) {
+        pv_set_error("pv_gather: %s failed: %s", what, bad > 0 && R->GetErrorString ? R->GetErrorString(bad) : "HIP error");
+        return PV_ERR_HIP;
+    }
+    PV_NCCL(end);
     return PV_OK;
 }

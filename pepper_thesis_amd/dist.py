@@ -28,24 +28,43 @@ def _gather_padded(t: torch.Tensor, m: int, dst: int, world: int, rank: int):
     return bufs
 
 
-def gather_predictions(local: torch.Tensor, dst: int = 0, keys: Optional[torch.Tensor] = None):
+class GatherCapacityError(RuntimeError):
+    """more rows arrive than the destination has room for; raised on EVERY rank (the decision is collective)"""
+
+    def __init__(self, total, capacity, counts):
+        super().__init__("gather: %d rows arrive, the destination holds %d" % (total, capacity))
+        self.total, self.capacity, self.counts = total, capacity, counts
+
+
+def gather_predictions(local: torch.Tensor, dst: int = 0, keys: Optional[torch.Tensor] = None,
+                       capacity_rows: Optional[int] = None):
     """Gather [n_r, C] float rows (and optional int64 keys [n_r]) from every rank to rank `dst`.
 
-    Ranks may hold different row counts: the counts are all-gathered (8 B per rank, every rank needs the
+    Ranks may hold different row counts: the counts are all-gathered (16 B per rank, every rank needs the
     padded size), the payloads are padded to the maximum and moved with ONE gather to `dst`
     (~12-20 B per window; only `dst` allocates receive buffers).
+    capacity_rows (meaningful on `dst`; None = unbounded) travels WITH the counts, exactly as in pv_gather
+    (csrc/pv_comm.hip): when the rows do not fit, every rank raises GatherCapacityError before any payload
+    collective is entered, so no rank is left inside a gather its partner never joins.
     Returns (rows [sum n_r, C], keys or None, counts) on dst, None elsewhere."""
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        if capacity_rows is not None and int(local.shape[0]) > int(capacity_rows):
+            raise GatherCapacityError(int(local.shape[0]), int(capacity_rows), [int(local.shape[0])])
         return local, keys, [int(local.shape[0])]
     world, rank = dist.get_world_size(), dist.get_rank()
     if dist.get_backend() != "nccl" and local.is_cuda:  # gloo rehearsal with device tensors: collective on the host
         local = local.cpu()
         keys = None if keys is None else keys.cpu()
     dev = local.device
-    n = torch.tensor([local.shape[0]], dtype=torch.int64, device=dev)
-    counts = torch.zeros(world, dtype=torch.int64, device=dev)
-    dist.all_gather_into_tensor(counts, n)
-    counts_l = [int(c) for c in counts.tolist()]
+    unbounded = (1 << 62)
+    cap = (unbounded if capacity_rows is None else int(capacity_rows)) if rank == dst else -1
+    n = torch.tensor([local.shape[0], cap], dtype=torch.int64, device=dev)
+    pairs = torch.zeros(2 * world, dtype=torch.int64, device=dev)
+    dist.all_gather_into_tensor(pairs, n)
+    pairs_l = [int(c) for c in pairs.tolist()]
+    counts_l = pairs_l[0::2]
+    if sum(counts_l) > pairs_l[2 * dst + 1]:  # same verdict on every rank
+        raise GatherCapacityError(sum(counts_l), pairs_l[2 * dst + 1], counts_l)
     m = max(max(counts_l), 1)
     row_bufs = _gather_padded(local, m, dst, world, rank)
     key_bufs = None if keys is None else _gather_padded(keys.to(torch.int64), m, dst, world, rank)
@@ -90,14 +109,20 @@ class CabiGather:
 
     def gather(self, local: torch.Tensor, dst: int = 0, capacity_rows: Optional[int] = None, stream: int = 0):
         """local: contiguous DEVICE tensor [n_r, ...]; returns (rows [sum n_r, ...], counts) on dst, (None, counts) elsewhere.
-        capacity_rows: rows the destination provides room for (default world * n_local: right when the ranks hold equal row
-        counts, as the region-sharded benchmark does; ragged callers pass their bound)."""
+        capacity_rows: rows the destination provides room for. None = size the buffer from the counts (pv_gather_counts: one
+        more 8-byte all-gather), which is right for ragged ranks; a caller with a bound passes it and gets PV_ERR_CAPACITY
+        on every rank when the rows do not fit."""
         import ctypes as C
         from . import _ffi
         assert local.is_cuda and local.is_contiguous()
         n = int(local.shape[0])
-        row_bytes = int(local[0].numel() * local.element_size()) if n else int(np_prod(local.shape[1:]) * local.element_size())
-        cap = int(capacity_rows) if capacity_rows is not None else n * self.world
+        row_bytes = int(np_prod(local.shape[1:]) * local.element_size())
+        if capacity_rows is None:
+            pre = (C.c_int64 * self.world)()
+            _ffi.check(self.lib.pv_gather_counts(self.ctx.handle, self.handle, n, pre, stream or None))
+            cap = sum(int(c) for c in pre)
+        else:
+            cap = int(capacity_rows)
         recv = None
         if self.rank == dst:
             recv = torch.empty((max(cap, 1),) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)

@@ -69,4 +69,12 @@ def test_pv_gather_single_rank(hip_ctx):
     assert counts == [7] and torch.equal(rows, x)
     rows, counts = g.gather(x[:0].contiguous(), dst=0)
     assert counts == [0] and rows.shape[0] == 0
+    # an explicit bound that is too small: PV_ERR_CAPACITY (the verdict every rank would reach), and the communicator is
+    # still usable afterwards (no group left open)
+    from pepper_thesis_amd import _ffi
+    with pytest.raises(_ffi.PepperHipError) as e:
+        g.gather(x, dst=0, capacity_rows=3)
+    assert e.value.code == _ffi.PV_ERR_CAPACITY
+    rows, counts = g.gather(x, dst=0, capacity_rows=7)
+    assert counts == [7] and torch.equal(rows, x)
     g.close()
