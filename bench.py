@@ -279,17 +279,15 @@ def single_call_secondary(ctx, dev, weights):
     # batches with no fusion across callers; the (tile, direction) workgroups of the callers share the CUs.
     from pepper_thesis_amd import runtime
     # (a 512-window call alone runs in the unit-split LSTM form, which takes the whole chip for one call; callers that share
-    # the GPU without fusion do better in the one-workgroup form, PV_LSTM_SPLIT=0: both are reported)
+    # the GPU without fusion do better in the one-workgroup form, option shared_device = 1: both are reported)
     for ncall, form in ((4, "default"), (8, "default"), (4, "one_workgroup_form"), (8, "one_workgroup_form")):
         key = "callers%d_x_B512" % ncall + ("" if form == "default" else "_" + form)
-        if form == "default":
-            os.environ.pop("PV_LSTM_SPLIT", None)
-        else:
-            os.environ["PV_LSTM_SPLIT"] = "0"
         try:
             ctxs = [ctx] + [runtime.Context(ctx.device_id) for _ in range(ncall - 1)]
             for c in ctxs[1:]:
                 c.load_p1(weights)
+            for c in ctxs:   # what run_inference sets for un-fused callers that share a GPU
+                c.set_option("shared_device", 0 if form == "default" else 1)
             xs = [torch.from_numpy(synth.synth_windows(30 + i, 512)).to(dev) for i in range(ncall)]
             ps = [torch.zeros((512, 3), dtype=torch.float32, device=dev) for _ in range(ncall)]
             for c, x, p in zip(ctxs, xs, ps):
@@ -312,7 +310,7 @@ def single_call_secondary(ctx, dev, weights):
                 c.close()
         except Exception as e:
             out[key] = {"error": repr(e)}
-    os.environ.pop("PV_LSTM_SPLIT", None)
+    ctx.set_option("shared_device", 0)
     return out
 
 

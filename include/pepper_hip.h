@@ -315,12 +315,32 @@ int pv_profile_begin_only(pv_ctx* ctx, const char* prefix);
 int pv_profile_end(pv_ctx* ctx, char* names_buf, int buf_len, float* ms_sum, int* counts, int max_kernels);
 
 /* Small batches run in "split" kernel forms whose workgroups swap hidden state every time step (pv_rnn_forward_p1* up to
- * 1024 windows, pv_rnn_forward_p2* up to 1024 chunks); a launch needs all its workgroups resident at once, which holds
+ * 1024 windows, pv_rnn_forward_p2* up to 2048 chunks); a launch needs all its workgroups resident at once, which holds
  * whenever it is chosen, except on a GPU that other work keeps busy for long stretches: a poll then gives up after a bounded
- * wait and the results of that call are wrong. The host-buffer entry points check for it themselves (PV_ERR_STATE); callers of
- * the asynchronous *_dev forms call this at their own synchronisation points: it synchronises the context's stream and returns
- * the number of polls that gave up since the last call (0 = every result is good), or a negative PV_ERR_* code. */
+ * wait. A call in which that happened NEVER returns numbers that look like results: its last kernel overwrites the outputs
+ * (P1 probabilities NaN; P2 labels 255, accumulated softmax / logits / hidden state NaN), and so does every later call on the
+ * context until the host acknowledges the condition. The host-buffer entry points check for it themselves (PV_ERR_STATE, and
+ * acknowledge); callers of the asynchronous *_dev forms call this at their own synchronisation points: it synchronises the
+ * context's stream, acknowledges, and returns the number of polls that gave up since the last call (0 = every result is
+ * good), or a negative PV_ERR_* code. A context that shares its GPU with other work sets option shared_device = 1. */
 int pv_rnn_exchange_timeouts(pv_ctx* ctx);
+
+/* Kernel-form options of a context. They replace process-environment lookups at call time: the environment only supplies
+ * DEFAULTS, read once in pv_create (variable in brackets); a forward call reads the context's options and nothing else.
+ *   lstm_split    [PV_LSTM_SPLIT]   1 (default) / 0: allow / never use the unit-split LSTM form (<= 1024 windows per call)
+ *   lstm_rows     [PV_LSTM_ROWS]    0 auto / 16 / 32: tile form of the one-workgroup LSTM kernel (explicit: no unit split)
+ *   tail_rows     [PV_TAIL_ROWS]    0 auto / 16 / 32;   head_splits [PV_HEAD_SPLITS] 0 auto / 1 / 3 / 11 / 33;   head_map [PV_HEAD_MAP] 1 / 0
+ *   gru_rows      [PV_GRU_ROWS]     0 auto / 16 / 32
+ *   gru_split     [PV_GRU_SPLIT]    1 / 0: allow the split GRU forms at all;   gru_usplit [PV_GRU_USPLIT] 1 / 0: the unit-split one
+ *   gru_mid       [PV_GRU_MID]      1 / 0: 1025..4096 chunks as sub-batches in split forms / as one launch of the one-workgroup form
+ *   shared_device [PV_SHARED_DEVICE] 0 / 1: other streams or processes keep this GPU busy (e.g. several un-fused callers per
+ *                                   GPU, RunInferenceArguments.py:67-74): never choose a form that needs co-resident workgroups
+ *   exchange_spin_log2              2..22 (default 18): bounded polls give up after 2^n tries
+ *   debug_drop_part                 -1 (off) / 0..3: diagnostic, one part of every unit-split group never runs (tests force a
+ *                                   time-out with it and see the poison)
+ * Unknown names and values outside these sets return PV_ERR_INVALID. */
+int pv_set_option(pv_ctx* ctx, const char* name, int value);
+int pv_get_option(pv_ctx* ctx, const char* name, int* value);
 
 /* ---- hipGraph capture of a launch sequence ------------------------------------------------------------------------
  * Everything the *_dev entry points do is stream work with device-resident state (no host read-back, tags / counters of

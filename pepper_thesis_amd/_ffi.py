@@ -179,6 +179,8 @@ SYMBOLS = [
     ("pv_profile_begin_only", C.c_int, [C.c_void_p, C.c_char_p]),
     ("pv_profile_end", C.c_int, [C.c_void_p, C.c_char_p, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_int), C.c_int]),
     ("pv_rnn_exchange_timeouts", C.c_int, [C.c_void_p]),
+    ("pv_set_option", C.c_int, [C.c_void_p, C.c_char_p, C.c_int]),
+    ("pv_get_option", C.c_int, [C.c_void_p, C.c_char_p, C.POINTER(C.c_int)]),
     ("pv_graph_begin", C.c_int, [C.c_void_p, C.c_void_p]),
     ("pv_graph_end", C.c_int, [C.c_void_p, C.POINTER(C.c_void_p)]),
     ("pv_graph_launch", C.c_int, [C.c_void_p, C.c_void_p]),

@@ -1,6 +1,8 @@
 // pv_api.hip — context management entry points of the C-ABI (include/pepper_hip.h).
 #include "pv_common.hpp"
 
+#include <cstdlib>
+
 static thread_local char g_err[512] = "";
 
 void pv_set_error(const char* fmt, ...) {
@@ -12,6 +14,74 @@ void pv_set_error(const char* fmt, ...) {
 
 extern "C" const char* pv_last_error(void) { return g_err; }
 extern "C" int pv_version(void) { return PV_VERSION_NUM; }
+
+namespace {
+__global__ __launch_bounds__(256) void k_zero_words(unsigned* __restrict__ p, size_t n_words) {
+    const size_t n4 = n_words / 4, i0 = (size_t)blockIdx.x * blockDim.x + threadIdx.x, stride = (size_t)gridDim.x * blockDim.x;
+    typedef unsigned u4 __attribute__((ext_vector_type(4)));
+    const bool al = ((uintptr_t)p & 15) == 0;
+    if (al) {
+        for (size_t i = i0; i < n4; i += stride) reinterpret_cast<u4*>(p)[i] = u4{0u, 0u, 0u, 0u};
+        for (size_t i = n4 * 4 + i0; i < n_words; i += stride) p[i] = 0u;
+    } else {
+        for (size_t i = i0; i < n_words; i += stride) p[i] = 0u;
+    }
+}
+}  // namespace
+
+int pv_zero_async(void* p, size_t bytes, hipStream_t st) {
+    if (!bytes) return PV_OK;
+    PV_CHECK(p && bytes % 4 == 0, PV_ERR_INVALID, "pv_zero_async: bad range");
+    const size_t words = bytes / 4;
+    const size_t blocks = (words / 4 + 255) / 256;
+    k_zero_words<<<(unsigned)(blocks < 1 ? 1 : (blocks > 2048 ? 2048 : blocks)), 256, 0, st>>>((unsigned*)p, words);
+    PV_HIP(hipGetLastError());
+    return PV_OK;
+}
+
+namespace {
+struct opt_desc { const char* name; const char* env; int pv_opts::*field; int lo, hi; };
+const opt_desc OPTS[] = {
+    {"lstm_split", "PV_LSTM_SPLIT", &pv_opts::lstm_split, 0, 1},
+    {"lstm_rows", "PV_LSTM_ROWS", &pv_opts::lstm_rows, 0, 32},
+    {"tail_rows", "PV_TAIL_ROWS", &pv_opts::tail_rows, 0, 32},
+    {"head_splits", "PV_HEAD_SPLITS", &pv_opts::head_splits, 0, 33},
+    {"head_map", "PV_HEAD_MAP", &pv_opts::head_map, 0, 1},
+    {"gru_rows", "PV_GRU_ROWS", &pv_opts::gru_rows, 0, 32},
+    {"gru_split", "PV_GRU_SPLIT", &pv_opts::gru_split, 0, 1},
+    {"gru_usplit", "PV_GRU_USPLIT", &pv_opts::gru_usplit, 0, 1},
+    {"gru_mid", "PV_GRU_MID", &pv_opts::gru_mid, 0, 1},
+    {"shared_device", "PV_SHARED_DEVICE", &pv_opts::shared_device, 0, 1},
+    {"exchange_spin_log2", nullptr, &pv_opts::exchange_spin_log2, 2, 22},
+    {"debug_drop_part", nullptr, &pv_opts::debug_drop_part, -1, 3},
+};
+bool opt_value_ok(const opt_desc& d, int v) {
+    if (v < d.lo || v > d.hi) return false;
+    if (!strcmp(d.name, "lstm_rows") || !strcmp(d.name, "tail_rows") || !strcmp(d.name, "gru_rows")) return v == 0 || v == 16 || v == 32;
+    if (!strcmp(d.name, "head_splits")) return v == 0 || v == 1 || v == 3 || v == 11 || v == 33;
+    return true;
+}
+}  // namespace
+
+extern "C" int pv_set_option(pv_ctx* c, const char* name, int value) {
+    PV_CHECK(c && name, PV_ERR_INVALID, "null argument");
+    for (const opt_desc& d : OPTS)
+        if (!strcmp(d.name, name)) {
+            PV_CHECK(opt_value_ok(d, value), PV_ERR_INVALID, "option %s: value %d not allowed", name, value);
+            c->opt.*(d.field) = value;
+            return PV_OK;
+        }
+    pv_set_error("unknown option '%s'", name);
+    return PV_ERR_INVALID;
+}
+
+extern "C" int pv_get_option(pv_ctx* c, const char* name, int* value) {
+    PV_CHECK(c && name && value, PV_ERR_INVALID, "null argument");
+    for (const opt_desc& d : OPTS)
+        if (!strcmp(d.name, name)) { *value = c->opt.*(d.field); return PV_OK; }
+    pv_set_error("unknown option '%s'", name);
+    return PV_ERR_INVALID;
+}
 
 extern "C" pv_ctx* pv_create(int device_id) {
     int n = 0;
@@ -33,6 +103,13 @@ extern "C" pv_ctx* pv_create(int device_id) {
     c->device = device_id;
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device_id) == hipSuccess) c->num_cu = prop.multiProcessorCount;
+    // the environment supplies DEFAULTS for the kernel-form options, read here and nowhere else
+    for (const opt_desc& d : OPTS)
+        if (d.env)
+            if (const char* ev = getenv(d.env)) {
+                const int v = atoi(ev);
+                if (opt_value_ok(d, v)) c->opt.*(d.field) = v;
+            }
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
         hipHostMalloc((void**)&c->h_counts, 16 * sizeof(int64_t), hipHostMallocDefault) != hipSuccess) {
         pv_set_error("stream / pinned buffer creation failed");

@@ -93,6 +93,24 @@ struct pv_prof {
 struct pv_rnn_p1;  // rnn_kernels.hip
 struct pv_rnn_p2;
 
+// Kernel-form choices of a context (pv_set_option / pv_get_option, include/pepper_hip.h). Defaults come from the
+// environment ONCE, in pv_create (PV_LSTM_SPLIT, PV_LSTM_ROWS, PV_TAIL_ROWS, PV_HEAD_SPLITS, PV_HEAD_MAP, PV_GRU_ROWS,
+// PV_GRU_SPLIT, PV_GRU_USPLIT, PV_SHARED_DEVICE); a forward call never reads the environment.
+struct pv_opts {
+    int lstm_split = 1;          // 0: never use the unit-split LSTM form
+    int lstm_rows = 0;           // 0 auto, 16 or 32: tile form of k_lstm_layer (an explicit form also disables the unit split)
+    int tail_rows = 0;           // 0 auto, 16 or 32
+    int head_splits = 0;         // 0 auto, 1 / 3 / 11 / 33
+    int head_map = 1;            // XCD-aware order of k_head_splitk
+    int gru_rows = 0;            // 0 auto, 16 or 32
+    int gru_split = 1;           // 0: neither split form of the GRU
+    int gru_usplit = 1;          // 0: no unit-split form (the direction-split form stays)
+    int gru_mid = 1;             // 0: 1025-4096 chunks in one launch of the one-workgroup form instead of sub-batches
+    int shared_device = 0;       // 1: other work shares this GPU: no form that needs all its workgroups resident at once
+    int exchange_spin_log2 = 18; // bounded polls of the split forms give up after 2^n tries (layer hand-offs: 2^(n+8))
+    int debug_drop_part = -1;    // diagnostic: this part of a unit-split launch never runs (forces exchange time-outs)
+};
+
 struct pv_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -104,6 +122,7 @@ struct pv_ctx {
     pv_rnn_p2* p2 = nullptr;
     pv_prof prof;
     hipStream_t capture_stream = nullptr;   // pv_graph_begin .. pv_graph_end
+    pv_opts opt;
 };
 
 // RAII bracket: { pv_prof_scope ps(ctx, "k_name", stream); kernel<<<...>>>(...); }
@@ -129,6 +148,12 @@ static inline int pv_get(pv_ctx* c, const char* name, size_t n, T** out) {
 }
 
 static inline hipStream_t pv_pick_stream(pv_ctx* c, void* stream) { return stream ? (hipStream_t)stream : c->stream; }
+
+// pv_api.hip: zero `bytes` (a multiple of 4) of device memory with an ordinary KERNEL on `st`. The *_dev entry points use it
+// instead of hipMemsetAsync: inside a captured hipGraph a memset becomes a memset node, and replays were seen to run the kernel
+// behind such a node on a stale buffer (flags of the previous replay still set: hand-offs passed at once; ROCm 7.2, gfx950) -
+// kernel nodes keep their order.
+int pv_zero_async(void* p, size_t bytes, hipStream_t st);
 
 // rnn_kernels.hip
 void pv_rnn_free(pv_ctx* ctx);

@@ -20,6 +20,7 @@
 #include "pv_common.hpp"
 #include "mfma_tiles.hpp"
 
+#include <algorithm>
 #include <cstdlib>
 
 namespace {
@@ -141,7 +142,10 @@ struct GruArgs {
     unsigned tag_base;      // tags of this launch run from tag_base + 1 (set by the kernel from *epoch)
     unsigned* epoch;        // device word: launches of the unit-split form so far (bumped by k_gru_bump behind every launch, so a
                             // replayed hipGraph advances the tags like eager launches do)
-    int* err;               // bumped when a bounded poll of the exchange gave up
+    int* err;               // bumped when a bounded poll of the exchange or of a layer hand-off gave up
+    int spin_limit;         // polls of the per-step exchange give up after this many tries; layer hand-offs after 256 x as many
+    int drop_part;          // diagnostic (pv_opts::debug_drop_part): workgroup `sub` of every tile (unit-split form) or direction
+                            // `drop_part & 1` (direction-split form) leaves at once; -1 = none
 };
 
 // ---- the two directions of a tile on two CUs (small batches) -----------------------------------------------------------
@@ -154,7 +158,7 @@ struct GruArgs {
 // workgroup's barrier, one lane publishes (release fence, drained, then the relaxed counter store) and polls the partner's
 // counter with relaxed loads, one acquire fence, barrier. Used only while both workgroups of every tile are resident at
 // once (grid <= CUs, one workgroup per CU), so a poll can never wait for a workgroup that has not been dispatched.
-__device__ __forceinline__ void pair_handoff(int* mine, const int* theirs, int value, int tid) {
+__device__ __forceinline__ void pair_handoff(int* mine, const int* theirs, int value, int tid, int* err, int limit) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's stores have left
     __syncthreads();
     if (tid == 0) {
@@ -164,7 +168,7 @@ __device__ __forceinline__ void pair_handoff(int* mine, const int* theirs, int v
         int spins = 0;
         while (__hip_atomic_load(theirs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < value) {
             __builtin_amdgcn_s_sleep(2);
-            if (++spins > (1 << 26)) break;   // bounded: a lost partner ends in wrong results, never in a hung device
+            if (++spins > limit) { atomicAdd(err, 1); break; }   // bounded: a lost partner ends in POISONED results (k_gru_finish), never in a hung device
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -488,6 +492,7 @@ __global__ __launch_bounds__(SPLIT ? 256 : 512, SPLIT ? 1 : 2) void k_gru_p2(Gru
     float* hbuf = smem + (SPLIT ? 0 : dir) * (2 * TR * LDH + (TR == 16 ? 2 : 1) * TR * LDXD);
     float* xbuf = hbuf + 2 * TR * LDH;
     const int tile = SPLIT ? (int)(blockIdx.x >> 1) : (int)blockIdx.x;
+    if (SPLIT && a.drop_part >= 0 && dir == (a.drop_part & 1)) return;   // diagnostic: a partner that never shows up
     int* my_flag = SPLIT ? a.pair_flags + 2 * tile + dir : nullptr;
     const int* their_flag = SPLIT ? a.pair_flags + 2 * tile + (dir ^ 1) : nullptr;
     int handoffs = 0;
@@ -523,11 +528,11 @@ __global__ __launch_bounds__(SPLIT ? 256 : 512, SPLIT ? 1 : 2) void k_gru_p2(Gru
         const int ws = w * JUMP;
         if constexpr (SPLIT) gru_window_ovl<KPE, true>(a, ws, dir, wq, lane, tid_dir, b0, xbuf, hbuf, cur, hst, enc_wp, enc_bias, nullptr, enc_out);
         else gru_window<TR, KPE, true>(a, ws, dir, wq, lane, tid_dir, b0, xbuf, hbuf, cur, hst, enc_wp, enc_bias, nullptr, enc_out);
-        if constexpr (SPLIT) pair_handoff(my_flag, their_flag, ++handoffs, tid);   // both halves of the encoder output are there
+        if constexpr (SPLIT) pair_handoff(my_flag, their_flag, ++handoffs, tid, a.err, a.spin_limit << 8);   // both halves of the encoder output are there
         // decoder h0 = encoder final state of the same direction: hst / hbuf[cur] simply carry over
         if constexpr (SPLIT) gru_window_ovl<KPD, false>(a, ws, dir, wq, lane, tid_dir, b0, xbuf, hbuf, cur, hst, dec_wp, dec_bias, enc_out, dec_out);
         else gru_window<TR, KPD, false>(a, ws, dir, wq, lane, tid_dir, b0, xbuf, hbuf, cur, hst, dec_wp, dec_bias, enc_out, dec_out);
-        if constexpr (SPLIT) pair_handoff(my_flag, their_flag, ++handoffs, tid);   // both halves of the decoder output; the partner is
+        if constexpr (SPLIT) pair_handoff(my_flag, their_flag, ++handoffs, tid, a.err, a.spin_limit << 8);   // both halves of the decoder output; the partner is
                                                                                     // done reading the encoder output as well
         // dense1 + softmax + accumulate over the window (predict.py:70-89); TR*100 (row, t) pairs. Split form: the workgroup of
         // direction d owns the columns of parity d (ws is even), for acc, logits and labels alike, so no column is shared.
@@ -639,7 +644,7 @@ __device__ __forceinline__ void ring_us(f32x4& gr, f32x4& gz, f32x4& gn, const f
 }
 
 // counters + fences among the four workgroups of a tile (layer boundaries only)
-__device__ __forceinline__ void quad_handoff(int* flags_tile, int me, int value, int tid) {
+__device__ __forceinline__ void quad_handoff(int* flags_tile, int me, int value, int tid, int* err, int limit) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (tid == 0) {
@@ -652,7 +657,7 @@ __device__ __forceinline__ void quad_handoff(int* flags_tile, int me, int value,
             int spins = 0;
             while (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < value) {
                 __builtin_amdgcn_s_sleep(2);
-                if (++spins > (1 << 24)) break;   // bounded: a lost partner ends in wrong results, never in a hung device
+                if (++spins > limit) { atomicAdd(err, 1); break; }   // bounded: a lost partner ends in POISONED results, never in a hung device
             }
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
@@ -749,7 +754,7 @@ __device__ __forceinline__ void gru_window_us(const GruArgs& a, int win_start, i
                 }
                 asm volatile("" ::: "memory");   // the loads are repeated, not hoisted
                 if (ok) break;
-                if (++spins > (1 << 18)) { atomicAdd(a.err, 1); break; }
+                if (++spins > a.spin_limit) { atomicAdd(a.err, 1); break; }
             }
             float* dst = hbuf + cur * TR * LDH + 4 * rowg * LDH + 64 * (half ^ 1) + 16 * wv + (lane & 15);
 #pragma unroll
@@ -803,7 +808,29 @@ __device__ __forceinline__ void gru_window_us(const GruArgs& a, int win_start, i
     __syncthreads();   // the window's outputs (global scratch) are read by the next phase (after the hand-off)
 }
 
-__global__ void k_gru_bump(unsigned* epoch) { atomicAdd(epoch, 1u); }
+// Behind every P2 launch: bumps the launch counter of the unit-split form (a replayed hipGraph advances the exchange tags like
+// eager launches do) and, while exchange time-outs are pending (a poll or a layer hand-off of a split form gave up: some
+// workgroup computed on stale state, and its partners on what it sent afterwards), POISONS what the launch wrote: labels 255,
+// accumulated softmax / logits / hidden state NaN. The word stays set until the host acknowledges it
+// (pv_rnn_exchange_timeouts, or the host-buffer entry points, which return PV_ERR_STATE).
+struct GruFinishArgs {
+    unsigned* epoch;      // or NULL
+    const int* err;
+    uint8_t* labels; int64_t n_labels;
+    float* f[3]; int64_t nf[3];   // acc, logits, hidden_out (NULL / 0 when absent)
+};
+__global__ __launch_bounds__(256) void k_gru_finish(GruFinishArgs a) {
+    if (a.epoch && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(a.epoch, 1u);
+#ifdef PV_DBG_NOFINISH
+    return;
+#endif
+    if (a.err[0] == 0) return;
+    const int64_t i0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = i0; a.labels && i < a.n_labels; i += stride) a.labels[i] = 255;
+    const float nanv = __builtin_nanf("");
+    for (int k = 0; k < 3; k++)
+        for (int64_t i = i0; a.f[k] && i < a.nf[k]; i += stride) a.f[k][i] = nanv;
+}
 
 __global__ __launch_bounds__(256, 1) void k_gru_us(GruArgs a_in) {
     GruArgs a = a_in;
@@ -819,6 +846,7 @@ __global__ __launch_bounds__(256, 1) void k_gru_us(GruArgs a_in) {
     const int tile = (q >> 2) * 8 + xcd;
     const int n_tiles = (int)((a.B + TR - 1) / TR);
     if (tile >= n_tiles) return;           // whole tiles leave together
+    if (sub == a.drop_part) return;        // diagnostic: a partner that never shows up (the others' polls time out and say so)
     const int64_t b0 = (int64_t)tile * TR;
     float* enc_out = a.enc_out + (size_t)tile * WIN * TR * KPD;
     float* dec_out = a.dec_out + (size_t)tile * WIN * TR * KPD;
@@ -852,9 +880,9 @@ __global__ __launch_bounds__(256, 1) void k_gru_us(GruArgs a_in) {
     for (int w = 0; w < a.nwin; w++) {
         const int ws = w * JUMP;
         gru_window_us<KPE, true, NPE>(a, ws, dir, half, wv, lane, tid, b0, xbuf, hbuf, cur, hst, step, enc_wp, enc_bias, nullptr, enc_out, hsr);
-        quad_handoff(flags_tile, sub, ++handoffs, tid);   // all four quarters of the encoder output are there
+        quad_handoff(flags_tile, sub, ++handoffs, tid, a.err, a.spin_limit << 8);   // all four quarters of the encoder output are there
         gru_window_us<KPD, false, 8>(a, ws, dir, half, wv, lane, tid, b0, xbuf, hbuf, cur, hst, step, dec_wp, dec_bias, enc_out, dec_out, hsr);
-        quad_handoff(flags_tile, sub, ++handoffs, tid);   // the decoder output; everybody is done reading the encoder output too
+        quad_handoff(flags_tile, sub, ++handoffs, tid, a.err, a.spin_limit << 8);   // the decoder output; everybody is done reading the encoder output too
         // dense1 + softmax + accumulate (predict.py:70-89): workgroup `sub` owns the columns with (position & 3) == sub, for
         // acc, logits and labels alike (windows overlap, positions do not move), so no column is shared
         for (int p = tid; p < TR * WIN; p += 256) {
@@ -1052,7 +1080,7 @@ static int p2_launch(pv_ctx* ctx, const uint8_t* d_images, int64_t B, uint8_t* d
     pv_rnn_p2* m = ctx->p2;
     // tile form: 32-row tiles once they fill the chip, else 16-row tiles (twice the workgroups, half the time per step)
     int tr = ((B + 31) / 32 >= ctx->num_cu) ? 32 : 16;
-    if (const char* e = getenv("PV_GRU_ROWS")) { const int v = atoi(e); if (v == 16 || v == 32) tr = v; }
+    if (ctx->opt.gru_rows) tr = ctx->opt.gru_rows;
     const int f = tr == 16 ? 1 : 0;
     const int64_t n_tiles = (B + tr - 1) / tr;
     GruArgs g;
@@ -1068,44 +1096,50 @@ static int p2_launch(pv_ctx* ctx, const uint8_t* d_images, int64_t B, uint8_t* d
     g.labels = d_labels;
     g.B = B;
     g.seq = seq; g.nwin = nwin; g.hidden_in = d_hidden_in; g.hidden_out = d_hidden_out; g.logits = d_logits;
-    PV_HIP(hipMemsetAsync(g.acc, 0, (size_t)B * seq * NCLS * sizeof(float), st));
+    if ((rc = pv_zero_async(g.acc, (size_t)B * seq * NCLS * sizeof(float), st))) return rc;
     // the two directions of a tile on two CUs while every (tile, direction) workgroup has a CU of its own: the launch is a
     // chain of dependent steps, and a step then carries one direction's MFMAs per SIMD instead of two
-    bool split = tr == 16 && 2 * n_tiles <= ctx->num_cu;
-    if (const char* e = getenv("PV_GRU_SPLIT")) split = split && atoi(e) != 0;
+    bool split = tr == 16 && 2 * n_tiles <= ctx->num_cu && ctx->opt.gru_split && !ctx->opt.shared_device;
     g.pair_flags = nullptr;
     g.hx = nullptr; g.quad_flags = nullptr; g.tag_base = 0; g.err = m->us_err; g.epoch = nullptr;
+    g.spin_limit = 1 << ctx->opt.exchange_spin_log2; g.drop_part = ctx->opt.debug_drop_part;
+    GruFinishArgs fin;
+    fin.epoch = nullptr; fin.err = m->us_err; fin.labels = d_labels; fin.n_labels = d_labels ? B * seq : 0;
+    fin.f[0] = g.acc; fin.nf[0] = B * seq * NCLS;
+    fin.f[1] = d_logits; fin.nf[1] = d_logits ? B * WIN * NCLS : 0;
+    fin.f[2] = d_hidden_out; fin.nf[2] = d_hidden_out ? B * 2 * HG : 0;
+    const unsigned fin_grid = (unsigned)std::min<int64_t>((B * seq + 255) / 256, 4 * ctx->num_cu);
     // unit-split form: (tile, direction, half of the units) workgroups with a per-step h exchange, while all of them can be
-    // resident at once (up to 1024 chunks on 256 CUs); PV_GRU_USPLIT=0 keeps the direction-split form
-    bool usplit = tr == 16 && 4 * n_tiles <= ctx->num_cu;
-    if (const char* e = getenv("PV_GRU_USPLIT")) usplit = usplit && atoi(e) != 0;
-    if (const char* e = getenv("PV_GRU_SPLIT")) usplit = usplit && atoi(e) != 0;
+    // resident at once (up to 1024 chunks on 256 CUs); option gru_usplit = 0 keeps the direction-split form, gru_split = 0 or
+    // shared_device = 1 the one-workgroup form
+    const bool usplit = tr == 16 && 4 * n_tiles <= ctx->num_cu && ctx->opt.gru_usplit && ctx->opt.gru_split && !ctx->opt.shared_device;
     if (usplit) {
         g.enc_wp = m->enc_wp[3]; g.dec_wp = m->dec_wp[3];
         const size_t nfl = (size_t)n_tiles * 4 * US_FLAG_STRIDE;
         if ((rc = pv_get(ctx, "p2.quad_flags", nfl, &g.quad_flags))) return rc;
-        PV_HIP(hipMemsetAsync(g.quad_flags, 0, nfl * sizeof(int), st));
+        if ((rc = pv_zero_async(g.quad_flags, nfl * sizeof(int), st))) return rc;
         const size_t nhx = (size_t)n_tiles * 2 * US_HX_QUADS;
         if ((rc = pv_get(ctx, "p2.hx", nhx, &g.hx))) return rc;
         // tags advance with every launch (4096 per launch, device counter): a buffer this sequence has not written yet is
         // cleared once (tag 0 is never waited for)
         if (m->us_hx_seen != (const void*)g.hx || m->us_hx_n != nhx) {
             m->us_hx_seen = g.hx; m->us_hx_n = nhx;
-            PV_HIP(hipMemsetAsync(g.hx, 0, nhx * sizeof(u32x4), st));
+            if ((rc = pv_zero_async(g.hx, nhx * sizeof(u32x4), st))) return rc;
         }
         g.epoch = m->us_epoch;
         {
             pv_prof_scope ps(ctx, "k_gru_us", st);
             k_gru_us<<<(unsigned)(((n_tiles + 7) / 8) * 32), 256, LDS_US, st>>>(g);
         }
-        k_gru_bump<<<1, 1, 0, st>>>(m->us_epoch);
+        fin.epoch = m->us_epoch;
+        k_gru_finish<<<fin_grid, 256, 0, st>>>(fin);
         PV_HIP(hipGetLastError());
         return PV_OK;
     }
     if (split) {
         g.enc_wp = m->enc_wp[2]; g.dec_wp = m->dec_wp[2];   // [h | x] stream order of the overlapped window form
         if ((rc = pv_get(ctx, "p2.pair_flags", (size_t)2 * n_tiles + 96, &g.pair_flags))) return rc;
-        PV_HIP(hipMemsetAsync(g.pair_flags, 0, ((size_t)2 * n_tiles + 96) * sizeof(int), st));
+        if ((rc = pv_zero_async(g.pair_flags, ((size_t)2 * n_tiles + 96) * sizeof(int), st))) return rc;
     }
     {
         pv_prof_scope ps(ctx, "k_gru_p2", st);
@@ -1113,6 +1147,7 @@ static int p2_launch(pv_ctx* ctx, const uint8_t* d_images, int64_t B, uint8_t* d
         else if (split) k_gru_p2<16, true><<<(unsigned)(2 * n_tiles), 256, lds_p2<16, true>(), st>>>(g);
         else k_gru_p2<16, false><<<(unsigned)n_tiles, 512, lds_p2<16, false>(), st>>>(g);
     }
+    k_gru_finish<<<fin_grid, 256, 0, st>>>(fin);
     PV_HIP(hipGetLastError());
     return PV_OK;
 }
@@ -1125,7 +1160,8 @@ static int p2_finish(pv_ctx* ctx, hipStream_t st) {
     PV_HIP(hipStreamSynchronize(st));
     if (n_timeouts) {
         PV_HIP(hipMemset(ctx->p2->us_err, 0, sizeof(int)));
-        pv_set_error("unit-split GRU form: %d exchange polls timed out (GPU shared with other work?); rerun with PV_GRU_USPLIT=0", n_timeouts);
+        pv_set_error("split GRU form: %d exchange polls / hand-offs timed out (GPU shared with other work?); the outputs of this call are poisoned "
+                     "(labels 255, NaN). Set option shared_device = 1 (or gru_split = 0) on this context", n_timeouts);
         return PV_ERR_STATE;
     }
     return PV_OK;

@@ -347,6 +347,8 @@ struct LstmSplitArgs {
     const unsigned* epoch;  // device word, bumped once per forward call by its last kernel (k_head_tail): tags of this launch run
     int layer;              // from (2 * epoch + layer) * 64 + 1, so a replayed hipGraph advances them like eager launches do
     int* err;             // bumped when a bounded poll of the exchange gave up (a partner workgroup never showed up)
+    int spin_limit;       // polls give up after this many tries (pv_opts::exchange_spin_log2)
+    int drop_part;        // diagnostic (pv_opts::debug_drop_part): the workgroups of this part leave at once; -1 = none
 };
 
 template <int KB0, int NKB, int NTOT>
@@ -397,6 +399,7 @@ __global__ __launch_bounds__(1024 / SP_NS) void k_lstm_split(LstmSplitArgs a) {
     const int dir = xcd & 1;
     const int tile = (q / SP_NS) * 4 + (xcd >> 1);
     if (tile >= a.n_tiles) return;   // whole groups leave together: `tile` does not depend on `part`
+    if (part == a.drop_part) return; // diagnostic: a partner that never shows up (its twins' polls time out and say so)
     const int td = tile * 2 + dir;
     const int64_t b0 = (int64_t)tile * TR;
     const float* wp = a.wp + ((size_t)((dir * SP_NS + part) * NW + wv) * NTOT) * 2 * 256;
@@ -494,7 +497,7 @@ __global__ __launch_bounds__(1024 / SP_NS) void k_lstm_split(LstmSplitArgs a) {
                     int spins = 0;
                     while ((unsigned)__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != want) {
                         __builtin_amdgcn_s_sleep(1);
-                        if (++spins > (1 << 24)) break;
+                        if (++spins > a.spin_limit) { atomicAdd(a.err, 1); break; }
                     }
                 }
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
@@ -519,7 +522,7 @@ __global__ __launch_bounds__(1024 / SP_NS) void k_lstm_split(LstmSplitArgs a) {
                     }
                 asm volatile("" ::: "memory");   // the loads are repeated, not hoisted
                 if (ok) break;
-                if (++spins > (1 << 18)) { atomicAdd(a.err, 1); break; }
+                if (++spins > a.spin_limit) { atomicAdd(a.err, 1); break; }
             }
 #endif
             float* hc = hbuf + cur * TR * LDH;
@@ -673,6 +676,9 @@ struct TailArgs {
     float* probs;        // [B,3]
     int64_t B;
     unsigned* epoch;     // the forward-call counter of the unit-split LSTM form: bumped here, by the call's last kernel
+    const int* err;      // exchange time-outs of the unit-split LSTM form since the host last acknowledged them: while it is
+                         // non-zero every call's probabilities leave as NaN (both LSTM kernels of this call are complete when
+                         // this kernel runs, so the word is stable here)
 };
 
 // TR = batch rows per workgroup: 32, or 16 when 32-row tiles would leave CUs idle (the tail is a chain of four dependent
@@ -744,9 +750,13 @@ __global__ __launch_bounds__(256, 1) void k_head_tail(TailArgs a) {
             const float m = fmaxf(l0, fmaxf(l1, l2));
             const float e0 = expf(l0 - m), e1 = expf(l1 - m), e2 = expf(l2 - m);
             const float inv = 1.0f / (e0 + e1 + e2);
-            a.probs[b * 3 + 0] = e0 * inv;
-            a.probs[b * 3 + 1] = e1 * inv;
-            a.probs[b * 3 + 2] = e2 * inv;
+            // a poll of the unit-split form gave up (a partner workgroup was not resident): the numbers below are computed from
+            // stale hidden state. They must not look like results: NaN until the host acknowledges (pv_rnn_exchange_timeouts).
+            const bool bad = a.err && a.err[0] != 0;
+            const float nanv = __builtin_nanf("");
+            a.probs[b * 3 + 0] = bad ? nanv : e0 * inv;
+            a.probs[b * 3 + 1] = bad ? nanv : e1 * inv;
+            a.probs[b * 3 + 2] = bad ? nanv : e2 * inv;
         }
     }
 }
@@ -1287,7 +1297,7 @@ extern "C" int pv_rnn_load_p1(pv_ctx* ctx, const pv_weights_p1* w, int dtype) {
 // tail of the head: 16-row tiles unless 32-row tiles already fill the chip
 static void launch_tail(pv_ctx* ctx, pv_rnn_p1* m, TailArgs& t, int n_tiles32, hipStream_t st) {
     int tr = n_tiles32 >= ctx->num_cu ? 32 : 16;
-    if (const char* ev = getenv("PV_TAIL_ROWS")) { const int v = atoi(ev); if (v == 16 || v == 32) tr = v; }
+    if (ctx->opt.tail_rows) tr = ctx->opt.tail_rows;
     for (int i = 0; i < 4; i++) { t.wp[i] = m->wlp[tr == 16 ? 1 : 0][i]; t.b[i] = m->bl[i]; }
     pv_prof_scope ps(ctx, "k_head_tail", st);
     if (tr == 32) k_head_tail<32><<<(unsigned)n_tiles32, 256, lds_tail<32>(), st>>>(t);
@@ -1301,7 +1311,7 @@ static int p1_forward_launch(pv_ctx* ctx, const int8_t* d_images, int64_t B, flo
     // LSTM tile form: 32-row tiles once (tile, direction) workgroups fill the chip, else 16-row tiles: twice the workgroups,
     // half the MFMA cycles per time step (the bf16x3 mode keeps 32: its recurrence kernel has one form)
     int tr = ((int64_t)n_tiles * 2 >= ctx->num_cu || m->dtype != PV_DTYPE_F32) ? 32 : 16;
-    if (const char* ev = getenv("PV_LSTM_ROWS")) { const int v = atoi(ev); if ((v == 16 && m->dtype == PV_DTYPE_F32) || v == 32) tr = v; }
+    if ((ctx->opt.lstm_rows == 16 && m->dtype == PV_DTYPE_F32) || ctx->opt.lstm_rows == 32) tr = ctx->opt.lstm_rows;
     const int f = tr == 16 ? 1 : 0;
     const int n_lt = n_tiles * (ROWS / tr);             // whole 32-row tiles are covered in either form
     const unsigned lstm_grid = (unsigned)(((n_lt + 3) / 4) * 8);
@@ -1320,19 +1330,18 @@ static int p1_forward_launch(pv_ctx* ctx, const int8_t* d_images, int64_t B, flo
         if (!taps) e.out = nullptr;
     }
     // unit-split form: one small fp32 batch whose (16-row tile, direction, part of the hidden units) workgroups all fit on
-    // the chip at once: four parts up to 512 windows on 256 CUs, two parts up to 1024; PV_LSTM_SPLIT=0 keeps the
-    // one-workgroup form
+    // the chip at once: four parts up to 512 windows on 256 CUs, two parts up to 1024. Options lstm_split = 0, an explicit
+    // lstm_rows, or shared_device = 1 (other work on this GPU: residency is not given) keep the one-workgroup form
     const int n_t16 = n_tiles * 2;
     const int sp_ns = (int64_t)n_t16 * 2 * 4 <= ctx->num_cu ? 4 : 2;
     bool split = m->dtype == PV_DTYPE_F32 && n_t16 <= SP_MAX_TILES && (int64_t)n_t16 * 2 * sp_ns <= ctx->num_cu;
-    if (const char* ev = getenv("PV_LSTM_SPLIT")) { if (atoi(ev) == 0) split = false; }
-    if (getenv("PV_LSTM_ROWS")) split = false;   // an explicit tile form was asked for
+    if (!ctx->opt.lstm_split || ctx->opt.lstm_rows || ctx->opt.shared_device) split = false;
     LstmSplitArgs se;
     const unsigned split_grid = (unsigned)(((n_t16 + 3) / 4) * 8 * sp_ns);
     if (split) {
         se.x_i8 = d_images; se.x_f32 = nullptr; se.wp = m->enc_wps[sp_ns == 4 ? 0 : 1]; se.bias = m->enc_bias; se.out = enc_out;
         se.hx = m->sp_hx; se.flags = m->sp_flags; se.B = B; se.n_tiles = n_t16; se.epoch = m->sp_epoch; se.layer = 0;
-        se.err = m->sp_err;
+        se.err = m->sp_err; se.spin_limit = 1 << ctx->opt.exchange_spin_log2; se.drop_part = ctx->opt.debug_drop_part;
         pv_prof_scope ps(ctx, "k_lstm_split_enc", st);
         if (sp_ns == 4) k_lstm_split<32, true, 4><<<split_grid, 256, lds_lstm_split<32>(), st>>>(se);
         else k_lstm_split<32, true, 2><<<split_grid, 512, lds_lstm_split<32>(), st>>>(se);
@@ -1378,7 +1387,7 @@ static int p1_forward_launch(pv_ctx* ctx, const int8_t* d_images, int64_t B, flo
         }
         TailArgs tb;
         tb.part = part; tb.b1 = m->b1; tb.splits = gs; tb.part_rows = Bp;
-        tb.wo = m->wo; tb.bo = m->bo; tb.probs = d_probs; tb.B = B; tb.epoch = m->sp_epoch;
+        tb.wo = m->wo; tb.bo = m->bo; tb.probs = d_probs; tb.B = B; tb.epoch = m->sp_epoch; tb.err = m->sp_err;
         launch_tail(ctx, m, tb, n_tiles, st);
         PV_HIP(hipGetLastError());
         return PV_OK;
@@ -1400,16 +1409,16 @@ static int p1_forward_launch(pv_ctx* ctx, const int8_t* d_images, int64_t B, flo
     HeadArgs h;
     // split-K factor: 11 slabs of 3 time steps; 33 single-step slabs only for batches too small to fill the chip
     int splits = ((int64_t)n_tiles * 11 >= ctx->num_cu) ? 11 : 33;
-    if (const char* e = getenv("PV_HEAD_SPLITS")) { const int v = atoi(e); if (v == 1 || v == 3 || v == 11 || v == 33) splits = v; }
+    if (ctx->opt.head_splits) splits = ctx->opt.head_splits;
     h.dec = dec_out; h.w1p = m->w1p; h.part = part; h.B = B; h.n_tiles = n_tiles; h.splits = splits; h.steps_per_split = T_STEPS / splits;
-    static const int head_map = getenv("PV_HEAD_MAP") ? atoi(getenv("PV_HEAD_MAP")) : 1;
+    const int head_map = ctx->opt.head_map;
     const int total_wg = n_tiles * splits;
     h.per_xcd = head_map ? (total_wg + 7) / 8 : 0;
     const unsigned head_grid = head_map ? (unsigned)(h.per_xcd * 8) : (unsigned)total_wg;
     { pv_prof_scope ps(ctx, "k_head_splitk", st); k_head_splitk<<<head_grid, 256, LDS_SPLITK, st>>>(h); }
     TailArgs t;
     t.part = part; t.b1 = m->b1; t.splits = splits; t.part_rows = B;
-    t.wo = m->wo; t.bo = m->bo; t.probs = d_probs; t.B = B; t.epoch = m->sp_epoch;
+    t.wo = m->wo; t.bo = m->bo; t.probs = d_probs; t.B = B; t.epoch = m->sp_epoch; t.err = m->sp_err;
     launch_tail(ctx, m, t, n_tiles, st);
     PV_HIP(hipGetLastError());
     return PV_OK;
@@ -1479,7 +1488,8 @@ extern "C" int pv_rnn_forward_p1_debug(pv_ctx* ctx, const int8_t* images, int64_
     PV_HIP(hipStreamSynchronize(st));
     if (n_timeouts) {   // only possible when the launch's workgroups could not all be resident (a GPU shared with other work)
         PV_HIP(hipMemset(ctx->p1->sp_err, 0, sizeof(int)));
-        pv_set_error("unit-split LSTM form: %d exchange polls timed out (GPU shared with other work?); rerun with PV_LSTM_SPLIT=0", n_timeouts);
+        pv_set_error("unit-split LSTM form: %d exchange polls timed out (GPU shared with other work?); the probabilities of this call are NaN. "
+                     "Set option shared_device = 1 (or lstm_split = 0) on this context", n_timeouts);
         return PV_ERR_STATE;
     }
     return PV_OK;

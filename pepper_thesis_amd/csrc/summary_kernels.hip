@@ -2548,7 +2548,7 @@ static int polish_launch(pv_ctx* ctx, const pv_batch_in* in, int64_t n_reads, in
 
     pv_prof_scope ps_all(ctx, "polish_pipeline", st);
     k_init<<<grid_for(std::max<int64_t>(a.n_tiles, D_NDIAG + 8), 256), 256, 0, st>>>(a);
-    PV_HIP(hipMemsetAsync(a.ins_cnt, 0, (size_t)(max_ins_rows > 0 ? max_ins_rows : 1) * 10 * sizeof(int32_t), st));
+    { int rcz = pv_zero_async(a.ins_cnt, (size_t)(max_ins_rows > 0 ? max_ins_rows : 1) * 10 * sizeof(int32_t), st); if (rcz) return rcz; }
     if (n_reads > 0) { pv_prof_scope ps(ctx, "k_cigar_scan", st); k_cigar_scan<<<grid_for(n_reads, 4), 256, 0, st>>>(a); }
     k_scan_tiles<<<1, 1024, 0, st>>>(a);
     if (n_reads > 0) { pv_prof_scope ps(ctx, "k_tile_fill", st); k_tile_fill<<<grid_for(n_reads, 4), 256, 0, st>>>(a); }

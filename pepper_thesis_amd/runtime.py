@@ -74,8 +74,26 @@ class Context:
     def stream(self) -> int:
         return int(self.lib.pv_stream(self.handle) or 0)
 
-    def synchronize(self):
+    def synchronize(self, check: bool = True):
+        """wait for the context's stream. check=True also asks whether a poll of the split RNN forms gave up since the last
+        synchronisation point (the outputs of such calls are poisoned on the device: NaN / label 255) and raises
+        PepperHipError(PV_ERR_STATE) if so - callers of the asynchronous *_dev forms get the verdict where they wait."""
         _ffi.check(self.lib.pv_synchronize(self.handle))
+        if check:
+            n = self.exchange_timeouts()
+            if n:
+                raise _ffi.PepperHipError(_ffi.PV_ERR_STATE, "%d exchange polls of a split RNN form timed out: the outputs of the "
+                                          "calls since the last synchronisation are poisoned (set_option('shared_device', 1) "
+                                          "on a GPU shared with other work)" % n)
+
+    def set_option(self, name: str, value: int):
+        """kernel-form options of this context (include/pepper_hip.h, pv_set_option)"""
+        _ffi.check(self.lib.pv_set_option(self.handle, name.encode(), int(value)))
+
+    def get_option(self, name: str) -> int:
+        v = C.c_int()
+        _ffi.check(self.lib.pv_get_option(self.handle, name.encode(), C.byref(v)))
+        return int(v.value)
 
     def graph_capture(self, stream: int = 0):
         """context manager: the *_dev calls made inside (with this stream) are recorded into a hipGraph instead of run;

@@ -42,3 +42,18 @@ def hip_ctx():
     ctx = runtime.Context(0)
     yield ctx
     ctx.close()
+
+
+OPTION_DEFAULTS = {"lstm_split": 1, "lstm_rows": 0, "tail_rows": 0, "head_splits": 0, "head_map": 1, "gru_rows": 0, "gru_split": 1,
+                   "gru_usplit": 1, "gru_mid": 1, "shared_device": 0, "exchange_spin_log2": 18, "debug_drop_part": -1}
+
+
+@pytest.fixture
+def opts(hip_ctx):
+    """set kernel-form options on the session context for one test (pv_set_option); defaults are restored afterwards"""
+    def set_(**kw):
+        for k, v in kw.items():
+            hip_ctx.set_option(k, v)
+    yield set_
+    for k, v in OPTION_DEFAULTS.items():
+        hip_ctx.set_option(k, v)

@@ -20,19 +20,16 @@ def gold():
     return np.load(GOLD, allow_pickle=False)
 
 
-def _lstm_form(monkeypatch, rows):
+def _lstm_form(opts, rows):
     """"16" / "32": the two tile forms of k_lstm_layer (16x16x4 and 32x32x2 MFMA); "split": the library's own choice for a small
     batch, the unit-split form k_lstm_split (four workgroups per tile and direction, h exchanged every step)"""
-    if rows == "split":
-        monkeypatch.delenv("PV_LSTM_ROWS", raising=False)
-    else:
-        monkeypatch.setenv("PV_LSTM_ROWS", rows)
+    opts(lstm_rows=0 if rows == "split" else int(rows))
 
 
 @pytest.mark.parametrize("rows", ["16", "32", "split"])
 @pytest.mark.parametrize("tag", ["p1", "p1sharp"])
-def test_p1_matches_reference_golden(hip_ctx, gold, tag, rows, monkeypatch):
-    _lstm_form(monkeypatch, rows)
+def test_p1_matches_reference_golden(hip_ctx, gold, tag, rows, opts):
+    _lstm_form(opts, rows)
     w = synth.make_weights_p1(int(gold[tag + "/seed"][0]), float(gold[tag + "/gain"][0]))
     hip_ctx.load_p1(w)
     probs, enc, dec = hip_ctx.forward_p1(gold[tag + "/images"], taps=True)
@@ -43,9 +40,9 @@ def test_p1_matches_reference_golden(hip_ctx, gold, tag, rows, monkeypatch):
 
 @pytest.mark.parametrize("rows", ["16", "32", "split"])
 @pytest.mark.parametrize("B", [1, 15, 16, 17, 31, 32, 33, 100, 512])
-def test_p1_ragged_batches_vs_oracle(hip_ctx, B, rows, monkeypatch):
+def test_p1_ragged_batches_vs_oracle(hip_ctx, B, rows, opts):
     """batch sizes around the 16- and 32-row tile edges, all three kernel forms; the oracle runs in float64"""
-    _lstm_form(monkeypatch, rows)
+    _lstm_form(opts, rows)
     w = synth.make_weights_p1(99, 2.5)
     hip_ctx.load_p1(w)
     x = synth.synth_windows(1000 + B, B)
@@ -60,16 +57,16 @@ def test_p1_ragged_batches_vs_oracle(hip_ctx, B, rows, monkeypatch):
 
 
 @pytest.mark.parametrize("B", [1, 17, 100, 512, 513, 1000])
-def test_p1_unit_split_form_equals_one_workgroup_form(hip_ctx, B, monkeypatch):
+def test_p1_unit_split_form_equals_one_workgroup_form(hip_ctx, B, opts):
     """a small batch runs with the hidden units of every (tile, direction) split over four workgroups (up to 512 windows) or
     two (up to 1024) that exchange h once per step (data-tagged write-through pairs). Same MFMA shape, same K order per
     accumulator as the 16-row one-workgroup form: the layer outputs and the probabilities are BIT-identical to it, and run to run"""
     w = synth.make_weights_p1(31, 2.0)
     hip_ctx.load_p1(w)
     x = synth.synth_windows(3100 + B, B)
-    monkeypatch.delenv("PV_LSTM_ROWS", raising=False)
+    opts(lstm_rows=0)
     runs = [hip_ctx.forward_p1(x, taps=True) for _ in range(3)]
-    monkeypatch.setenv("PV_LSTM_ROWS", "16")
+    opts(lstm_rows=16)
     p0, e0, d0 = hip_ctx.forward_p1(x, taps=True)
     for p1, e1, d1 in runs:
         if B <= 512:   # the four-part instantiation: the very same bits
@@ -166,8 +163,8 @@ def _check_labels(labels, acc_ref, labels_ref):
 
 @pytest.mark.parametrize("rows", ["16", "32"])
 @pytest.mark.parametrize("tag", ["p2", "p2sharp"])
-def test_p2_matches_reference_golden(hip_ctx, gold, tag, rows, monkeypatch):
-    monkeypatch.setenv("PV_GRU_ROWS", rows)  # both tile forms of k_gru_p2 (16x16x4 and 32x32x2 MFMA)
+def test_p2_matches_reference_golden(hip_ctx, gold, tag, rows, opts):
+    opts(gru_rows=int(rows))  # both tile forms of k_gru_p2 (16x16x4 and 32x32x2 MFMA)
     w = synth.make_weights_p2(int(gold[tag + "/seed"][0]), float(gold[tag + "/gain"][0]))
     hip_ctx.load_p2(w)
     labels, acc = hip_ctx.forward_p2(gold[tag + "/images"], want_acc=True)
@@ -177,8 +174,8 @@ def test_p2_matches_reference_golden(hip_ctx, gold, tag, rows, monkeypatch):
 
 @pytest.mark.parametrize("rows", ["16", "32"])
 @pytest.mark.parametrize("B", [1, 33, 70])
-def test_p2_ragged_batches_vs_oracle(hip_ctx, B, rows, monkeypatch):
-    monkeypatch.setenv("PV_GRU_ROWS", rows)
+def test_p2_ragged_batches_vs_oracle(hip_ctx, B, rows, opts):
+    opts(gru_rows=int(rows))
     w = synth.make_weights_p2(31, 3.0)
     hip_ctx.load_p2(w)
     x = synth.synth_p2_images(500 + B, B)
@@ -344,23 +341,23 @@ def test_p1_bf16_mode_chunks_large_batches():
 
 
 @pytest.mark.parametrize("B", [5, 40, 200, 1000])
-def test_p2_split_forms_equal_fused_form(hip_ctx, B, monkeypatch):
+def test_p2_split_forms_equal_fused_form(hip_ctx, B, opts):
     """small batches run split over CUs: by default the UNIT-split form (workgroup = tile x direction x half of the hidden
-    units, the halves swap h every step through data-tagged write-through pairs; up to 1024 chunks), with PV_GRU_USPLIT=0 the
+    units, the halves swap h every step through data-tagged write-through pairs; up to 1024 chunks), with option gru_usplit = 0 the
     direction-split form (two workgroups per tile, hand-offs at the layer boundaries only). Both keep x- and h-products in
     separate accumulators, so sums round differently from the one-workgroup form: agreement to 1e-5 on logits / accumulated
     softmax, equal labels away from ties, and bit-identical run to run, for the 19-window loop and the single-window operator"""
     hip_ctx.load_p2(synth.make_weights_p2(11, 2.0))
     y = synth.synth_p2_images(500 + B, B)
-    monkeypatch.setenv("PV_GRU_SPLIT", "0")
+    opts(gru_split=0)
     l0, a0 = hip_ctx.forward_p2(y, want_acc=True)                       # one workgroup per tile
     lg0, h0 = hip_ctx.forward_p2_window(y[:, :100].copy())
-    monkeypatch.delenv("PV_GRU_SPLIT")
+    opts(gru_split=1)
     top2 = np.sort(a0, axis=2)
     clear = (top2[..., -1] - top2[..., -2]) > 1e-4
     for form in ("unit_split", "direction_split"):
         if form == "direction_split":
-            monkeypatch.setenv("PV_GRU_USPLIT", "0")
+            opts(gru_usplit=0)
         l1, a1 = hip_ctx.forward_p2(y, want_acc=True)
         lg1, h1 = hip_ctx.forward_p2_window(y[:, :100].copy())
         np.testing.assert_allclose(a1, a0, atol=1e-5, rtol=0, err_msg=form)
@@ -402,3 +399,95 @@ def test_p2_unit_split_exchange_under_uneven_load(hip_ctx):
     for k, (l, a) in enumerate(outs):
         assert torch.equal(a.view(torch.int32), qa.view(torch.int32)) and torch.equal(l, ql), "call %d" % k
     other.close()
+
+
+# ---- a split form whose partner never shows up: the results must not look like results ---------------------------------
+def test_p1_exchange_timeout_poisons_the_call(hip_ctx, opts):
+    """debug_drop_part masks one of the four workgroups of every (tile, direction) off and the spin limit is lowered: its
+    partners' polls give up, k_head_tail sees the error word and writes NaN; the asynchronous form returns PV_OK but its
+    output cannot be mistaken for probabilities, the verdict arrives at the synchronisation point, every later call on the
+    context is poisoned too until the host has acknowledged, and after that the context works again"""
+    import torch
+    from pepper_thesis_amd import _ffi
+    w = synth.make_weights_p1(21, 2.0)
+    hip_ctx.load_p1(w)
+    x = synth.synth_windows(77, 100)
+    good = hip_ctx.forward_p1(x)
+    opts(exchange_spin_log2=4, debug_drop_part=1)
+    dev = "cuda:%d" % hip_ctx.device_id
+    dx = torch.from_numpy(x).to(dev)
+    dp = torch.zeros((100, 3), dtype=torch.float32, device=dev)
+    hip_ctx.forward_p1_dev(dx.data_ptr(), 100, dp.data_ptr())          # rc 0: asynchronous
+    with pytest.raises(_ffi.PepperHipError) as e:
+        hip_ctx.synchronize()
+    assert e.value.code == _ffi.PV_ERR_STATE
+    assert torch.isnan(dp).all()
+    # the host-buffer form reports it itself
+    with pytest.raises(_ffi.PepperHipError) as e:
+        hip_ctx.forward_p1(x)
+    assert e.value.code == _ffi.PV_ERR_STATE
+    # sticky until acknowledged: a healthy call behind a failed one is poisoned as well
+    hip_ctx.forward_p1_dev(dx.data_ptr(), 100, dp.data_ptr())
+    opts(debug_drop_part=-1, exchange_spin_log2=18)
+    hip_ctx.forward_p1_dev(dx.data_ptr(), 100, dp.data_ptr())
+    hip_ctx.synchronize(check=False)
+    assert torch.isnan(dp).all()
+    assert hip_ctx.exchange_timeouts() > 0      # acknowledge
+    assert hip_ctx.exchange_timeouts() == 0
+    np.testing.assert_array_equal(hip_ctx.forward_p1(x), good)
+
+
+@pytest.mark.parametrize("form", ["unit_split", "direction_split"])
+def test_p2_exchange_timeout_poisons_the_call(hip_ctx, opts, form):
+    """the same for the GRU forms: the per-step poll (unit split), pair_handoff (direction split) and quad_handoff all count
+    their give-ups; k_gru_finish then writes labels 255 and NaN into everything the launch produced"""
+    from pepper_thesis_amd import _ffi
+    hip_ctx.load_p2(synth.make_weights_p2(13, 2.0))
+    y = synth.synth_p2_images(640, 20)
+    if form == "direction_split":
+        opts(gru_usplit=0)
+    good_l, good_a = hip_ctx.forward_p2(y, want_acc=True)
+    opts(exchange_spin_log2=4, debug_drop_part=1)
+    with pytest.raises(_ffi.PepperHipError) as e:
+        hip_ctx.forward_p2(y, want_acc=True)
+    assert e.value.code == _ffi.PV_ERR_STATE
+    # device form: poisoned outputs, PV_OK from the call, the verdict at the synchronisation point
+    import torch
+    dev = "cuda:%d" % hip_ctx.device_id
+    dy = torch.from_numpy(y).to(dev)
+    dl = torch.zeros((20, 1000), dtype=torch.uint8, device=dev)
+    da = torch.zeros((20, 1000, 5), dtype=torch.float32, device=dev)
+    hip_ctx.forward_p2_dev(dy.data_ptr(), 20, dl.data_ptr(), da.data_ptr())
+    with pytest.raises(_ffi.PepperHipError):
+        hip_ctx.synchronize()
+    assert (dl == 255).all() and torch.isnan(da).all()
+    with pytest.raises(_ffi.PepperHipError):
+        hip_ctx.forward_p2_window(y[:, :100].copy())
+    opts(debug_drop_part=-1, exchange_spin_log2=18)
+    l, a = hip_ctx.forward_p2(y, want_acc=True)
+    assert np.array_equal(l, good_l) and np.array_equal(a.view(np.uint32), good_a.view(np.uint32))
+
+
+def test_shared_device_option_picks_resident_free_forms(hip_ctx, opts):
+    """shared_device = 1: no form that needs co-resident workgroups, whatever the batch size - the masked-off partner of the
+    tests above is then irrelevant (nothing polls), and results agree with the default forms to rounding"""
+    hip_ctx.load_p1(synth.make_weights_p1(21, 2.0))
+    x = synth.synth_windows(78, 64)
+    ref = hip_ctx.forward_p1(x)
+    opts(shared_device=1, debug_drop_part=2, exchange_spin_log2=4)
+    np.testing.assert_allclose(hip_ctx.forward_p1(x), ref, atol=2e-6, rtol=0)
+    hip_ctx.load_p2(synth.make_weights_p2(13, 2.0))
+    y = synth.synth_p2_images(641, 9)
+    l1, a1 = hip_ctx.forward_p2(y, want_acc=True)
+    opts(shared_device=0, debug_drop_part=-1, exchange_spin_log2=18)
+    l0, a0 = hip_ctx.forward_p2(y, want_acc=True)
+    np.testing.assert_allclose(a1, a0, atol=1e-5, rtol=0)
+
+
+def test_options_are_validated(hip_ctx):
+    from pepper_thesis_amd import _ffi
+    for name, v in (("lstm_rows", 8), ("head_splits", 5), ("no_such_option", 1), ("exchange_spin_log2", 40)):
+        with pytest.raises(_ffi.PepperHipError) as e:
+            hip_ctx.set_option(name, v)
+        assert e.value.code == _ffi.PV_ERR_INVALID
+    assert hip_ctx.get_option("lstm_split") == 1

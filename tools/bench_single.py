@@ -37,6 +37,8 @@ def callers(ctx, dev, weights, ncall, reps=20):
     from pepper_thesis_amd import runtime, synth
     ctxs = [ctx] + [runtime.Context(ctx.device_id) for _ in range(ncall - 1)]
     for c in ctxs[1:]:
+        c.set_option("lstm_split", ctx.get_option("lstm_split"))
+    for c in ctxs[1:]:
         c.load_p1(weights)
     xs = [torch.from_numpy(synth.synth_windows(30 + i, 512)).to(dev) for i in range(ncall)]
     ps = [torch.zeros((512, 3), dtype=torch.float32, device=dev) for _ in range(ncall)]
@@ -63,7 +65,7 @@ if __name__ == "__main__":
     ctx.load_p1(w)
     out = {}
     for form in ("split", "one_workgroup"):
-        os.environ["PV_LSTM_SPLIT"] = "1" if form == "split" else "0"
+        ctx.set_option("lstm_split", 1 if form == "split" else 0)
         out[form] = {"B%d" % B: one(ctx, "cuda:0", B) for B in (64, 256, 512, 1024)}
         out[form]["callers4_x_B512_windows_per_s"] = callers(ctx, "cuda:0", w, 4)
         sys.stderr.write("[bench_single] %s done\n" % form)
