@@ -10,8 +10,8 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(CSRC, "libpepper_hip.so")
-SOURCES = ["pv_api.hip", "summary_kernels.hip", "rnn_kernels.hip", "rnn_gru.hip", "pv_comm.hip"]
-HEADERS = ["pv_common.hpp", "mfma_tiles.hpp", os.path.join("..", "..", "include", "pepper_hip.h")]
+SOURCES = ["pv_api.hip", "summary_kernels.hip", "rnn_kernels.hip", "rnn_gru.hip", "rnn_rec_bf16.hip", "pv_comm.hip"]
+HEADERS = ["pv_common.hpp", "mfma_tiles.hpp", "rnn_bf16.hpp", os.path.join("..", "..", "include", "pepper_hip.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
          "-fgpu-rdc" if False else "-fno-gpu-rdc"]
 

@@ -19,6 +19,7 @@
 // argmax are fused into the same launch.
 #include "pv_common.hpp"
 #include "mfma_tiles.hpp"
+#include "rnn_bf16.hpp"
 
 #include <algorithm>
 #include <cstdlib>
@@ -1013,6 +1014,8 @@ struct pv_rnn_p2 {
     const void* us_hx_seen = nullptr; size_t us_hx_n = 0;   // the exchange buffer whose tags belong to this epoch sequence
     float* enc_bias = nullptr; float* dec_bias = nullptr;
     float* dense_w = nullptr; float* dense_b = nullptr;
+    int dtype = PV_DTYPE_F32;
+    pv_p2_bf16_weights bf;   // PV_DTYPE_BF16_INPUT_GEMM: fragment streams / split8 rows of the layer-wise path (rnn_rec_bf16.hip)
     std::vector<void*> owned;
 };
 
@@ -1033,7 +1036,7 @@ void pv_rnn_free_p2(pv_ctx* ctx) {
 
 extern "C" int pv_rnn_load_p2(pv_ctx* ctx, const pv_weights_p2* w, int dtype) {
     PV_CHECK(ctx && w, PV_ERR_INVALID, "null argument");
-    PV_CHECK(dtype == PV_DTYPE_F32, PV_ERR_INVALID, "dtype %d not implemented (only PV_DTYPE_F32)", dtype);
+    PV_CHECK(dtype == PV_DTYPE_F32 || dtype == PV_DTYPE_BF16_INPUT_GEMM, PV_ERR_INVALID, "unknown dtype %d", dtype);
     for (int d = 0; d < 2; d++)
         PV_CHECK(w->encoder[d].w_ih && w->encoder[d].w_hh && w->encoder[d].b_ih && w->encoder[d].b_hh &&
                      w->decoder[d].w_ih && w->decoder[d].w_hh && w->decoder[d].b_ih && w->decoder[d].b_hh,
@@ -1046,8 +1049,34 @@ extern "C" int pv_rnn_load_p2(pv_ctx* ctx, const pv_weights_p2* w, int dtype) {
     }
     pv_rnn_p2* m = new pv_rnn_p2();
     ctx->p2 = m;
+    m->dtype = dtype;
     std::vector<float> wp, bias;
     int rc;
+    if (dtype == PV_DTYPE_BF16_INPUT_GEMM) {
+        // every matrix product on the bf16 MFMA with 3-term split operands: W_hh / encoder W_ih as fragment streams of
+        // k_rec_bf16, the decoder's W_ih of both directions as split8 rows for the per-window GEMM
+        std::vector<float> eb((size_t)2 * 3 * HG), ehn((size_t)2 * HG), dhn((size_t)2 * HG), wcat((size_t)6 * HG * KPD), bcat((size_t)6 * HG);
+        for (int d = 0; d < 2; d++) {
+            for (int u = 0; u < HG; u++) {
+                for (int g = 0; g < 2; g++) {
+                    eb[(size_t)d * 3 * HG + g * HG + u] = w->encoder[d].b_ih[g * HG + u] + w->encoder[d].b_hh[g * HG + u];
+                    bcat[(size_t)d * 3 * HG + g * HG + u] = w->decoder[d].b_ih[g * HG + u] + w->decoder[d].b_hh[g * HG + u];
+                }
+                eb[(size_t)d * 3 * HG + 2 * HG + u] = w->encoder[d].b_ih[2 * HG + u];
+                bcat[(size_t)d * 3 * HG + 2 * HG + u] = w->decoder[d].b_ih[2 * HG + u];
+                ehn[(size_t)d * HG + u] = w->encoder[d].b_hh[2 * HG + u];
+                dhn[(size_t)d * HG + u] = w->decoder[d].b_hh[2 * HG + u];
+            }
+            memcpy(&wcat[(size_t)d * 3 * HG * KPD], w->decoder[d].w_ih, (size_t)3 * HG * KPD * sizeof(float));
+        }
+        if ((rc = pv_pack_rec_bf16(w->encoder, 3, FEAT, &m->bf.enc_wp, &m->bf.enc_wx, m->owned))) return rc;
+        if ((rc = pv_pack_rec_bf16(w->decoder, 3, 0, &m->bf.dec_wp, nullptr, m->owned))) return rc;
+        if ((rc = up2(eb.data(), eb.size(), &m->bf.enc_bias, m->owned)) || (rc = up2(ehn.data(), ehn.size(), &m->bf.enc_bias_hn, m->owned)) ||
+            (rc = up2(dhn.data(), dhn.size(), &m->bf.dec_bias_hn, m->owned)) || (rc = up2(bcat.data(), bcat.size(), &m->bf.dec_bias_cat, m->owned)))
+            return rc;
+        if ((rc = pv_upload_split8(wcat.data(), (size_t)6 * HG, KPD, &m->bf.dec_wih_s, m->owned))) return rc;
+        if ((rc = pv_gemm_bf16x3_prepare()) || (rc = pv_rec_bf16_prepare())) return rc;
+    }
     for (int f = 0; f < 3; f++) {
         pack_gru(w->encoder, FEAT, KPE, f ? 16 : 32, wp, bias, f == 2);
         if ((rc = up2(wp.data(), wp.size(), &m->enc_wp[f], m->owned))) return rc;
@@ -1068,6 +1097,7 @@ extern "C" int pv_rnn_load_p2(pv_ctx* ctx, const pv_weights_p2* w, int dtype) {
     m->owned.push_back(m->us_epoch);
     PV_HIP(hipMemset(m->us_epoch, 0, 64));
     if ((rc = up2(w->dense_w, (size_t)NCLS * KPD, &m->dense_w, m->owned)) || (rc = up2(w->dense_b, NCLS, &m->dense_b, m->owned))) return rc;
+    m->bf.dense_w = m->dense_w; m->bf.dense_b = m->dense_b;
     PV_HIP(hipFuncSetAttribute((const void*)k_gru_p2<32, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_p2<32, false>()));
     PV_HIP(hipFuncSetAttribute((const void*)k_gru_p2<16, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_p2<16, false>()));
     PV_HIP(hipFuncSetAttribute((const void*)k_gru_p2<16, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_p2<16, true>()));
@@ -1078,6 +1108,21 @@ static int p2_launch(pv_ctx* ctx, const uint8_t* d_images, int64_t B, uint8_t* d
                      int seq = SEQ, int nwin = NWIN, const float* d_hidden_in = nullptr, float* d_hidden_out = nullptr,
                      float* d_logits = nullptr) {
     pv_rnn_p2* m = ctx->p2;
+    if (m->dtype == PV_DTYPE_BF16_INPUT_GEMM) {
+        // the layer-wise path: no split form, no exchange (the finishing kernel still honours a pending error word)
+        float* acc = d_acc;
+        int rcb;
+        if (!acc && (rcb = pv_get(ctx, "p2.acc", (size_t)B * seq * NCLS, &acc))) return rcb;
+        if ((rcb = pv_p2_bf16_forward(ctx, m->bf, d_images, B, d_labels, acc, st, seq, nwin, d_hidden_in, d_hidden_out, d_logits))) return rcb;
+        GruFinishArgs fb;
+        fb.epoch = nullptr; fb.err = m->us_err; fb.labels = d_labels; fb.n_labels = d_labels ? B * seq : 0;
+        fb.f[0] = acc; fb.nf[0] = B * seq * NCLS;
+        fb.f[1] = d_logits; fb.nf[1] = d_logits ? B * WIN * NCLS : 0;
+        fb.f[2] = d_hidden_out; fb.nf[2] = d_hidden_out ? B * 2 * HG : 0;
+        k_gru_finish<<<(unsigned)std::min<int64_t>((B * seq + 255) / 256, 4 * ctx->num_cu), 256, 0, st>>>(fb);
+        PV_HIP(hipGetLastError());
+        return PV_OK;
+    }
     // tile form: 32-row tiles once they fill the chip, else 16-row tiles (twice the workgroups, half the time per step)
     int tr = ((B + 31) / 32 >= ctx->num_cu) ? 32 : 16;
     if (ctx->opt.gru_rows) tr = ctx->opt.gru_rows;

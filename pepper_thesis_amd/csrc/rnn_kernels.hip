@@ -17,10 +17,11 @@
 //   k_head_splitk          linear_1 (K = 16896) as a split-K MFMA product over time-step chunks,
 //        deterministic partial slabs (no float atomics).
 //   k_head_tail<TR>        sum of slabs + bias + SELU, linear_2..5 + SELU (MFMA), output layer, softmax.
-//   k_gemm_bf16x3, k_lstm_rec_g   PV_DTYPE_BF16_INPUT_GEMM: decoder input projection and linear_1 as 3-term bf16 split
-//        GEMMs on the bf16 MFMA, recurrence on the pre-computed projections in fp32.
+//   k_gemm_bf16x3          PV_DTYPE_BF16_INPUT_GEMM: decoder input projection and linear_1 as 3-term bf16 split GEMMs on the
+//        bf16 MFMA; the recurrent layers of that mode are k_rec_bf16 (rnn_rec_bf16.hip).
 #include "pv_common.hpp"
 #include "mfma_tiles.hpp"
+#include "rnn_bf16.hpp"
 
 #include <algorithm>
 #include <cmath>
@@ -47,8 +48,11 @@ __device__ __forceinline__ float sigmoidf_(float x) { return rcpf_(1.0f + __expf
 __device__ __forceinline__ float tanhf_(float x) {
     // 1 - 2/(e^{2x}+1): saturates cleanly at +-1 (e = inf -> 1, e = 0 -> -1)
     const float e = __expf(2.0f * x);
-    return 1.0f - 2.0f * rcpf_(e + 1.0f);
+    return __builtin_fmaf(-2.0f, rcpf_(e + 1.0f), 1.0f);
 }
+// c' = f * c + i * g with the fused multiply-add spelled out: left to the compiler's contraction, two instantiations of the
+// same cell update (k_lstm_layer / k_lstm_split) can round differently, and their outputs are compared bit for bit
+__device__ __forceinline__ float lstm_c_(float fg, float c, float ig, float gg) { return __builtin_fmaf(fg, c, ig * gg); }
 __device__ __forceinline__ float seluf_(float x) {
     return 1.0507009873554805f * (x > 0.0f ? x : 1.6732632423543772f * (__expf(x) - 1.0f));
 }
@@ -58,14 +62,6 @@ __device__ __forceinline__ float seluf_(float x) {
 // One 16-byte half of a group is exactly one MFMA A/B fragment of v_mfma_f32_32x32x16_bf16, so the GEMM moves operands
 // from HBM to LDS by LDS-DMA without touching a register. Byte offset of element k inside a row: (k >> 3) * 32 + (k & 7) * 2
 // (+16 for lo).
-__device__ __forceinline__ void split8_store(float x, __amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
-    const __bf16 hi = (__bf16)x;
-    const __bf16 lo = (__bf16)(x - (float)hi);
-    __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(unsigned short, hi), r, voff, soff, 0);
-    __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(unsigned short, lo), r, voff, soff + 16u, 0);
-}
-__device__ __forceinline__ unsigned split8_off(unsigned k) { return (k >> 3) * 32u + (k & 7u) * 2u; }
-
 // ---- weight-fragment rings ------------------------------------------------------------------------------------------
 // The B operand (packed weights, one f32x4 per lane per gate tile per k-block of 8) comes from L2, ~1 us away, while a
 // k-block is 12-16 MFMAs (0.3-0.45 us): fragments run in a ring of FOUR register sets fed by raw buffer loads THREE
@@ -167,9 +163,7 @@ struct LstmArgs {
     const float* x_f32;   // [Bp,33,512]  (decoder; padded to whole 32-row tiles)
     const float* wp;      // packed [2 dirs][8 waves][nkb][4 gates][64][4] in the tile form of the launch
     const float* bias;    // [2][1024] b_ih + b_hh
-    float* out;           // [Bp,33,512] fp32 (may be NULL when out_split is given)
-    unsigned char* out_split;  // optional split8 rows, TIME-MAJOR [33][Bp][512]: A operand of the bf16x3 decoder GEMM
-    int64_t Bp;           // rows of a time slab of out_split
+    float* out;           // [Bp,33,512] fp32
     int64_t B;
     int n_tiles;          // tiles of TR rows
 };
@@ -227,7 +221,6 @@ __global__ __launch_bounds__(512, 2) void k_lstm_layer(LstmArgs a) {
     // (tile resource) + (lane offset, computed once) + (scalar offset of row group u and step t)
     const __amdgpu_buffer_rsrc_t xsr = make_rsrc(INT8 ? (const void*)a.wp : (const void*)(a.x_f32 + (size_t)b0 * T_STEPS * KP));
     const __amdgpu_buffer_rsrc_t osr = make_rsrc(a.out + (size_t)b0 * T_STEPS * 2 * H);
-    const __amdgpu_buffer_rsrc_t ssr = make_rsrc(a.out_split + (size_t)b0 * 2 * H * 4);
     const unsigned xg_l = (unsigned)(((tid / V4) * T_STEPS * KP + (tid % V4) * 4) * 4);
     const unsigned xl_l = (unsigned)((tid / V4) * LDX + (tid % V4) * 4);
     const unsigned xe_l = (unsigned)((tid >> 5) * LDX + (tid & 31));
@@ -263,7 +256,6 @@ __global__ __launch_bounds__(512, 2) void k_lstm_layer(LstmArgs a) {
     };
     const unsigned h_l = (unsigned)(lane_row<TR>(lane) * LDH + unit0);                      // lane part of the h tile offset
     const unsigned og_l = (unsigned)((lane_row<TR>(lane) * T_STEPS * 2 * H + unit0) * 4);   // lane part of the output byte offset
-    const unsigned sg_l = (unsigned)(lane_row<TR>(lane) * 2 * H * 4) + split8_off((unsigned)unit0);  // same for the split8 rows (unit0 + 16 adds two groups)
     x_load(dir ? T_STEPS - 1 : 0);
     x_store();
     __syncthreads();
@@ -289,15 +281,13 @@ __global__ __launch_bounds__(512, 2) void k_lstm_layer(LstmArgs a) {
             const float fg = sigmoidf_(gate_get<TR>(acc[1], e));
             const float gg = tanhf_(gate_get<TR>(acc[2], e));
             const float og = sigmoidf_(gate_get<TR>(acc[3], e));
-            const float c = fg * cst[e] + ig * gg;
+            const float c = lstm_c_(fg, cst[e], ig, gg);
             cst[e] = c;
             const float h = og * tanhf_(c);
             (hn + elem_row<TR>(e) * LDH + elem_unit<TR>(e))[h_l] = h;
             // outputs are padded to whole tiles: unconditional stores, tile resource + lane offset + scalar offset
             const unsigned o_s = (unsigned)((t * 2 * H + dir * H + elem_row<TR>(e) * T_STEPS * 2 * H + elem_unit<TR>(e)) * 4);
-            if (a.out) PV_OSTORE(h, osr, og_l, o_s);
-            if (a.out_split)   // row (t, b), element dir*H + unit
-                split8_store(h, ssr, sg_l, (unsigned)(((size_t)t * a.Bp + elem_row<TR>(e)) * 2 * H * 4 + split8_off(dir * H + elem_unit<TR>(e))));
+            PV_OSTORE(h, osr, og_l, o_s);
         }
         lds_barrier();  // everyone is done reading xbuf / hbuf[cur]; hbuf[nxt] is complete (LDS only: mfma_tiles.hpp)
         if (s + 1 < T_STEPS) {
@@ -550,7 +540,7 @@ __global__ __launch_bounds__(1024 / SP_NS) void k_lstm_split(LstmSplitArgs a) {
             const float fg = sigmoidf_(acc[1][i]);
             const float gg = tanhf_(acc[2][i]);
             const float og = sigmoidf_(acc[3][i]);
-            const float c = fg * cst[i] + ig * gg;
+            const float c = lstm_c_(fg, cst[i], ig, gg);
             cst[i] = c;
             hv[i] = og * tanhf_(c);
         }
@@ -970,84 +960,6 @@ __global__ __launch_bounds__(512, 2) void k_gemm_bf16x3(GemmArgs g) {
     }
 }
 
-// decoder recurrence on pre-computed input projections G (fp32 [Bp*33, 2048], bias included): per step only the
-// h part runs on the f32 MFMA; G is fetched into registers at the start of the step and added in the cell update.
-struct RecArgs {
-    const float* G;       // quads [33*Bp/4][2048][4]: row m = t*Bp + b (time-major), columns dir*1024 + gate*256 + unit, four
-                          // consecutive rows of a column adjacent (k_gemm_bf16x3, c_quads)
-    int64_t Bp;
-    const float* wp;      // packed decoder weights [2 dirs][8 waves][96 kb][4][64][4] (the h part starts at k-block 64)
-    float* out;           // [Bp, 33, 512] fp32, or NULL (only the debug taps read it)
-    unsigned char* out_split;  // [Bp] split8 rows of 33*512 elements (A operand of the linear_1 GEMM)
-    int n_tiles;
-};
-
-__global__ __launch_bounds__(512, 2) void k_lstm_rec_g(RecArgs a) {
-    constexpr int LDH = H + 4, NKB_X = 64, NKB_H = H / 8, NT = 4, UW = 32;
-    extern __shared__ float smem[];
-    float* hbuf = smem;  // [2][32][LDH]
-    const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int xcd = blockIdx.x & 7;
-    const int dir = xcd & 1;
-    const int tile = (blockIdx.x >> 3) * 4 + (xcd >> 1);
-    if (tile >= a.n_tiles) return;
-    const int64_t b0 = (int64_t)tile * ROWS;
-    const float* wph = a.wp + ((size_t)(dir * 8 + wv) * (NKB_X + NKB_H) + NKB_X) * NT * 256;
-    for (int i = tid; i < 2 * ROWS * LDH; i += 512) hbuf[i] = 0.0f;
-    f32x16 cst;
-#pragma unroll
-    for (int r = 0; r < 16; r++) cst[r] = 0.0f;
-    const __amdgpu_buffer_rsrc_t wr = make_rsrc(wph);
-    f32x4 bq[4][NT];
-    ring_prime<NT>(bq, wr, 0, lane);
-    const int unit = UW * wv + (lane & 31);
-    // raw buffer accesses (tile resource + lane offset + scalar offset): no per-lane 64-bit addresses next to the 64 gx values
-    const __amdgpu_buffer_rsrc_t gsr = make_rsrc(a.G + (size_t)b0 * 2048);     // quad (b0 / 4) of time slab 0
-    const __amdgpu_buffer_rsrc_t osr = make_rsrc(a.out + (size_t)b0 * T_STEPS * 2 * H);
-    const unsigned gl_l = (unsigned)(((lane >> 5) * 2048 + (lane & 31)) * 16);  // quad h of a group of 8 rows, this lane's column
-    const unsigned og_l = (unsigned)((4 * (lane >> 5) * T_STEPS * 2 * H + (lane & 31)) * 4);
-    const __amdgpu_buffer_rsrc_t ssr = make_rsrc(a.out_split + (size_t)b0 * T_STEPS * 2 * H * 4);
-    const unsigned sg_l = (unsigned)(4 * (lane >> 5) * T_STEPS * 2 * H * 4) + split8_off((unsigned)(lane & 31));
-    __syncthreads();
-    for (int s = 0; s < T_STEPS; s++) {
-        const int t = dir ? (T_STEPS - 1 - s) : s;
-        const int cur = s & 1, nxt = cur ^ 1;
-        // input projections of this step: 64 values per lane, in flight during the h-part MFMAs
-        // (accumulator registers 4g..4g+3 = rows 8g + 4*(lane>>5) + 0..3 of this lane's column = one 16-byte quad of G)
-        f32x4 gx[NT][4];
-#pragma unroll
-        for (int nt = 0; nt < NT; nt++)
-#pragma unroll
-            for (int gq = 0; gq < 4; gq++)
-                gx[nt][gq] = buf_load4_nt(gsr, gl_l, (unsigned)((((size_t)t * a.Bp / 4 + 2 * gq) * 2048 + dir * 1024 + nt * H + UW * wv) * 16));
-        Gate<32> acc[NT];
-#pragma unroll
-        for (int nt = 0; nt < NT; nt++)
-#pragma unroll
-            for (int r = 0; r < 16; r++) acc[nt].v[r] = 0.0f;
-        mma_dual_ringb<32, NT>(acc, hbuf + cur * ROWS * LDH, LDH, s == 0 ? 0 : NKB_H, hbuf, LDH, 0, wr, bq, lane);  // h_0 = 0
-        float* hn = hbuf + nxt * ROWS * LDH;
-#pragma unroll
-        for (int r = 0; r < 16; r++) {
-            const float ig = sigmoidf_(acc[0].v[r] + gx[0][r >> 2][r & 3]);
-            const float fg = sigmoidf_(acc[1].v[r] + gx[1][r >> 2][r & 3]);
-            const float gg = tanhf_(acc[2].v[r] + gx[2][r >> 2][r & 3]);
-            const float og = sigmoidf_(acc[3].v[r] + gx[3][r >> 2][r & 3]);
-            const float c = fg * cst[r] + ig * gg;
-            cst[r] = c;
-            const float h = og * tanhf_(c);
-            const int rr = (r & 3) + 8 * (r >> 2);
-            const int row = rr + 4 * (lane >> 5);
-            hn[row * LDH + unit] = h;
-            const unsigned o_s = (unsigned)((t * 2 * H + dir * H + UW * wv + rr * T_STEPS * 2 * H) * 4);
-            if (a.out) buf_store1_nt(h, osr, og_l, o_s);
-            // row b, element k = t*512 + dir*256 + unit: flattened [t][512] = K index of linear_1
-            split8_store(h, ssr, sg_l, (unsigned)(rr * T_STEPS * 2 * H * 4) + split8_off((unsigned)(t * 2 * H + dir * H + UW * wv)));
-        }
-        lds_barrier();
-    }
-}
-
 // ---- host-side weight packing -----------------------------------------------------------------------
 // LSTM layer, 8 waves per workgroup, wave w owns hidden units [32w, 32w+32) of the gates i,f,g,o (nt).
 // Packed stream of one wave: [k-block of 8][gate][lane][4]; K = [x (padded to KP) | h]. Tile forms as in mfma_tiles.hpp:
@@ -1128,7 +1040,6 @@ static constexpr int64_t P1_BF16_MAX_BATCH = 16384;
 template <int KP> constexpr size_t lds_lstm_split() { return (size_t)(16 * (KP + 4) + 2 * 16 * (H + 4)) * sizeof(float); }
 static constexpr int SP_MAX_TILES = 64;   // 16-row tiles the exchange buffers are sized for (1024 windows)
 template <int KP, int TR> constexpr size_t lds_lstm() { return (size_t)(TR * (KP + 4) + 2 * TR * (H + 4)) * sizeof(float); }
-static constexpr size_t LDS_REC = (size_t)(2 * ROWS * (H + 4)) * sizeof(float);
 static constexpr size_t LDS_GEMM = (size_t)2 * 4 * 256 * 32 * 2 + 1024;   // 2 buffers x {A_hi, A_lo, W_hi, W_lo} x 256 rows x 32 bf16 = 128 KB, + bias slot
 static constexpr size_t LDS_SPLITK = (size_t)ROWS * (2 * H + 4) * sizeof(float);
 template <int TR> constexpr size_t lds_tail() { return (size_t)2 * TR * (HEAD_N + 4) * sizeof(float); }
@@ -1150,6 +1061,7 @@ struct pv_rnn_p1 {
     // PV_DTYPE_BF16_INPUT_GEMM: bf16 hi/lo splits of the decoder W_ih (both directions, [2048,512]) and linear_1 ([512,16896])
     unsigned char* dec_wih_s = nullptr; float* dec_bias_cat = nullptr;   // split8 rows
     unsigned char* w1_s = nullptr;
+    unsigned char* enc_rb = nullptr; unsigned char* dec_rb = nullptr;    // bf16 fragment streams of k_rec_bf16 (encoder: W_ih | W_hh; decoder: W_hh)
     std::vector<void*> owned;
 };
 
@@ -1276,8 +1188,9 @@ extern "C" int pv_rnn_load_p1(pv_ctx* ctx, const pv_weights_p1* w, int dtype) {
         if ((rc = dev_upload_split(wcat.data(), 2048, 512, &m->dec_wih_s, m->owned))) return rc;
         if ((rc = dev_upload(bcat, &m->dec_bias_cat, m->owned))) return rc;
         if ((rc = dev_upload_split(w->linear_w[0], HEAD_N, HEAD_K, &m->w1_s, m->owned))) return rc;
-        PV_HIP(hipFuncSetAttribute((const void*)k_gemm_bf16x3, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_GEMM));
-        PV_HIP(hipFuncSetAttribute((const void*)k_lstm_rec_g, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_REC));
+        if ((rc = pv_pack_rec_bf16(w->encoder, 4, F_IN, &m->enc_rb, nullptr, m->owned))) return rc;
+        if ((rc = pv_pack_rec_bf16(w->decoder, 4, 0, &m->dec_rb, nullptr, m->owned))) return rc;
+        if ((rc = pv_gemm_bf16x3_prepare()) || (rc = pv_rec_bf16_prepare())) return rc;
     }
     // opt in to > 64 KB of dynamic LDS (exact sizes; static LDS counts against the 160 KB too)
     PV_HIP(hipFuncSetAttribute((const void*)k_lstm_layer<32, true, 32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_lstm<32, 32>()));
@@ -1309,32 +1222,62 @@ static int p1_forward_launch(pv_ctx* ctx, const int8_t* d_images, int64_t B, flo
     pv_rnn_p1* m = ctx->p1;
     const int n_tiles = (int)((B + ROWS - 1) / ROWS);   // 32-row tiles: the granularity of every buffer and of the head
     // LSTM tile form: 32-row tiles once (tile, direction) workgroups fill the chip, else 16-row tiles: twice the workgroups,
-    // half the MFMA cycles per time step (the bf16x3 mode keeps 32: its recurrence kernel has one form)
-    int tr = ((int64_t)n_tiles * 2 >= ctx->num_cu || m->dtype != PV_DTYPE_F32) ? 32 : 16;
-    if ((ctx->opt.lstm_rows == 16 && m->dtype == PV_DTYPE_F32) || ctx->opt.lstm_rows == 32) tr = ctx->opt.lstm_rows;
+    // half the MFMA cycles per time step (the bf16x3 mode has its own layer kernel, below)
+    int tr = (int64_t)n_tiles * 2 >= ctx->num_cu ? 32 : 16;
+    if (ctx->opt.lstm_rows) tr = ctx->opt.lstm_rows;
     const int f = tr == 16 ? 1 : 0;
     const int n_lt = n_tiles * (ROWS / tr);             // whole 32-row tiles are covered in either form
     const unsigned lstm_grid = (unsigned)(((n_lt + 3) / 4) * 8);
-    const unsigned rec_grid = (unsigned)(((n_tiles + 3) / 4) * 8);
+    if (m->dtype == PV_DTYPE_BF16_INPUT_GEMM) {
+        // every matrix product on the bf16 MFMA: encoder layer (x-part in the step) -> decoder input projection as ONE GEMM
+        // -> decoder layer on the projections -> linear_1 as a split-K GEMM -> fp32 tail. 64-row tiles (one weight fetch of
+        // the recurrent stream feeds twice the rows) once 32-row (tile, direction) workgroups would not fit the chip at once.
+        const int mt = (int64_t)n_tiles * 2 > ctx->num_cu ? 2 : 1;
+        const int64_t Bp = (B + 32 * mt - 1) / (32 * mt) * (32 * mt), M = Bp * T_STEPS;
+        const size_t nel = (size_t)Bp * T_STEPS * 2 * H;
+        unsigned char *enc_split = nullptr, *dec_split = nullptr;
+        float* G = nullptr;
+        int rcb;
+        if ((rcb = pv_get(ctx, "p1.enc_split", nel * 4, &enc_split)) || (rcb = pv_get(ctx, "p1.dec_split", nel * 4, &dec_split)) ||
+            (rcb = pv_get(ctx, "p1.G", (size_t)M * 2048, &G))) return rcb;
+        pv_rec_desc re = {};
+        re.cell = 4; re.enc = 1; re.wp = m->enc_rb; re.bias = m->enc_bias; re.x = d_images; re.x_row_bytes = PV_WINDOW_BYTES; re.x_t0 = 0;
+        re.xf = F_IN; re.x_signed = 1; re.B = B; re.Bp = Bp; re.T = T_STEPS; re.out_tm = enc_split; re.out_f32 = taps ? enc_out : nullptr;
+        re.mt = mt; re.prof_name = "k_rec_bf16_lstm_enc";
+        if ((rcb = pv_rec_bf16_async(ctx, re, st))) return rcb;
+        pv_gemm_desc ga = {};
+        ga.A = enc_split; ga.W = m->dec_wih_s; ga.bias = m->dec_bias_cat; ga.C = G; ga.M = M; ga.N = 2048; ga.K = 2 * H; ga.splits = 1;
+        ga.quads = 1; ga.prof_name = "k_gemm_bf16x3_dec";
+        if ((rcb = pv_gemm_bf16x3_async(ctx, ga, st))) return rcb;
+        pv_rec_desc rd = {};
+        rd.cell = 4; rd.enc = 0; rd.G = G; rd.wp = m->dec_rb; rd.B = B; rd.Bp = Bp; rd.T = T_STEPS; rd.out_bm = dec_split;
+        rd.out_f32 = taps ? dec_out : nullptr; rd.mt = mt; rd.prof_name = "k_rec_bf16_lstm_dec";
+        if ((rcb = pv_rec_bf16_async(ctx, rd, st))) return rcb;
+        // linear_1 as a split-K bf16x3 GEMM into slabs [splits][Bp][512]: the smallest split factor (a divisor of the 528
+        // K steps of 32) whose work items fill the chip
+        static const int divs[] = {1, 2, 3, 4, 6, 8, 11, 12, 16, 22, 24, 33};
+        const int tiles = (int)((Bp + 255) / 256) * (HEAD_N / 256);
+        int gs = 33;
+        for (int dv : divs) if (tiles * dv >= ctx->num_cu) { gs = dv; break; }
+        pv_gemm_desc gl = {};
+        gl.A = dec_split; gl.W = m->w1_s; gl.bias = nullptr; gl.C = part; gl.M = Bp; gl.N = HEAD_N; gl.K = HEAD_K; gl.splits = gs; gl.quads = 0;
+        gl.prof_name = "k_gemm_bf16x3_lin1";
+        if ((rcb = pv_gemm_bf16x3_async(ctx, gl, st))) return rcb;
+        TailArgs tb;
+        tb.part = part; tb.b1 = m->b1; tb.splits = gs; tb.part_rows = Bp;
+        tb.wo = m->wo; tb.bo = m->bo; tb.probs = d_probs; tb.B = B; tb.epoch = m->sp_epoch; tb.err = m->sp_err;
+        launch_tail(ctx, m, tb, n_tiles, st);
+        PV_HIP(hipGetLastError());
+        return PV_OK;
+    }
     LstmArgs e;
     e.x_i8 = d_images; e.x_f32 = nullptr; e.wp = m->enc_wp[f]; e.bias = m->enc_bias; e.out = enc_out; e.B = B; e.n_tiles = n_lt;
-    e.out_split = nullptr; e.Bp = 0;
-    unsigned char *enc_split = nullptr, *dec_split = nullptr;
-    if (m->dtype == PV_DTYPE_BF16_INPUT_GEMM) {
-        // layer outputs leave the producers as split-bf16 words (hi | lo << 16), the operand form of the bf16x3 GEMMs; the
-        // fp32 copies are only written for the debug taps
-        const size_t nel = (size_t)n_tiles * ROWS * T_STEPS * 2 * H;
-        int rcb;
-        if ((rcb = pv_get(ctx, "p1.enc_split", nel * 4, &enc_split)) || (rcb = pv_get(ctx, "p1.dec_split", nel * 4, &dec_split))) return rcb;
-        e.out_split = enc_split; e.Bp = (int64_t)n_tiles * ROWS;
-        if (!taps) e.out = nullptr;
-    }
     // unit-split form: one small fp32 batch whose (16-row tile, direction, part of the hidden units) workgroups all fit on
     // the chip at once: four parts up to 512 windows on 256 CUs, two parts up to 1024. Options lstm_split = 0, an explicit
     // lstm_rows, or shared_device = 1 (other work on this GPU: residency is not given) keep the one-workgroup form
     const int n_t16 = n_tiles * 2;
     const int sp_ns = (int64_t)n_t16 * 2 * 4 <= ctx->num_cu ? 4 : 2;
-    bool split = m->dtype == PV_DTYPE_F32 && n_t16 <= SP_MAX_TILES && (int64_t)n_t16 * 2 * sp_ns <= ctx->num_cu;
+    bool split = n_t16 <= SP_MAX_TILES && (int64_t)n_t16 * 2 * sp_ns <= ctx->num_cu;
     if (!ctx->opt.lstm_split || ctx->opt.lstm_rows || ctx->opt.shared_device) split = false;
     LstmSplitArgs se;
     const unsigned split_grid = (unsigned)(((n_t16 + 3) / 4) * 8 * sp_ns);
@@ -1349,48 +1292,6 @@ static int p1_forward_launch(pv_ctx* ctx, const int8_t* d_images, int64_t B, flo
         pv_prof_scope ps(ctx, "k_lstm_layer_enc", st);
         if (tr == 32) k_lstm_layer<32, true, 32><<<lstm_grid, 512, lds_lstm<32, 32>(), st>>>(e);
         else k_lstm_layer<32, true, 16><<<lstm_grid, 512, lds_lstm<32, 16>(), st>>>(e);
-    }
-    if (m->dtype == PV_DTYPE_BF16_INPUT_GEMM) {
-        // decoder: G = enc_out . W_ih^T + b on the bf16 MFMA (3-term split), then the fp32 recurrence on G
-        const int64_t Bp = (int64_t)n_tiles * ROWS, M = Bp * T_STEPS;
-        float* G = nullptr;
-        int rc2 = pv_get(ctx, "p1.G", (size_t)M * 2048, &G);
-        if (rc2) return rc2;
-        auto gemm_grid = [&](int items) { return (unsigned)(std::min((items + 7) / 8 * 8, (ctx->num_cu + 7) / 8 * 8)); };
-        GemmArgs ga;
-        ga.A = enc_split; ga.W = m->dec_wih_s; ga.bias = m->dec_bias_cat; ga.C = G;
-        ga.M = M; ga.N = 2048; ga.K = 2 * H; ga.splits = 1;
-        ga.tiles_m = (int)((M + 255) / 256); ga.tiles_n = 2048 / 256; ga.items = ga.tiles_m * ga.tiles_n; ga.c_quads = 1;
-        {
-            pv_prof_scope ps(ctx, "k_gemm_bf16x3_dec", st);
-            k_gemm_bf16x3<<<gemm_grid(ga.items), 512, LDS_GEMM, st>>>(ga);
-        }
-        RecArgs ra;
-        ra.G = G; ra.Bp = Bp; ra.wp = m->dec_wp[0]; ra.out = taps ? dec_out : nullptr; ra.out_split = dec_split; ra.n_tiles = n_tiles;
-        {
-            pv_prof_scope ps(ctx, "k_lstm_rec_g", st);
-            k_lstm_rec_g<<<rec_grid, 512, LDS_REC, st>>>(ra);
-        }
-        // linear_1 as a split-K bf16x3 GEMM into slabs [splits][Bp][512]: the smallest split factor (a divisor of the 528
-        // K steps of 32) whose work items fill the chip
-        GemmArgs gl;
-        gl.A = dec_split; gl.W = m->w1_s; gl.bias = nullptr; gl.C = part;
-        gl.M = Bp; gl.N = HEAD_N; gl.K = HEAD_K;
-        gl.tiles_m = (int)((Bp + 255) / 256); gl.tiles_n = HEAD_N / 256;
-        static const int divs[] = {1, 2, 3, 4, 6, 8, 11, 12, 16, 22, 24, 33};
-        int gs = 33;
-        for (int dv : divs) if (gl.tiles_m * gl.tiles_n * dv >= ctx->num_cu) { gs = dv; break; }
-        gl.splits = gs; gl.items = gl.tiles_m * gl.tiles_n * gs; gl.c_quads = 0;
-        {
-            pv_prof_scope ps(ctx, "k_gemm_bf16x3_lin1", st);
-            k_gemm_bf16x3<<<gemm_grid(gl.items), 512, LDS_GEMM, st>>>(gl);
-        }
-        TailArgs tb;
-        tb.part = part; tb.b1 = m->b1; tb.splits = gs; tb.part_rows = Bp;
-        tb.wo = m->wo; tb.bo = m->bo; tb.probs = d_probs; tb.B = B; tb.epoch = m->sp_epoch; tb.err = m->sp_err;
-        launch_tail(ctx, m, tb, n_tiles, st);
-        PV_HIP(hipGetLastError());
-        return PV_OK;
     }
     LstmArgs d = e;
     d.x_i8 = nullptr; d.x_f32 = enc_out; d.wp = m->dec_wp[f]; d.bias = m->dec_bias; d.out = dec_out;
@@ -1426,7 +1327,7 @@ static int p1_forward_launch(pv_ctx* ctx, const int8_t* d_images, int64_t B, flo
 
 static int p1_workspace(pv_ctx* ctx, int64_t B, float** enc, float** dec, float** part) {
     int rc;
-    const size_t Bp = (size_t)((B + ROWS - 1) / ROWS) * ROWS;  // LSTM kernels store whole 32-row tiles
+    const size_t Bp = (size_t)((B + 2 * ROWS - 1) / (2 * ROWS)) * 2 * ROWS;  // layer kernels store whole tiles (32 rows; 64 in the bf16x3 mode)
     if ((rc = pv_get(ctx, "p1.enc_out", Bp * T_STEPS * 2 * H, enc))) return rc;
     if ((rc = pv_get(ctx, "p1.dec_out", Bp * T_STEPS * 2 * H, dec))) return rc;
     if ((rc = pv_get(ctx, "p1.part", (size_t)HEAD_MAX_SPLITS * Bp * HEAD_N, part))) return rc;
@@ -1439,8 +1340,8 @@ extern "C" int pv_rnn_forward_p1_dev(pv_ctx* ctx, const int8_t* d_images, int64_
     PV_CHECK(B >= 0 && B < (1ll << 24), PV_ERR_INVALID, "batch %lld out of range", (long long)B);
     if (B == 0) return PV_OK;
     PV_HIP(hipSetDevice(ctx->device));
-    // the bf16x3 mode addresses its time-major split8 rows and the G quads with 32-bit scalar offsets (33 x Bp x 2 KB and
-    // 33 x Bp x 8 KB): larger batches run as chunks of P1_BF16_MAX_BATCH windows on the same stream
+    // the bf16x3 mode materialises the decoder's input projections (33 x 8 KB per window: 4.4 GB at 16384 windows): larger
+    // batches run as chunks of P1_BF16_MAX_BATCH windows on the same stream
     const int64_t chunk = ctx->p1->dtype == PV_DTYPE_BF16_INPUT_GEMM ? P1_BF16_MAX_BATCH : B;
     float *enc, *dec, *part;
     int rc = p1_workspace(ctx, std::min(B, chunk), &enc, &dec, &part);
@@ -1513,6 +1414,28 @@ extern "C" int pv_rnn_exchange_timeouts(pv_ctx* ctx) {
 
 extern "C" int pv_rnn_forward_p1(pv_ctx* ctx, const int8_t* images, int64_t B, float* probs) {
     return pv_rnn_forward_p1_debug(ctx, images, B, probs, nullptr, nullptr);
+}
+
+int pv_gemm_bf16x3_prepare() {
+    PV_HIP(hipFuncSetAttribute((const void*)k_gemm_bf16x3, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_GEMM));
+    return PV_OK;
+}
+
+int pv_upload_split8(const float* w, size_t N, size_t K, unsigned char** d_split, std::vector<void*>& owned) {
+    return dev_upload_split(w, N, K, d_split, owned);
+}
+
+int pv_gemm_bf16x3_async(pv_ctx* ctx, const pv_gemm_desc& d, hipStream_t st) {
+    PV_CHECK(d.A && d.W && d.C && d.M > 0 && d.M % 4 == 0 && d.N % 256 == 0 && d.splits >= 1 && d.K % (32 * d.splits) == 0 &&
+                 (!d.quads || d.splits == 1), PV_ERR_INVALID, "bad GEMM shape");
+    GemmArgs g;
+    g.A = d.A; g.W = d.W; g.bias = d.bias; g.C = d.C; g.M = d.M; g.N = d.N; g.K = d.K; g.splits = d.splits;
+    g.tiles_m = (int)((d.M + 255) / 256); g.tiles_n = d.N / 256; g.items = g.tiles_m * g.tiles_n * d.splits; g.c_quads = d.quads;
+    const unsigned grid = (unsigned)(std::min((g.items + 7) / 8 * 8, (ctx->num_cu + 7) / 8 * 8));
+    pv_prof_scope ps(ctx, d.prof_name ? d.prof_name : "k_gemm_bf16x3", st);
+    k_gemm_bf16x3<<<grid, 512, LDS_GEMM, st>>>(g);
+    PV_HIP(hipGetLastError());
+    return PV_OK;
 }
 
 // Diagnostic entry (tests, tuning): C = A . W^T + bias through k_gemm_bf16x3 alone. HOST pointers, fp32 row-major A [M,K],

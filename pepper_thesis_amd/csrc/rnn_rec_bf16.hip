@@ -1,0 +1,574 @@
+// rnn_rec_bf16.hip — recurrent layers of PV_DTYPE_BF16_INPUT_GEMM on the bf16 MFMA (gfx950), and the layer-wise P2 path.
+//
+// k_rec_bf16<NG, ENC, MT>: one bidirectional recurrent layer, NG = 4 LSTM (P1: pepper_variant/modules/python/models/
+// simple_model.py:23-32,50-54; hidden 256) or NG = 3 GRU (P2: pepper/modules/python/models/simple_model.py:12-21,27-42; hidden
+// 128). Workgroup = (batch tile of 32 * MT rows, direction), wave w owns hidden units [32w, 32w + 32) of every gate, so the
+// cell update is in-register. Per time step
+//     gates = G_t (input projection, pre-computed by k_gemm_bf16x3; biases folded in)          [ENC = false]
+//           = bias + x_t . W_ih^T with x_t bytes, exact in bf16: two terms x.w_hi + x.w_lo        [ENC = true]
+//           + h_{t-1} . W_hh^T as three terms h_hi.w_hi + h_hi.w_lo + h_lo.w_hi on v_mfma_f32_32x32x16_bf16, fp32 accumulate
+// h lives in LDS as "split8" rows (per 8 units: 8 bf16 hi, 8 bf16 lo), double-buffered, one barrier per step; a 16-byte half
+// of a group is exactly one A fragment. W_hh (and the LSTM encoder's W_ih) are pre-split on the host into B-fragment order and
+// streamed from L2 through a ring of D register sets requested D - 1 (gate, k-step) slots ahead, wrapping into the next step.
+// At 4 bytes per weight the stream is what bounds a step (1 MB per LSTM step and workgroup against 12 k MFMA cycles for 32
+// rows), hence MT = 2: 64 rows per weight fetch. The projections G arrive as quads [m / 4][column][4] whose four values are
+// the accumulator registers 4q .. 4q+3 of a lane: they are loaded straight INTO the accumulators at the end of the previous
+// step, so the MFMAs simply continue from them.
+#include "rnn_bf16.hpp"
+#include "mfma_tiles.hpp"
+
+#include <algorithm>
+#include <cstdlib>
+
+namespace {
+
+using namespace pvdev;
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ float rcpf_(float x) { return __builtin_amdgcn_rcpf(x); }
+__device__ __forceinline__ float sigmoidf_(float x) { return rcpf_(1.0f + __expf(-x)); }
+__device__ __forceinline__ float tanhf_(float x) {
+    const float e = __expf(2.0f * x);
+    return 1.0f - 2.0f * rcpf_(e + 1.0f);
+}
+__device__ __forceinline__ unsigned split8_off(unsigned k) { return (k >> 3) * 32u + (k & 7u) * 2u; }
+
+template <int NG, bool ENC, int MT = 1> struct RecCfg {
+    static constexpr int HID = NG == 4 ? 256 : 128;
+    static constexpr int NW = HID / 32, NTHR = 64 * NW;
+    static constexpr int KS_H = HID / 16;                       // k-steps (K = 16) of the recurrent product
+    static constexpr int XK = ENC ? (NG == 4 ? 32 : 16) : 0;    // padded input features (26 -> 32, 10 -> 16)
+    static constexpr int KS_X = XK / 16;
+    static constexpr bool XRES = ENC && NG == 3;                // GRU encoder: the x-part fragments (one k-step) stay in registers
+    static constexpr int NSLOT = (XRES ? 0 : KS_X * NG) + KS_H * NG;   // (gate, k-step) slots of the weight stream per step
+    // ring depth (NSLOT % D == 0): 8 register sets where they fit; 4 for the 64-row LSTM forms (128 accumulator + 32 state
+    // registers of 256) and the GRU encoder (its x-part fragments stay resident)
+    static constexpr int D = ((NG == 3 && ENC) || (NG == 4 && MT == 2)) ? 4 : 8;
+    static constexpr int NA = NG + ((NG == 3 && ENC) ? 1 : 0);  // accumulators per M-tile (GRU keeps the n gate's x-part apart)
+    static constexpr int HS = HID * 4 + 16;                     // LDS row stride of the split8 h tile: (HS / 4) % 64 == 4
+    static constexpr int XS = XK * 2 + 16;                      // LDS row stride of the bf16 x tile
+    static_assert(NSLOT % D == 0, "ring depth must divide the stream length");
+};
+
+struct RecArgs {
+    const float* G;
+    const unsigned char* wp;
+    const unsigned char* wx;
+    const float* bias;
+    const float* bias_hn;
+    const unsigned char* x;
+    int64_t x_row_bytes;
+    int x_t0, xf, x_signed;
+    int64_t B, Bp;
+    int T;
+    const float* h0;
+    float* h_out;
+    float* out_f32;
+    unsigned char* out_tm;
+    unsigned char* out_bm;
+    float* out_f32_tm;
+    int n_tiles;
+};
+
+// slots [I0, I0 + NKS * NG) of a stream of NTOT slots: slot = (k-step, gate) = [hi fragments | lo fragments] of 1 KB each.
+// At = this lane's A-fragment address of M-tile 0, k-step 0; XP: x-part (plain bf16 rows, exact operand, two terms).
+template <int NG, int MT, int NA, int D, int NTOT, int I0, int NKS, bool XP>
+__device__ __forceinline__ void ring_bf16(f32x16 (&acc)[MT][NA], const unsigned char* __restrict__ At, int m_stride,
+                                          __amdgpu_buffer_rsrc_t wr, f32x4 (&bq)[D][2], unsigned lane16) {
+    constexpr int KSB = XP ? 32 : 64;   // bytes of one k-step inside an A row
+    bf16x8 ah[MT], al[MT];
+#pragma unroll
+    for (int i = 0; i < NKS * NG; i++) {
+        {   // request slot i + D - 1 (wrapping into the next step's first slots: same weights every step)
+            const int sv = (I0 + i + D - 1) % NTOT, rs = (I0 + i + D - 1) % D;
+            bq[rs][0] = buf_load4(wr, lane16, (unsigned)(sv * 2048));
+            bq[rs][1] = buf_load4(wr, lane16, (unsigned)(sv * 2048 + 1024));
+        }
+        const int ks = i / NG, g = i % NG;
+        if (g == 0) {
+#pragma unroll
+            for (int m = 0; m < MT; m++) {
+                ah[m] = *reinterpret_cast<const bf16x8*>(At + m * m_stride + ks * KSB);
+                if (!XP) al[m] = *reinterpret_cast<const bf16x8*>(At + m * m_stride + ks * KSB + 16);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);   // keep hipcc from sinking the prefetches next to their uses
+        {
+            const int ai = (XP && NG == 3 && g == 2) ? 3 : g;
+            const int rs = (I0 + i) % D;
+            const bf16x8 bh = __builtin_bit_cast(bf16x8, bq[rs][0]), bl = __builtin_bit_cast(bf16x8, bq[rs][1]);
+#pragma unroll
+            for (int m = 0; m < MT; m++) {
+                acc[m][ai] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[m], bh, acc[m][ai], 0, 0, 0);
+                acc[m][ai] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[m], bl, acc[m][ai], 0, 0, 0);
+                if (!XP) acc[m][ai] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[m], bh, acc[m][ai], 0, 0, 0);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+template <int NG, bool ENC, int MT>
+__global__ __launch_bounds__(NG == 4 ? 512 : 256, 1) void k_rec_bf16(RecArgs a) {
+    typedef RecCfg<NG, ENC, MT> C;
+    constexpr int HID = C::HID, NW = C::NW, NTHR = C::NTHR, ROWS = 32 * MT, HS = C::HS, XS = C::XS, D = C::D, NA = C::NA;
+    constexpr int NSLOT = C::NSLOT, NXS = C::XRES ? 0 : C::KS_X * NG;   // x slots at the head of the stream
+    constexpr int NCOL = 2 * NG * HID;                                  // columns of a G row
+    extern __shared__ __attribute__((aligned(16))) unsigned char sm[];
+    unsigned char* hbuf = sm;                    // [2][ROWS][HS]
+    unsigned char* xbuf = sm + 2 * ROWS * HS;    // [2][ROWS][XS]   (ENC)
+    const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // XCD-aware mapping (blocks b and b + 8 share an XCD): one direction per XCD, so its L2 holds one direction's weights
+    const int xcd = blockIdx.x & 7;
+    const int dir = xcd & 1;
+    const int tile = (blockIdx.x >> 3) * 4 + (xcd >> 1);
+    if (tile >= a.n_tiles) return;
+    const int64_t b0 = (int64_t)tile * ROWS;
+    const int unit = 32 * wv + (lane & 31), rg = lane >> 5;
+    const int T = a.T;
+    const __amdgpu_buffer_rsrc_t wr = make_rsrc(a.wp + (size_t)(dir * NW + wv) * NSLOT * 2048);
+    const unsigned lane16 = (unsigned)lane * 16u;
+    f32x4 bq[D][2];
+#pragma unroll
+    for (int k = 0; k < D - 1; k++) {
+        bq[k][0] = buf_load4(wr, lane16, (unsigned)(k * 2048));
+        bq[k][1] = buf_load4(wr, lane16, (unsigned)(k * 2048 + 1024));
+    }
+    // GRU encoder: resident x-part fragments [dir][wave][gate][hi, lo][lane][16 B]
+    bf16x8 xw[C::XRES ? 3 : 1][2];
+    if constexpr (C::XRES) {
+        const __amdgpu_buffer_rsrc_t xr = make_rsrc(a.wx + (size_t)(dir * NW + wv) * 3 * 2048);
+#pragma unroll
+        for (int g = 0; g < 3; g++) {
+            xw[g][0] = __builtin_bit_cast(bf16x8, buf_load4(xr, lane16, (unsigned)(g * 2048)));
+            xw[g][1] = __builtin_bit_cast(bf16x8, buf_load4(xr, lane16, (unsigned)(g * 2048 + 1024)));
+        }
+    }
+    float bs[NA];   // ENC: gate biases of this lane's unit; GRU (both): index NG - 1 ... see below
+    float b_hn = 0.0f;
+    if constexpr (ENC) {
+#pragma unroll
+        for (int g = 0; g < NG; g++) bs[g] = a.bias[dir * NG * HID + g * HID + unit];
+    }
+    if constexpr (NG == 3) b_hn = a.bias_hn[dir * HID + unit];
+
+    // ---- state: c (LSTM) / h (GRU) of this lane's elements; h_{t-1} as split8 rows in LDS --------------------------------
+    float st[MT][16];
+    for (int i = tid; i < ROWS * HS / 16; i += NTHR) reinterpret_cast<u32x4*>(hbuf)[i] = u32x4{0u, 0u, 0u, 0u};
+#pragma unroll
+    for (int m = 0; m < MT; m++)
+#pragma unroll
+        for (int e = 0; e < 16; e++) st[m][e] = 0.0f;
+    const unsigned hl = (unsigned)(4 * rg * HS) + split8_off((unsigned)unit);   // lane part of an h element's LDS offset
+    __syncthreads();
+    if (NG == 3 && a.h0) {
+#pragma unroll
+        for (int m = 0; m < MT; m++)
+#pragma unroll
+            for (int e = 0; e < 16; e++) {
+                const int row = 32 * m + 8 * (e >> 2) + (e & 3) + 4 * rg;
+                const float h = a.h0[((b0 + row) * 2 + dir) * HID + unit];
+                st[m][e] = h;
+                const __bf16 hi = (__bf16)h;
+                const __bf16 lo = (__bf16)(h - (float)hi);
+                unsigned char* p = hbuf + (32 * m + 8 * (e >> 2) + (e & 3)) * HS + hl;
+                *reinterpret_cast<__bf16*>(p) = hi;
+                *reinterpret_cast<__bf16*>(p + 16) = lo;
+            }
+    }
+
+    // ---- x staging (ENC): bytes -> bf16 rows [ROWS][XK]; thread = (row, group of 4 features) ------------------------------
+    constexpr int FG = ENC ? C::XK / 4 : 1;
+    const int xrow = tid / FG, xfg = tid % FG;
+    const bool x_on = ENC && xrow < ROWS;
+    const unsigned char* xsrc = nullptr;
+    unsigned xv[4] = {0u, 0u, 0u, 0u};
+    if constexpr (ENC) {
+        int64_t r = b0 + xrow;
+        if (r >= a.B) r = a.B - 1;   // rows beyond B replicate row B-1 (finite values, never handed to the caller)
+        xsrc = a.x + r * a.x_row_bytes + (int64_t)a.x_t0 * a.xf;
+    }
+    auto x_load = [&](int t) {
+        if constexpr (ENC) {
+            if (x_on) {
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    const int f = 4 * xfg + j;
+                    xv[j] = f < a.xf ? (unsigned)xsrc[(int64_t)t * a.xf + f] : 0u;
+                }
+            }
+        }
+    };
+    auto x_store = [&](int slot) {
+        if constexpr (ENC) {
+            if (x_on) {
+                bf16x4 v;
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    const float f = a.x_signed ? (float)(int)(signed char)xv[j] : (float)xv[j];   // |f| <= 255: exact in bf16
+                    v[j] = (__bf16)f;
+                }
+                *reinterpret_cast<bf16x4*>(xbuf + (slot * ROWS + xrow) * XS + xfg * 8) = v;
+            }
+        }
+    };
+
+    // ---- accumulators -------------------------------------------------------------------------------------------------------
+    f32x16 acc[MT][NA];
+    f32x4 gn[(NG == 3 && !ENC) ? MT : 1][4];   // GRU decoder: the n gate's input projection, kept apart from W_hn h
+    const unsigned gl = (unsigned)((rg * NCOL + (lane & 31)) * 16);   // lane part of a G quad's byte offset
+    auto acc_init = [&](int t) {
+        if constexpr (ENC) {
+#pragma unroll
+            for (int m = 0; m < MT; m++) {
+#pragma unroll
+                for (int g = 0; g < NG; g++)
+#pragma unroll
+                    for (int e = 0; e < 16; e++) acc[m][(NG == 3 && g == 2) ? 3 : g][e] = bs[g];
+                if constexpr (NG == 3)
+#pragma unroll
+                    for (int e = 0; e < 16; e++) acc[m][2][e] = b_hn;
+            }
+        } else {
+            // quad row (t * Bp + b0) / 4 + 8m + 2q + rg, column dir * NG * HID + g * HID + unit: a per-step resource keeps the
+            // offsets inside the tile's 32 * MT rows (33 x 8192 rows x 8 KB would not fit 32 bits)
+            const __amdgpu_buffer_rsrc_t gsr = make_rsrc(a.G + ((size_t)t * a.Bp + b0) * NCOL);
+#pragma unroll
+            for (int m = 0; m < MT; m++)
+#pragma unroll
+                for (int g = 0; g < NG; g++)
+#pragma unroll
+                    for (int q = 0; q < 4; q++) {
+                        const f32x4 v = buf_load4_nt(gsr, gl, (unsigned)(((8 * m + 2 * q) * NCOL + dir * NG * HID + g * HID + 32 * wv) * 16));
+                        if (NG == 3 && g == 2) {
+                            gn[m][q] = v;
+                        } else {
+#pragma unroll
+                            for (int j = 0; j < 4; j++) acc[m][g][4 * q + j] = v[j];
+                        }
+                    }
+            if constexpr (NG == 3)
+#pragma unroll
+                for (int m = 0; m < MT; m++)
+#pragma unroll
+                    for (int e = 0; e < 16; e++) acc[m][2][e] = b_hn;
+        }
+    };
+
+    x_load(dir ? T - 1 : 0);
+    x_store(0);
+    acc_init(dir ? T - 1 : 0);
+    __syncthreads();
+
+    const unsigned char* a_h = hbuf + (lane & 31) * HS + rg * 32;    // + cur * ROWS * HS
+    const unsigned char* a_x = xbuf + (lane & 31) * XS + rg * 16;    // + slot * ROWS * XS
+    const unsigned rowb_tm = 2u * HID * 4u;                          // bytes of a time-major output row
+    const unsigned rowb_bm = (unsigned)T * 2u * HID * 4u;            // bytes of a batch-major output row
+    const unsigned o_tm_l = (unsigned)(4 * rg) * rowb_tm + split8_off((unsigned)unit);
+    const unsigned o_bm_l = (unsigned)(4 * rg) * rowb_bm + split8_off((unsigned)unit);
+    const unsigned o_f_l = (unsigned)(4 * rg) * rowb_bm + (unsigned)unit * 4u;
+    const unsigned o_ft_l = (unsigned)(4 * rg) * rowb_tm + (unsigned)unit * 4u;
+    const __amdgpu_buffer_rsrc_t bmr = make_rsrc(a.out_bm + (size_t)b0 * rowb_bm);
+    const __amdgpu_buffer_rsrc_t ofr = make_rsrc(reinterpret_cast<unsigned char*>(a.out_f32) + (size_t)b0 * rowb_bm);
+    int cur = 0;
+    for (int s = 0; s < T; s++) {
+        const int t = dir ? (T - 1 - s) : s;
+        const int tn = dir ? (T - 2 - s) : (s + 1);
+        if (s + 1 < T) x_load(tn);
+        // ---- x-part (ENC) -------------------------------------------------------------------------------------------------
+        if constexpr (C::XRES) {
+            bf16x8 ax[MT];
+#pragma unroll
+            for (int m = 0; m < MT; m++) ax[m] = *reinterpret_cast<const bf16x8*>(a_x + ((s & 1) * ROWS + 32 * m) * XS);
+#pragma unroll
+            for (int g = 0; g < 3; g++)
+#pragma unroll
+                for (int m = 0; m < MT; m++) {
+                    const int ai = g == 2 ? 3 : g;
+                    acc[m][ai] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ax[m], xw[g][0], acc[m][ai], 0, 0, 0);
+                    acc[m][ai] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ax[m], xw[g][1], acc[m][ai], 0, 0, 0);
+                }
+        } else if constexpr (ENC) {
+            ring_bf16<NG, MT, NA, D, NSLOT, 0, C::KS_X, true>(acc, a_x + (s & 1) * ROWS * XS, 32 * XS, wr, bq, lane16);
+        }
+        // ---- h-part: h_{t-1} . W_hh^T, three terms ----------------------------------------------------------------------------
+        ring_bf16<NG, MT, NA, D, NSLOT, NXS, C::KS_H, false>(acc, a_h + cur * ROWS * HS, 32 * HS, wr, bq, lane16);
+        // ---- cell update --------------------------------------------------------------------------------------------------------
+        unsigned char* hn = hbuf + (cur ^ 1) * ROWS * HS;
+        const __amdgpu_buffer_rsrc_t tmr = make_rsrc(a.out_tm + ((size_t)t * a.Bp + b0) * rowb_tm);
+        const __amdgpu_buffer_rsrc_t ftr = make_rsrc(reinterpret_cast<unsigned char*>(a.out_f32_tm) + ((size_t)t * a.Bp + b0) * rowb_tm);
+#pragma unroll
+        for (int m = 0; m < MT; m++)
+#pragma unroll
+            for (int e = 0; e < 16; e++) {
+                float h;
+                if constexpr (NG == 4) {   // PyTorch LSTM gate order i, f, g, o
+                    const float ig = sigmoidf_(acc[m][0][e]);
+                    const float fg = sigmoidf_(acc[m][1][e]);
+                    const float gg = tanhf_(acc[m][2][e]);
+                    const float og = sigmoidf_(acc[m][3][e]);
+                    const float c = fg * st[m][e] + ig * gg;
+                    st[m][e] = c;
+                    h = og * tanhf_(c);
+                } else {                   // PyTorch GRU: n = tanh(W_in x + b_in + r * (W_hn h + b_hn)), h' = (1 - z) n + z h
+                    const float r = sigmoidf_(acc[m][0][e]);
+                    const float z = sigmoidf_(acc[m][1][e]);
+                    const float xn = ENC ? acc[m][NA - 1][e] : gn[ENC ? 0 : m][e >> 2][e & 3];
+                    const float n = tanhf_(xn + r * acc[m][2][e]);
+                    h = (1.0f - z) * n + z * st[m][e];
+                    st[m][e] = h;
+                }
+                const int row = 32 * m + 8 * (e >> 2) + (e & 3);   // + 4 * rg (lane part)
+                const __bf16 hi = (__bf16)h;
+                const __bf16 lo = (__bf16)(h - (float)hi);
+                *reinterpret_cast<__bf16*>(hn + row * HS + hl) = hi;
+                *reinterpret_cast<__bf16*>(hn + row * HS + hl + 16) = lo;
+                const unsigned short hb = __builtin_bit_cast(unsigned short, hi), lb = __builtin_bit_cast(unsigned short, lo);
+                if (a.out_tm) {
+                    const unsigned so = (unsigned)row * rowb_tm + (unsigned)(dir * HID * 4);
+                    __builtin_amdgcn_raw_buffer_store_b16(hb, tmr, o_tm_l, so, 0);
+                    __builtin_amdgcn_raw_buffer_store_b16(lb, tmr, o_tm_l, so + 16u, 0);
+                }
+                if (a.out_bm) {
+                    const unsigned so = (unsigned)row * rowb_bm + (unsigned)((t * 2 + dir) * HID * 4);
+                    __builtin_amdgcn_raw_buffer_store_b16(hb, bmr, o_bm_l, so, 0);
+                    __builtin_amdgcn_raw_buffer_store_b16(lb, bmr, o_bm_l, so + 16u, 0);
+                }
+                if (a.out_f32) buf_store1_nt(h, ofr, o_f_l, (unsigned)row * rowb_bm + (unsigned)((t * 2 + dir) * HID * 4));
+                if (a.out_f32_tm) buf_store1_nt(h, ftr, o_ft_l, (unsigned)row * rowb_tm + (unsigned)(dir * HID * 4));
+            }
+        if (s + 1 < T) {
+            acc_init(tn);     // the next step's projections travel into the accumulators during the barrier and the ring's wrap
+            x_store((s + 1) & 1);
+        }
+        cur ^= 1;
+        lds_barrier();        // h_t (and x_{t+1}) complete; LDS only: the weight ring and the output stores stay in flight
+    }
+    if (NG == 3 && a.h_out) {
+#pragma unroll
+        for (int m = 0; m < MT; m++)
+#pragma unroll
+            for (int e = 0; e < 16; e++) {
+                const int row = 32 * m + 8 * (e >> 2) + (e & 3) + 4 * rg;
+                a.h_out[((b0 + row) * 2 + dir) * HID + unit] = st[m][e];
+            }
+    }
+}
+
+template <int NG, bool ENC, int MT> constexpr size_t lds_rec() {
+    typedef RecCfg<NG, ENC> C;
+    return (size_t)2 * 32 * MT * C::HS + (ENC ? (size_t)2 * 32 * MT * C::XS : 0);
+}
+
+static inline uint16_t f2bf_bits(float x) {  // round to nearest even
+    uint32_t u;
+    memcpy(&u, &x, 4);
+    return (uint16_t)((u + 0x7FFFu + ((u >> 16) & 1u)) >> 16);
+}
+static inline float bf_bits2f(uint16_t h) {
+    const uint32_t u = (uint32_t)h << 16;
+    float f;
+    memcpy(&f, &u, 4);
+    return f;
+}
+
+}  // namespace
+
+// Fragment stream of one (direction, wave): slots [x-part k-steps x gates | h-part k-steps x gates]; a slot is 1 KB of hi
+// fragments followed by 1 KB of lo fragments; lane -> weight row gate * HID + 32 * wave + (lane & 31), 8 consecutive K values
+// 16 * ks + 8 * (lane >> 5) + j (the B operand of v_mfma_f32_32x32x16_bf16). GRU encoder: the x-part goes to a stream of its own.
+int pv_pack_rec_bf16(const pv_rnn_dir* dirs, int cell, int kx, unsigned char** d_wp, unsigned char** d_wx, std::vector<void*>& owned) {
+    const int NG = cell, HID = cell == 4 ? 256 : 128, NW = HID / 32, KS_H = HID / 16;
+    const int KS_X = kx ? (cell == 4 ? 2 : 1) : 0;
+    const bool xres = kx && cell == 3;
+    const int nslot = (xres ? 0 : KS_X * NG) + KS_H * NG;
+    std::vector<uint16_t> wp((size_t)2 * NW * nslot * 1024), wx(xres ? (size_t)2 * NW * NG * 1024 : 0);
+    for (int d = 0; d < 2; d++)
+        for (int w = 0; w < NW; w++) {
+            auto fill = [&](uint16_t* dst, bool xpart, int ks, int g) {
+                for (int lane = 0; lane < 64; lane++)
+                    for (int j = 0; j < 8; j++) {
+                        const int n = g * HID + 32 * w + (lane & 31), k = 16 * ks + 8 * (lane >> 5) + j;
+                        float v;
+                        if (xpart) v = k < kx ? dirs[d].w_ih[(size_t)n * kx + k] : 0.0f;
+                        else v = dirs[d].w_hh[(size_t)n * HID + k];
+                        const uint16_t hi = f2bf_bits(v);
+                        dst[lane * 8 + j] = hi;
+                        dst[512 + lane * 8 + j] = f2bf_bits(v - bf_bits2f(hi));
+                    }
+            };
+            uint16_t* base = wp.data() + (size_t)(d * NW + w) * nslot * 1024;
+            int slot = 0;
+            if (!xres)
+                for (int ks = 0; ks < KS_X; ks++)
+                    for (int g = 0; g < NG; g++) fill(base + (size_t)(slot++) * 1024, true, ks, g);
+            for (int ks = 0; ks < KS_H; ks++)
+                for (int g = 0; g < NG; g++) fill(base + (size_t)(slot++) * 1024, false, ks, g);
+            if (xres)
+                for (int g = 0; g < NG; g++) fill(wx.data() + ((size_t)(d * NW + w) * NG + g) * 1024, true, 0, g);
+        }
+    PV_HIP(hipMalloc((void**)d_wp, wp.size() * 2));
+    owned.push_back(*d_wp);
+    PV_HIP(hipMemcpy(*d_wp, wp.data(), wp.size() * 2, hipMemcpyHostToDevice));
+    if (d_wx) *d_wx = nullptr;
+    if (xres) {
+        PV_HIP(hipMalloc((void**)d_wx, wx.size() * 2));
+        owned.push_back(*d_wx);
+        PV_HIP(hipMemcpy(*d_wx, wx.data(), wx.size() * 2, hipMemcpyHostToDevice));
+    }
+    return PV_OK;
+}
+
+int pv_rec_bf16_prepare() {
+#define PV_REC_ATTR(NG, ENC, MT) \
+    PV_HIP(hipFuncSetAttribute((const void*)k_rec_bf16<NG, ENC, MT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_rec<NG, ENC, MT>()))
+    PV_REC_ATTR(4, true, 1); PV_REC_ATTR(4, true, 2); PV_REC_ATTR(4, false, 1); PV_REC_ATTR(4, false, 2);
+    PV_REC_ATTR(3, true, 1); PV_REC_ATTR(3, true, 2); PV_REC_ATTR(3, false, 1); PV_REC_ATTR(3, false, 2);
+#undef PV_REC_ATTR
+    return PV_OK;
+}
+
+int pv_rec_bf16_async(pv_ctx* ctx, const pv_rec_desc& d, hipStream_t st) {
+    PV_CHECK((d.cell == 3 || d.cell == 4) && (d.mt == 1 || d.mt == 2) && d.T > 0 && d.Bp % (32 * d.mt) == 0, PV_ERR_INVALID, "bad recurrent-layer launch");
+    RecArgs a;
+    a.G = d.G; a.wp = d.wp; a.wx = d.wx; a.bias = d.bias; a.bias_hn = d.bias_hn; a.x = (const unsigned char*)d.x;
+    a.x_row_bytes = d.x_row_bytes; a.x_t0 = d.x_t0; a.xf = d.xf; a.x_signed = d.x_signed; a.B = d.B; a.Bp = d.Bp; a.T = d.T;
+    a.h0 = d.h0; a.h_out = d.h_out; a.out_f32 = d.out_f32; a.out_tm = d.out_tm; a.out_bm = d.out_bm; a.out_f32_tm = d.out_f32_tm;
+    a.n_tiles = (int)(d.Bp / (32 * d.mt));
+    const unsigned grid = (unsigned)(((a.n_tiles + 3) / 4) * 8);
+    pv_prof_scope ps(ctx, d.prof_name, st);
+#define PV_REC_GO(NG, ENC, MT) k_rec_bf16<NG, ENC, MT><<<grid, RecCfg<NG, ENC>::NTHR, lds_rec<NG, ENC, MT>(), st>>>(a)
+    if (d.cell == 4) {
+        if (d.enc) { if (d.mt == 2) PV_REC_GO(4, true, 2); else PV_REC_GO(4, true, 1); }
+        else { if (d.mt == 2) PV_REC_GO(4, false, 2); else PV_REC_GO(4, false, 1); }
+    } else {
+        if (d.enc) { if (d.mt == 2) PV_REC_GO(3, true, 2); else PV_REC_GO(3, true, 1); }
+        else { if (d.mt == 2) PV_REC_GO(3, false, 2); else PV_REC_GO(3, false, 1); }
+    }
+#undef PV_REC_GO
+    PV_HIP(hipGetLastError());
+    return PV_OK;
+}
+
+// ---- P2 in PV_DTYPE_BF16_INPUT_GEMM: the sliding loop of pepper/modules/python/models/predict.py:47-97 layer by layer -------
+// Per 100-column window: encoder layer (k_rec_bf16<3, true>: x-part in the step, output as split8 rows = the A operand of)
+// the decoder's input projection as ONE GEMM over the window's 100 x B rows (k_gemm_bf16x3, N = 2 x 384, K = 256), the decoder
+// layer on those projections (k_rec_bf16<3, false>), dense1 + softmax + accumulate (k_p2_dense). The hidden state travels
+// between the launches in a [Bp][2][128] buffer: encoder h0 = carried state, decoder h0 = encoder final state, next window's
+// h0 = decoder final state (simple_model.py:27-42). 19 x 4 launches per call, all stream work (graph-capturable).
+namespace {
+constexpr int P2_WIN = 100, P2_JUMP = 50, P2_F = 10, P2_H = 128, P2_NC = 5;
+
+// dense1 (256 -> 5) + softmax + accumulate for one window: 8 lanes per (t, b) pair
+__global__ __launch_bounds__(256) void k_p2_dense(const float* __restrict__ dec /*[100][Bp][256]*/, int64_t Bp, int64_t B,
+                                                  const float* __restrict__ W, const float* __restrict__ bias, float* __restrict__ acc,
+                                                  int seq, int ws, float* __restrict__ logits) {
+    const int64_t pair = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 3;
+    const int sub = threadIdx.x & 7;
+    if (pair >= (int64_t)P2_WIN * B) return;   // whole groups of 8 lanes leave together
+    const int t = (int)(pair / B);
+    const int64_t b = pair - (int64_t)t * B;
+    const float* d = dec + ((size_t)t * Bp + b) * (2 * P2_H);
+    float lg[P2_NC] = {0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        const int k = 32 * i + 4 * sub;
+        const f32x4 v = *reinterpret_cast<const f32x4*>(d + k);
+#pragma unroll
+        for (int c = 0; c < P2_NC; c++) {
+            const f32x4 w = *reinterpret_cast<const f32x4*>(W + c * 2 * P2_H + k);
+            lg[c] += v[0] * w[0] + v[1] * w[1] + v[2] * w[2] + v[3] * w[3];
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < P2_NC; c++) {
+        lg[c] += __shfl_xor(lg[c], 4, 64);
+        lg[c] += __shfl_xor(lg[c], 2, 64);
+        lg[c] += __shfl_xor(lg[c], 1, 64);
+        lg[c] += bias[c];
+    }
+    if (sub != 0) return;
+    float m = lg[0];
+#pragma unroll
+    for (int c = 1; c < P2_NC; c++) m = fmaxf(m, lg[c]);
+    float e[P2_NC], sum = 0.0f;
+#pragma unroll
+    for (int c = 0; c < P2_NC; c++) { e[c] = expf(lg[c] - m); sum += e[c]; }
+    const float inv = 1.0f / sum;
+    float* ac = acc + ((size_t)b * seq + ws + t) * P2_NC;
+#pragma unroll
+    for (int c = 0; c < P2_NC; c++) ac[c] += e[c] * inv;
+    if (logits) {
+#pragma unroll
+        for (int c = 0; c < P2_NC; c++) logits[((size_t)b * P2_WIN + t) * P2_NC + c] = lg[c];
+    }
+}
+
+// labels = argmax of the accumulated softmax, first maximum wins (torch.max, predict.py:91)
+__global__ __launch_bounds__(256) void k_p2_argmax(const float* __restrict__ acc, int64_t n, uint8_t* __restrict__ labels) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float* ac = acc + i * P2_NC;
+    int best = 0;
+    float bv = ac[0];
+#pragma unroll
+    for (int c = 1; c < P2_NC; c++) if (ac[c] > bv) { bv = ac[c]; best = c; }
+    labels[i] = (uint8_t)best;
+}
+
+// state [Bp][2][128] <- hidden_in [B][2][128] (rows beyond B: zeros) or zeros;   hidden_out [B][2][128] <- state
+__global__ __launch_bounds__(256) void k_p2_state_in(float* __restrict__ state, const float* __restrict__ hin, int64_t B, int64_t Bp) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= Bp * 2 * P2_H) return;
+    state[i] = (hin && i < B * 2 * P2_H) ? hin[i] : 0.0f;
+}
+__global__ __launch_bounds__(256) void k_p2_state_out(const float* __restrict__ state, float* __restrict__ hout, int64_t B) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < B * 2 * P2_H) hout[i] = state[i];
+}
+}  // namespace
+
+int pv_p2_bf16_forward(pv_ctx* ctx, const pv_p2_bf16_weights& w, const uint8_t* d_images, int64_t B, uint8_t* d_labels, float* d_acc,
+                       hipStream_t st, int seq, int nwin, const float* d_hidden_in, float* d_hidden_out, float* d_logits) {
+    // 64-row tiles (one weight fetch feeds twice the rows) once 32-row (tile, direction) workgroups would need more than two
+    // rounds of the chip; below that 32-row tiles keep more CUs busy
+    const int mt = ((B + 31) / 32) * 2 > 2 * (int64_t)ctx->num_cu ? 2 : 1;
+    const int rows = 32 * mt;
+    const int64_t Bp = (B + rows - 1) / rows * rows, M = (int64_t)P2_WIN * Bp;
+    float *state = nullptr, *G = nullptr, *dec = nullptr;
+    unsigned char* enc_s = nullptr;
+    int rc;
+    if ((rc = pv_get(ctx, "p2b.state", (size_t)Bp * 2 * P2_H, &state))) return rc;
+    if ((rc = pv_get(ctx, "p2b.enc_s", (size_t)M * 2 * P2_H * 4, &enc_s))) return rc;
+    if ((rc = pv_get(ctx, "p2b.G", (size_t)M * 6 * P2_H, &G))) return rc;
+    if ((rc = pv_get(ctx, "p2b.dec", (size_t)M * 2 * P2_H, &dec))) return rc;
+    if ((rc = pv_zero_async(d_acc, (size_t)B * seq * P2_NC * sizeof(float), st))) return rc;
+    k_p2_state_in<<<(unsigned)((Bp * 2 * P2_H + 255) / 256), 256, 0, st>>>(state, d_hidden_in, B, Bp);
+    for (int wi = 0; wi < nwin; wi++) {
+        const int ws = wi * P2_JUMP;
+        pv_rec_desc e = {};
+        e.cell = 3; e.enc = 1; e.wp = w.enc_wp; e.wx = w.enc_wx; e.bias = w.enc_bias; e.bias_hn = w.enc_bias_hn;
+        e.x = d_images; e.x_row_bytes = (int64_t)seq * P2_F; e.x_t0 = ws; e.xf = P2_F; e.x_signed = 0;
+        e.B = B; e.Bp = Bp; e.T = P2_WIN; e.h0 = state; e.h_out = state; e.out_tm = enc_s; e.mt = mt; e.prof_name = "k_rec_bf16_gru_enc";
+        if ((rc = pv_rec_bf16_async(ctx, e, st))) return rc;
+        pv_gemm_desc g = {};
+        g.A = enc_s; g.W = w.dec_wih_s; g.bias = w.dec_bias_cat; g.C = G; g.M = M; g.N = 6 * P2_H; g.K = 2 * P2_H; g.splits = 1; g.quads = 1;
+        g.prof_name = "k_gemm_bf16x3_gru_dec";
+        if ((rc = pv_gemm_bf16x3_async(ctx, g, st))) return rc;
+        pv_rec_desc d = {};
+        d.cell = 3; d.enc = 0; d.G = G; d.wp = w.dec_wp; d.bias_hn = w.dec_bias_hn; d.B = B; d.Bp = Bp; d.T = P2_WIN;
+        d.h0 = state; d.h_out = state; d.out_f32_tm = dec; d.mt = mt; d.prof_name = "k_rec_bf16_gru_dec";
+        if ((rc = pv_rec_bf16_async(ctx, d, st))) return rc;
+        {
+            pv_prof_scope ps(ctx, "k_p2_dense", st);
+            const int64_t nthr = (int64_t)P2_WIN * B * 8;
+            k_p2_dense<<<(unsigned)((nthr + 255) / 256), 256, 0, st>>>(dec, Bp, B, w.dense_w, w.dense_b, d_acc, seq, ws,
+                                                                        (d_logits && wi == nwin - 1) ? d_logits : nullptr);
+        }
+    }
+    if (d_hidden_out) k_p2_state_out<<<(unsigned)((B * 2 * P2_H + 255) / 256), 256, 0, st>>>(state, d_hidden_out, B);
+    if (d_labels) k_p2_argmax<<<(unsigned)((B * seq + 255) / 256), 256, 0, st>>>(d_acc, B * seq, d_labels);
+    PV_HIP(hipGetLastError());
+    return PV_OK;
+}
