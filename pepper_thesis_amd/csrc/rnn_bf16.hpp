@@ -44,7 +44,6 @@ struct pv_rec_desc {
     float* out_f32;            // optional fp32 [Bp][T][2 * hidden]
     unsigned char* out_tm;     // optional split8, time-major [T][Bp][2 * hidden] (A operand of the next layer's GEMM)
     unsigned char* out_bm;     // optional split8, batch-major [Bp][T * 2 * hidden] (A operand of linear_1)
-    float* out_f32_tm;         // optional fp32 time-major [T][Bp][2 * hidden]
     int mt;                    // M-tiles of 32 rows per workgroup: 1 or 2
     const char* prof_name;
 };

@@ -41,6 +41,10 @@ template <int NG, bool ENC, int MT = 1> struct RecCfg {
     static constexpr int XK = ENC ? (NG == 4 ? 32 : 16) : 0;    // padded input features (26 -> 32, 10 -> 16)
     static constexpr int KS_X = XK / 16;
     static constexpr bool XRES = ENC && NG == 3;                // GRU encoder: the x-part fragments (one k-step) stay in registers
+    // GRU: W_hh of a direction is 196 KB of fragments = 192 registers per lane of its four waves (one wave per SIMD, 512
+    // registers each): the weights are loaded ONCE per launch and stay resident - a true persistent-RNN step with no weight
+    // stream at all (streamed, a 32-row step was bound by the 196 KB per step through the CU's 64 B/clk vector-memory path)
+    static constexpr bool WRES = NG == 3 && !(ENC && MT == 2);   // (the 64-row encoder form would spill: it streams)
     static constexpr int NSLOT = (XRES ? 0 : KS_X * NG) + KS_H * NG;   // (gate, k-step) slots of the weight stream per step
     // ring depth (NSLOT % D == 0): 8 register sets where they fit; 4 for the 64-row LSTM forms (128 accumulator + 32 state
     // registers of 256) and the GRU encoder (its x-part fragments stay resident)
@@ -67,7 +71,6 @@ struct RecArgs {
     float* out_f32;
     unsigned char* out_tm;
     unsigned char* out_bm;
-    float* out_f32_tm;
     int n_tiles;
 };
 
@@ -109,6 +112,17 @@ __device__ __forceinline__ void ring_bf16(f32x16 (&acc)[MT][NA], const unsigned 
     }
 }
 
+#ifndef PV_REC_ABL
+#define PV_REC_ABL 0   // diagnostic ablations (timing only, results wrong): 1 = no global output stores, 2 = no LDS h writes
+#endif
+#ifdef PV_REC_STAMPS
+// diagnostic build: cycle sums of the phases of a step (workgroup 0, every wave adds), read by pv_debug_rec_stamps
+__device__ unsigned long long g_rec_stamps[8];
+#define RSTAMP(i) { unsigned long long now_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(now_) :: "memory"); st_acc[i] += now_ - st_last; st_last = now_; }
+#else
+#define RSTAMP(i)
+#endif
+
 template <int NG, bool ENC, int MT>
 __global__ __launch_bounds__(NG == 4 ? 512 : 256, 1) void k_rec_bf16(RecArgs a) {
     typedef RecCfg<NG, ENC, MT> C;
@@ -129,11 +143,20 @@ __global__ __launch_bounds__(NG == 4 ? 512 : 256, 1) void k_rec_bf16(RecArgs a) 
     const int T = a.T;
     const __amdgpu_buffer_rsrc_t wr = make_rsrc(a.wp + (size_t)(dir * NW + wv) * NSLOT * 2048);
     const unsigned lane16 = (unsigned)lane * 16u;
-    f32x4 bq[D][2];
+    f32x4 bq[C::WRES ? 1 : D][2];
+    bf16x8 wres[C::WRES ? NSLOT : 1][2];
+    if constexpr (C::WRES) {
 #pragma unroll
-    for (int k = 0; k < D - 1; k++) {
-        bq[k][0] = buf_load4(wr, lane16, (unsigned)(k * 2048));
-        bq[k][1] = buf_load4(wr, lane16, (unsigned)(k * 2048 + 1024));
+        for (int k = 0; k < NSLOT; k++) {
+            wres[k][0] = __builtin_bit_cast(bf16x8, buf_load4(wr, lane16, (unsigned)(k * 2048)));
+            wres[k][1] = __builtin_bit_cast(bf16x8, buf_load4(wr, lane16, (unsigned)(k * 2048 + 1024)));
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < D - 1; k++) {
+            bq[k][0] = buf_load4(wr, lane16, (unsigned)(k * 2048));
+            bq[k][1] = buf_load4(wr, lane16, (unsigned)(k * 2048 + 1024));
+        }
     }
     // GRU encoder: resident x-part fragments [dir][wave][gate][hi, lo][lane][16 B]
     bf16x8 xw[C::XRES ? 3 : 1][2];
@@ -265,17 +288,41 @@ __global__ __launch_bounds__(NG == 4 ? 512 : 256, 1) void k_rec_bf16(RecArgs a) 
     const unsigned char* a_x = xbuf + (lane & 31) * XS + rg * 16;    // + slot * ROWS * XS
     const unsigned rowb_tm = 2u * HID * 4u;                          // bytes of a time-major output row
     const unsigned rowb_bm = (unsigned)T * 2u * HID * 4u;            // bytes of a batch-major output row
-    const unsigned o_tm_l = (unsigned)(4 * rg) * rowb_tm + split8_off((unsigned)unit);
-    const unsigned o_bm_l = (unsigned)(4 * rg) * rowb_bm + split8_off((unsigned)unit);
     const unsigned o_f_l = (unsigned)(4 * rg) * rowb_bm + (unsigned)unit * 4u;
-    const unsigned o_ft_l = (unsigned)(4 * rg) * rowb_tm + (unsigned)unit * 4u;
     const __amdgpu_buffer_rsrc_t bmr = make_rsrc(a.out_bm + (size_t)b0 * rowb_bm);
+    // The layer's outputs are split8 rows - the very layout of the h tile in LDS. Element-wise they were two 2-byte global
+    // stores per value (a third of a GRU step); instead the finished tile (stable for the whole next step: it is that step's
+    // A operand) is copied out with 16-byte loads / stores, a row of HID * 4 bytes per 2 * HID / 8 lanes.
+    constexpr int CPR = HID / 4, NCP = ROWS * CPR / NTHR;   // 16-byte chunks per row, chunks per thread
+    auto tile_out = [&](int tt, const unsigned char* tile) {
+        if (!a.out_tm && !a.out_bm) return;
+        const __amdgpu_buffer_rsrc_t tmr = make_rsrc(a.out_tm + ((size_t)tt * a.Bp + b0) * rowb_tm);
+#pragma unroll
+        for (int k = 0; k < NCP; k++) {
+            const int c = tid + k * NTHR, row = c / CPR, col = c % CPR;
+            const u32x4 v = *reinterpret_cast<const u32x4*>(tile + row * HS + col * 16);
+            if (a.out_tm)
+                __builtin_amdgcn_raw_buffer_store_b128(v, tmr, (unsigned)(row * (int)rowb_tm + col * 16), (unsigned)(dir * HID * 4), 2);
+            if (a.out_bm)
+                __builtin_amdgcn_raw_buffer_store_b128(v, bmr, (unsigned)row * rowb_bm + (unsigned)(col * 16), (unsigned)((tt * 2 + dir) * HID * 4), 2);
+        }
+    };
     const __amdgpu_buffer_rsrc_t ofr = make_rsrc(reinterpret_cast<unsigned char*>(a.out_f32) + (size_t)b0 * rowb_bm);
     int cur = 0;
+#ifdef PV_REC_STAMPS
+    unsigned long long st_acc[5] = {0, 0, 0, 0, 0}, st_last;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_last) :: "memory");
+#endif
     for (int s = 0; s < T; s++) {
         const int t = dir ? (T - 1 - s) : s;
         const int tn = dir ? (T - 2 - s) : (s + 1);
         if (s + 1 < T) x_load(tn);
+        if (s > 0) tile_out(dir ? t + 1 : t - 1, hbuf + cur * ROWS * HS);   // the previous step's h tile leaves behind this step's MFMAs
+        // the two waves of a SIMD (w and w + NW / 2 ... hardware places wave i on SIMD i % 4) would otherwise sit in the same
+        // phase - both on the matrix pipe, then both in the cell update: the lower half of the workgroup takes the pipe first
+        // and runs its cell update under the upper half's MFMAs
+        if (NW == 8) { if (wv < 4) __builtin_amdgcn_s_setprio(3); else __builtin_amdgcn_s_setprio(0); }
+        RSTAMP(0)
         // ---- x-part (ENC) -------------------------------------------------------------------------------------------------
         if constexpr (C::XRES) {
             bf16x8 ax[MT];
@@ -293,11 +340,32 @@ __global__ __launch_bounds__(NG == 4 ? 512 : 256, 1) void k_rec_bf16(RecArgs a) 
             ring_bf16<NG, MT, NA, D, NSLOT, 0, C::KS_X, true>(acc, a_x + (s & 1) * ROWS * XS, 32 * XS, wr, bq, lane16);
         }
         // ---- h-part: h_{t-1} . W_hh^T, three terms ----------------------------------------------------------------------------
-        ring_bf16<NG, MT, NA, D, NSLOT, NXS, C::KS_H, false>(acc, a_h + cur * ROWS * HS, 32 * HS, wr, bq, lane16);
+        if constexpr (C::WRES) {
+            const unsigned char* At = a_h + cur * ROWS * HS;
+#pragma unroll
+            for (int ks = 0; ks < C::KS_H; ks++) {
+                bf16x8 ah[MT], al[MT];
+#pragma unroll
+                for (int m = 0; m < MT; m++) {
+                    ah[m] = *reinterpret_cast<const bf16x8*>(At + m * 32 * HS + ks * 64);
+                    al[m] = *reinterpret_cast<const bf16x8*>(At + m * 32 * HS + ks * 64 + 16);
+                }
+#pragma unroll
+                for (int g = 0; g < NG; g++)
+#pragma unroll
+                    for (int m = 0; m < MT; m++) {
+                        acc[m][g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[m], wres[ks * NG + g][0], acc[m][g], 0, 0, 0);
+                        acc[m][g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[m], wres[ks * NG + g][1], acc[m][g], 0, 0, 0);
+                        acc[m][g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[m], wres[ks * NG + g][0], acc[m][g], 0, 0, 0);
+                    }
+            }
+        } else {
+            ring_bf16<NG, MT, NA, D, NSLOT, NXS, C::KS_H, false>(acc, a_h + cur * ROWS * HS, 32 * HS, wr, bq, lane16);
+        }
+        if (NW == 8) { if (wv < 4) __builtin_amdgcn_s_setprio(2); else __builtin_amdgcn_s_setprio(1); }
+        RSTAMP(1)
         // ---- cell update --------------------------------------------------------------------------------------------------------
         unsigned char* hn = hbuf + (cur ^ 1) * ROWS * HS;
-        const __amdgpu_buffer_rsrc_t tmr = make_rsrc(a.out_tm + ((size_t)t * a.Bp + b0) * rowb_tm);
-        const __amdgpu_buffer_rsrc_t ftr = make_rsrc(reinterpret_cast<unsigned char*>(a.out_f32_tm) + ((size_t)t * a.Bp + b0) * rowb_tm);
 #pragma unroll
         for (int m = 0; m < MT; m++)
 #pragma unroll
@@ -322,29 +390,32 @@ __global__ __launch_bounds__(NG == 4 ? 512 : 256, 1) void k_rec_bf16(RecArgs a) 
                 const int row = 32 * m + 8 * (e >> 2) + (e & 3);   // + 4 * rg (lane part)
                 const __bf16 hi = (__bf16)h;
                 const __bf16 lo = (__bf16)(h - (float)hi);
+#if PV_REC_ABL != 2
                 *reinterpret_cast<__bf16*>(hn + row * HS + hl) = hi;
                 *reinterpret_cast<__bf16*>(hn + row * HS + hl + 16) = lo;
-                const unsigned short hb = __builtin_bit_cast(unsigned short, hi), lb = __builtin_bit_cast(unsigned short, lo);
-                if (a.out_tm) {
-                    const unsigned so = (unsigned)row * rowb_tm + (unsigned)(dir * HID * 4);
-                    __builtin_amdgcn_raw_buffer_store_b16(hb, tmr, o_tm_l, so, 0);
-                    __builtin_amdgcn_raw_buffer_store_b16(lb, tmr, o_tm_l, so + 16u, 0);
+#endif
+#if PV_REC_ABL == 1
+                if (h == 123.456f)
+#endif
+                {
+                if (a.out_f32) buf_store1_nt(h, ofr, o_f_l, (unsigned)row * rowb_bm + (unsigned)((t * 2 + dir) * HID * 4));   // debug taps only
                 }
-                if (a.out_bm) {
-                    const unsigned so = (unsigned)row * rowb_bm + (unsigned)((t * 2 + dir) * HID * 4);
-                    __builtin_amdgcn_raw_buffer_store_b16(hb, bmr, o_bm_l, so, 0);
-                    __builtin_amdgcn_raw_buffer_store_b16(lb, bmr, o_bm_l, so + 16u, 0);
-                }
-                if (a.out_f32) buf_store1_nt(h, ofr, o_f_l, (unsigned)row * rowb_bm + (unsigned)((t * 2 + dir) * HID * 4));
-                if (a.out_f32_tm) buf_store1_nt(h, ftr, o_ft_l, (unsigned)row * rowb_tm + (unsigned)(dir * HID * 4));
             }
+        RSTAMP(2)
         if (s + 1 < T) {
             acc_init(tn);     // the next step's projections travel into the accumulators during the barrier and the ring's wrap
             x_store((s + 1) & 1);
         }
         cur ^= 1;
+        RSTAMP(3)
         lds_barrier();        // h_t (and x_{t+1}) complete; LDS only: the weight ring and the output stores stay in flight
+        RSTAMP(4)
     }
+    tile_out(dir ? 0 : T - 1, hbuf + cur * ROWS * HS);
+#ifdef PV_REC_STAMPS
+    if (blockIdx.x == 0 && lane == 0)
+        for (int i = 0; i < 5; i++) atomicAdd(&g_rec_stamps[i], st_acc[i]);
+#endif
     if (NG == 3 && a.h_out) {
 #pragma unroll
         for (int m = 0; m < MT; m++)
@@ -434,7 +505,7 @@ int pv_rec_bf16_async(pv_ctx* ctx, const pv_rec_desc& d, hipStream_t st) {
     RecArgs a;
     a.G = d.G; a.wp = d.wp; a.wx = d.wx; a.bias = d.bias; a.bias_hn = d.bias_hn; a.x = (const unsigned char*)d.x;
     a.x_row_bytes = d.x_row_bytes; a.x_t0 = d.x_t0; a.xf = d.xf; a.x_signed = d.x_signed; a.B = d.B; a.Bp = d.Bp; a.T = d.T;
-    a.h0 = d.h0; a.h_out = d.h_out; a.out_f32 = d.out_f32; a.out_tm = d.out_tm; a.out_bm = d.out_bm; a.out_f32_tm = d.out_f32_tm;
+    a.h0 = d.h0; a.h_out = d.h_out; a.out_f32 = d.out_f32; a.out_tm = d.out_tm; a.out_bm = d.out_bm;
     a.n_tiles = (int)(d.Bp / (32 * d.mt));
     const unsigned grid = (unsigned)(((a.n_tiles + 3) / 4) * 8);
     pv_prof_scope ps(ctx, d.prof_name, st);
@@ -461,7 +532,7 @@ namespace {
 constexpr int P2_WIN = 100, P2_JUMP = 50, P2_F = 10, P2_H = 128, P2_NC = 5;
 
 // dense1 (256 -> 5) + softmax + accumulate for one window: 8 lanes per (t, b) pair
-__global__ __launch_bounds__(256) void k_p2_dense(const float* __restrict__ dec /*[100][Bp][256]*/, int64_t Bp, int64_t B,
+__global__ __launch_bounds__(256) void k_p2_dense(const unsigned char* __restrict__ dec /*split8 [100][Bp][256]*/, int64_t Bp, int64_t B,
                                                   const float* __restrict__ W, const float* __restrict__ bias, float* __restrict__ acc,
                                                   int seq, int ws, float* __restrict__ logits) {
     const int64_t pair = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 3;
@@ -469,16 +540,21 @@ __global__ __launch_bounds__(256) void k_p2_dense(const float* __restrict__ dec 
     if (pair >= (int64_t)P2_WIN * B) return;   // whole groups of 8 lanes leave together
     const int t = (int)(pair / B);
     const int64_t b = pair - (int64_t)t * B;
-    const float* d = dec + ((size_t)t * Bp + b) * (2 * P2_H);
+    // the decoder's output arrives as split8 rows (hi + lo = the fp32 value to 2^-17): lane `sub` takes the 8-unit groups
+    // sub, sub + 8, sub + 16, sub + 24 (32 contiguous bytes each)
+    const unsigned char* d = dec + ((size_t)t * Bp + b) * (2 * P2_H * 4);
     float lg[P2_NC] = {0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int i = 0; i < 8; i++) {
-        const int k = 32 * i + 4 * sub;
-        const f32x4 v = *reinterpret_cast<const f32x4*>(d + k);
+    for (int i = 0; i < 4; i++) {
+        const int grp = sub + 8 * i;
+        const bf16x8 hi = *reinterpret_cast<const bf16x8*>(d + grp * 32), lo = *reinterpret_cast<const bf16x8*>(d + grp * 32 + 16);
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; j++) v[j] = (float)hi[j] + (float)lo[j];
 #pragma unroll
         for (int c = 0; c < P2_NC; c++) {
-            const f32x4 w = *reinterpret_cast<const f32x4*>(W + c * 2 * P2_H + k);
-            lg[c] += v[0] * w[0] + v[1] * w[1] + v[2] * w[2] + v[3] * w[3];
+            const f32x4 w0 = *reinterpret_cast<const f32x4*>(W + c * 2 * P2_H + grp * 8), w1 = *reinterpret_cast<const f32x4*>(W + c * 2 * P2_H + grp * 8 + 4);
+            lg[c] += v[0] * w0[0] + v[1] * w0[1] + v[2] * w0[2] + v[3] * w0[3] + v[4] * w1[0] + v[5] * w1[1] + v[6] * w1[2] + v[7] * w1[3];
         }
     }
 #pragma unroll
@@ -536,13 +612,13 @@ int pv_p2_bf16_forward(pv_ctx* ctx, const pv_p2_bf16_weights& w, const uint8_t* 
     const int mt = ((B + 31) / 32) * 2 > 2 * (int64_t)ctx->num_cu ? 2 : 1;
     const int rows = 32 * mt;
     const int64_t Bp = (B + rows - 1) / rows * rows, M = (int64_t)P2_WIN * Bp;
-    float *state = nullptr, *G = nullptr, *dec = nullptr;
-    unsigned char* enc_s = nullptr;
+    float *state = nullptr, *G = nullptr;
+    unsigned char *enc_s = nullptr, *dec = nullptr;
     int rc;
     if ((rc = pv_get(ctx, "p2b.state", (size_t)Bp * 2 * P2_H, &state))) return rc;
     if ((rc = pv_get(ctx, "p2b.enc_s", (size_t)M * 2 * P2_H * 4, &enc_s))) return rc;
     if ((rc = pv_get(ctx, "p2b.G", (size_t)M * 6 * P2_H, &G))) return rc;
-    if ((rc = pv_get(ctx, "p2b.dec", (size_t)M * 2 * P2_H, &dec))) return rc;
+    if ((rc = pv_get(ctx, "p2b.dec_s", (size_t)M * 2 * P2_H * 4, &dec))) return rc;
     if ((rc = pv_zero_async(d_acc, (size_t)B * seq * P2_NC * sizeof(float), st))) return rc;
     k_p2_state_in<<<(unsigned)((Bp * 2 * P2_H + 255) / 256), 256, 0, st>>>(state, d_hidden_in, B, Bp);
     for (int wi = 0; wi < nwin; wi++) {
@@ -558,7 +634,7 @@ int pv_p2_bf16_forward(pv_ctx* ctx, const pv_p2_bf16_weights& w, const uint8_t* 
         if ((rc = pv_gemm_bf16x3_async(ctx, g, st))) return rc;
         pv_rec_desc d = {};
         d.cell = 3; d.enc = 0; d.G = G; d.wp = w.dec_wp; d.bias_hn = w.dec_bias_hn; d.B = B; d.Bp = Bp; d.T = P2_WIN;
-        d.h0 = state; d.h_out = state; d.out_f32_tm = dec; d.mt = mt; d.prof_name = "k_rec_bf16_gru_dec";
+        d.h0 = state; d.h_out = state; d.out_tm = dec; d.mt = mt; d.prof_name = "k_rec_bf16_gru_dec";
         if ((rc = pv_rec_bf16_async(ctx, d, st))) return rc;
         {
             pv_prof_scope ps(ctx, "k_p2_dense", st);
@@ -572,3 +648,15 @@ int pv_p2_bf16_forward(pv_ctx* ctx, const pv_p2_bf16_weights& w, const uint8_t* 
     PV_HIP(hipGetLastError());
     return PV_OK;
 }
+
+#ifdef PV_REC_STAMPS
+// diagnostic build only: phase cycle sums {x load issue, MFMA loops, cell update, next-step init, barrier} of workgroup 0 (all
+// its waves added up) since the last call; resets them
+extern "C" int pv_debug_rec_stamps(unsigned long long* out5) {
+    unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    PV_HIP(hipDeviceSynchronize());
+    PV_HIP(hipMemcpyFromSymbol(out5, HIP_SYMBOL(g_rec_stamps), 5 * sizeof(unsigned long long)));
+    PV_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_rec_stamps), z, sizeof z));
+    return PV_OK;
+}
+#endif
