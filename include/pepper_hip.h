@@ -159,6 +159,13 @@ int pv_summarize_regions_dev(pv_ctx* ctx, const pv_batch_in* in, const pv_params
                              int64_t n_reads, int64_t n_bases, int64_t n_cigar, int64_t n_ref_bytes,
                              int64_t max_region_len, pv_batch_out* out, int64_t* d_counts, void* stream);
 
+/* Stage a HOST batch for the device-resident form: copies the arrays of `host` into the context's workspace (asynchronously
+ * on `stream`, after validating the offset arrays on the host) and fills `dev` with the same struct holding DEVICE pointers,
+ * valid until the next pv_upload_batch on this context; totals4 = {n_reads, n_bases, n_cigar, n_ref_bytes}, the totals
+ * pv_summarize_regions_dev takes. With pv_summarize_regions_dev and pv_rnn_forward_p1_dev behind it this is the fused
+ * call_variant step: reads in, probabilities out, windows never on the host. */
+int pv_upload_batch(pv_ctx* ctx, const pv_batch_in* host, pv_batch_in* dev, int64_t* totals4, void* stream);
+
 /* ---- haplotag-aware image builder (`make_images -hp`) --------------------------------------------
  * Replaces PEPPER_VARIANT.RegionalSummaryGeneratorHP (pybind_api.h:64-71; region_summary_hp.cpp:350-663 populate_summary_matrix,
  * :665-1012 generate_summary; call site AlignmentSummarizerHP.py:215-233). Same flat batch and scalar struct as

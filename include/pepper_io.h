@@ -6,11 +6,12 @@
  *              pepper_variant/modules/cpp/fasta_handler.cpp:18-56.
  *              pepper_variant/modules/python/AlignmentSummarizer.py:180-218 (per-interval fetch + reservoir sampling),
  *              pepper_variant/modules/python/VcfWriter.py:21-46 (bgzip + tabix outputs through pysam).
- * CPU-side library (libpepper_io.so, links zlib only); buffers returned through pvio_reads are owned
+ * CPU-side library (libpepper_io.so: zlib, and libdeflate.so.0 through dlopen when the host has it); buffers returned through pvio_reads are owned
  * by the handle and stay valid until the next pvio_bam_get_reads / pvio_bam_close on it; a pvio_batch owns its
  * arrays until pvio_batch_free. Handles are not thread-safe: one (pv_bam, pv_fasta) pair per reader thread;
  * the calls themselves hold no global state (errors are thread-local) and may run concurrently on distinct handles.
- * Every size read from a file is validated before use: corrupt or truncated inputs fail with a message.
+ * Every size read from a file is validated before use and every BGZF block is checked against its CRC32 trailer: corrupt or
+ * truncated inputs fail with a message - also in the middle of a region query (only a clean end of file ends one quietly).
  */
 #ifndef PEPPER_IO_H
 #define PEPPER_IO_H
@@ -21,6 +22,12 @@ extern "C" {
 
 typedef struct pv_bam pv_bam;
 typedef struct pv_fasta pv_fasta;
+
+/* BGZF blocks are inflated with libdeflate when libdeflate.so.0 can be opened (PEPPER_INFLATE=zlib forces zlib), else with
+ * zlib: byte-identical results, about twice the rate. pvio_inflate_backend names the one in use ("libdeflate" / "zlib");
+ * pvio_set_inflate_backend(0 / 1) switches at run time (tests) and returns 1 when libdeflate is then in use. */
+const char* pvio_inflate_backend(void);
+int pvio_set_inflate_backend(int use_libdeflate);
 
 /* the reads of ONE region after the reference's clipping, in the flat layout of pv_batch_in */
 typedef struct pvio_reads {

@@ -41,6 +41,8 @@ class pvio_batch(C.Structure):
 
 IO_SYMBOLS = [
     ("pvio_last_error", C.c_char_p, []),
+    ("pvio_inflate_backend", C.c_char_p, []),
+    ("pvio_set_inflate_backend", C.c_int, [C.c_int]),
     ("pvio_bam_open", C.c_void_p, [C.c_char_p]),
     ("pvio_bam_close", None, [C.c_void_p]),
     ("pvio_bam_nref", C.c_int, [C.c_void_p]),
@@ -287,3 +289,12 @@ def bgzf_read_all(path: str) -> bytes:
     if n < 0:
         raise IOError("bgzf_read_all: " + _err())
     return buf.raw[:n]
+
+
+def inflate_backend() -> str:
+    """"libdeflate" or "zlib": what inflates BGZF blocks in this process (include/pepper_io.h)"""
+    return load().pvio_inflate_backend().decode()
+
+
+def set_inflate_backend(use_libdeflate: bool) -> bool:
+    return bool(load().pvio_set_inflate_backend(1 if use_libdeflate else 0))

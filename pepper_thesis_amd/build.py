@@ -31,7 +31,7 @@ def build_io(force=False, verbose=False):
     src = os.path.join(CSRC, "pv_io.cpp")
     hdr = os.path.normpath(os.path.join(CSRC, "..", "..", "include", "pepper_io.h"))
     if force or _stale(IO_LIB, [src, hdr]):
-        cmd = [os.environ.get("CXX", "g++"), "-std=c++17", "-O2", "-fPIC", "-shared", "-Wall", "-o", IO_LIB, src, "-lz"]
+        cmd = [os.environ.get("CXX", "g++"), "-std=c++17", "-O2", "-fPIC", "-shared", "-Wall", "-o", IO_LIB, src, "-lz", "-ldl", "-pthread"]
         if verbose:
             print(" ".join(cmd), file=sys.stderr)
         subprocess.check_call(cmd)

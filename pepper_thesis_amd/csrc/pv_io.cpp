@@ -26,6 +26,10 @@
 // Every size taken from a file is validated before it is used as an offset.
 // Parity note: htslib is absent, so this reader is pinned by this repository's own writer-based tests only.
 #include <zlib.h>
+#include <dlfcn.h>
+
+#include <atomic>
+#include <mutex>
 
 #include <algorithm>
 #include <chrono>
@@ -56,6 +60,49 @@ static inline void wr32(std::vector<uint8_t>& v, uint32_t x) { for (int i = 0; i
 static inline void wr64(std::vector<uint8_t>& v, uint64_t x) { for (int i = 0; i < 8; i++) v.push_back((x >> (8 * i)) & 0xFF); }
 static inline double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
+// ---- raw-deflate backend ----------------------------------------------------------------------------------------
+// A BGZF block is an independent raw-deflate stream of <= 64 KiB: exactly libdeflate's whole-buffer use case (about twice
+// zlib's inflate rate). libdeflate.so.0 is resolved at run time with dlopen (its four entry points declared here, no header
+// needed); zlib stays the fallback and the two are byte-identical (tests/test_bamio.py). PEPPER_INFLATE=zlib forces zlib.
+struct Deflate {
+    void* h = nullptr;
+    void* (*alloc)() = nullptr;
+    int (*decompress)(void*, const void*, size_t, void*, size_t, size_t*) = nullptr;
+    void (*release)(void*) = nullptr;
+    uint32_t (*crc)(uint32_t, const void*, size_t) = nullptr;
+};
+static Deflate* libdeflate() {
+    static Deflate d;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        const char* names[] = {"libdeflate.so.0", "libdeflate.so", "/usr/lib/x86_64-linux-gnu/libdeflate.so.0", "/opt/conda/lib/libdeflate.so.0"};
+        for (const char* n : names)
+            if ((d.h = dlopen(n, RTLD_NOW | RTLD_LOCAL))) break;
+        if (!d.h) return;
+        d.alloc = (void* (*)())dlsym(d.h, "libdeflate_alloc_decompressor");
+        d.decompress = (int (*)(void*, const void*, size_t, void*, size_t, size_t*))dlsym(d.h, "libdeflate_deflate_decompress");
+        d.release = (void (*)(void*))dlsym(d.h, "libdeflate_free_decompressor");
+        d.crc = (uint32_t (*)(uint32_t, const void*, size_t))dlsym(d.h, "libdeflate_crc32");
+        if (!d.alloc || !d.decompress || !d.release || !d.crc) { dlclose(d.h); d.h = nullptr; }
+    });
+    return d.h ? &d : nullptr;
+}
+static std::atomic<int> g_inflate_choice{-1};   // -1: from the environment; 0 zlib; 1 libdeflate when present
+static bool want_libdeflate() {
+    int c = g_inflate_choice.load();
+    if (c < 0) {
+        const char* e = getenv("PEPPER_INFLATE");
+        c = (e && !strcmp(e, "zlib")) ? 0 : 1;
+        g_inflate_choice.store(c);
+    }
+    return c == 1 && libdeflate() != nullptr;
+}
+extern "C" const char* pvio_inflate_backend(void) { return want_libdeflate() ? "libdeflate" : "zlib"; }
+extern "C" int pvio_set_inflate_backend(int use_libdeflate) {   // tests; returns 1 if libdeflate is now in use
+    g_inflate_choice.store(use_libdeflate ? 1 : 0);
+    return want_libdeflate() ? 1 : 0;
+}
+
 // ---- BGZF reader ------------------------------------------------------------------------------------------------
 struct Bgzf {
     FILE* f = nullptr;
@@ -66,19 +113,33 @@ struct Bgzf {
     std::vector<uint8_t> cbuf;
     double t_inflate = 0.0;      // seconds spent reading + inflating blocks (stage timer)
     int64_t bytes_inflated = 0;
+    bool failed = false;         // a block could not be read for a reason OTHER than a clean end of file (message set)
+    int64_t fpos = -1;           // file position after the last read (-1 unknown): consecutive blocks need no seek, and an fseeko
+                                 // would throw the stdio buffer away every 20-64 KB
+    std::vector<char> iobuf;     // 1 MB stdio buffer (set on the first block)
+    void* ld = nullptr;          // libdeflate decompressor of this handle
+    ~Bgzf() { if (ld) libdeflate()->release(ld); }
 
+    bool fail() { failed = true; return false; }
     bool load_block(int64_t coffset) {
         const double t0 = now_s();
-        if (fseeko(f, coffset, SEEK_SET) != 0) return false;
+        if (iobuf.empty()) { iobuf.resize(1 << 20); setvbuf(f, iobuf.data(), _IOFBF, iobuf.size()); fpos = -1; }
+        if (coffset != fpos && fseeko(f, coffset, SEEK_SET) != 0) { io_err("seek to BGZF block at %lld failed", (long long)coffset); return fail(); }
+        fpos = -1;
         uint8_t h[18];
-        if (fread(h, 1, 18, f) != 18) { buf.clear(); pos = 0; block_coffset = coffset; next_coffset = coffset; return false; }
-        if (h[0] != 31 || h[1] != 139 || h[2] != 8 || !(h[3] & 4)) { io_err("not a BGZF block at offset %lld", (long long)coffset); return false; }
+        const size_t got = fread(h, 1, 18, f);
+        if (got != 18) {   // nothing left at a block boundary = clean end of file; a partial header = truncated file
+            buf.clear(); pos = 0; block_coffset = coffset; next_coffset = coffset;
+            if (got != 0) { io_err("truncated BGZF block header at offset %lld", (long long)coffset); return fail(); }
+            return false;
+        }
+        if (h[0] != 31 || h[1] != 139 || h[2] != 8 || !(h[3] & 4)) { io_err("not a BGZF block at offset %lld", (long long)coffset); return fail(); }
         const int xlen = rd16(h + 10);
-        if (xlen < 6) { io_err("BGZF block without BC field"); return false; }
+        if (xlen < 6) { io_err("BGZF block without BC field"); return fail(); }
         // find the BC subfield (it is the first one in practice; scan to be safe, never past the extra field)
         std::vector<uint8_t> extra(xlen);
         memcpy(extra.data(), h + 12, 6);
-        if (xlen > 6 && fread(extra.data() + 6, 1, xlen - 6, f) != (size_t)(xlen - 6)) { io_err("truncated BGZF header"); return false; }
+        if (xlen > 6 && fread(extra.data() + 6, 1, xlen - 6, f) != (size_t)(xlen - 6)) { io_err("truncated BGZF header"); return fail(); }
         int bsize = -1;
         for (int i = 0; i + 4 <= xlen;) {
             const int slen = rd16(&extra[i + 2]);
@@ -86,26 +147,44 @@ struct Bgzf {
             if (extra[i] == 'B' && extra[i + 1] == 'C' && slen == 2) bsize = rd16(&extra[i + 4]);
             i += 4 + slen;
         }
-        if (bsize < 0) { io_err("BGZF block without BC field"); return false; }
+        if (bsize < 0) { io_err("BGZF block without BC field"); return fail(); }
         const int clen = bsize + 1 - 12 - xlen - 8;
-        if (clen < 0) { io_err("corrupt BGZF block size"); return false; }
+        if (clen < 0) { io_err("corrupt BGZF block size"); return fail(); }
         cbuf.resize(clen + 8);
-        if (fread(cbuf.data(), 1, clen + 8, f) != (size_t)(clen + 8)) { io_err("truncated BGZF block"); return false; }
+        if (fread(cbuf.data(), 1, clen + 8, f) != (size_t)(clen + 8)) { io_err("truncated BGZF block"); return fail(); }
         const uint32_t isize = rd32(&cbuf[clen + 4]);
-        if (isize > 65536) { io_err("corrupt BGZF block (ISIZE %u > 64 KiB)", isize); return false; }
+        if (isize > 65536) { io_err("corrupt BGZF block (ISIZE %u > 64 KiB)", isize); return fail(); }
         buf.resize(isize);
-        if (isize) {
-            z_stream zs;
-            memset(&zs, 0, sizeof(zs));
-            if (inflateInit2(&zs, -15) != Z_OK) { io_err("inflateInit2 failed"); return false; }
-            zs.next_in = cbuf.data(); zs.avail_in = clen;
-            zs.next_out = buf.data(); zs.avail_out = isize;
-            const int rc = inflate(&zs, Z_FINISH);
-            inflateEnd(&zs);
-            if (rc != Z_STREAM_END) { io_err("inflate failed (%d)", rc); return false; }
+        uint32_t crc = 0;
+        if (want_libdeflate()) {
+            Deflate* L = libdeflate();
+            if (!ld && !(ld = L->alloc())) { io_err("libdeflate_alloc_decompressor failed"); return fail(); }
+            if (isize) {
+                size_t actual = 0;
+                const int rc = L->decompress(ld, cbuf.data(), (size_t)clen, buf.data(), isize, &actual);
+                if (rc != 0 || actual != isize) { io_err("inflate failed (libdeflate %d) at offset %lld", rc, (long long)coffset); return fail(); }
+            }
+            crc = L->crc(0, buf.data(), isize);
+        } else {
+            if (isize) {
+                z_stream zs;
+                memset(&zs, 0, sizeof(zs));
+                if (inflateInit2(&zs, -15) != Z_OK) { io_err("inflateInit2 failed"); return fail(); }
+                zs.next_in = cbuf.data(); zs.avail_in = clen;
+                zs.next_out = buf.data(); zs.avail_out = isize;
+                const int rc = inflate(&zs, Z_FINISH);
+                inflateEnd(&zs);
+                if (rc != Z_STREAM_END) { io_err("inflate failed (%d) at offset %lld", rc, (long long)coffset); return fail(); }
+            }
+            crc = (uint32_t)crc32(crc32(0L, Z_NULL, 0), buf.data(), (uInt)isize);
+        }
+        if (crc != rd32(&cbuf[clen])) {   // the gzip trailer's CRC32 of the uncompressed bytes: cheap next to the inflate
+            io_err("BGZF block at offset %lld: CRC32 mismatch (corrupt file)", (long long)coffset);
+            return fail();
         }
         block_coffset = coffset;
         next_coffset = coffset + bsize + 1;
+        fpos = next_coffset;
         pos = 0;
         t_inflate += now_s() - t0;
         bytes_inflated += isize;
@@ -598,10 +677,13 @@ static int query_region(pv_bam* b, int tid, int64_t start, int64_t stop, int inc
     std::vector<uint32_t> cigbuf;
     bool done = false;
     for (size_t ci = 0; ci < chunks.size() && !done; ci++) {
-        if (!b->z.seek(chunks[ci].beg)) { io_err("seek failed in BAM"); return -1; }
+        if (!b->z.seek(chunks[ci].beg)) { if (!b->z.failed) io_err("seek failed in BAM"); return -1; }   // (a failed block keeps its own message)
         while (b->z.tell() < chunks[ci].end) {
             uint8_t h4[4];
-            if (!b->z.read(h4, 4)) break;
+            if (!b->z.read(h4, 4)) {
+                if (b->z.failed) return -1;   // a corrupt / truncated block in the middle of a chunk is an error, not "no more reads"
+                break;                        // clean end of file
+            }
             const uint32_t bs = rd32(h4);
             if (bs < 32 || bs > (1u << 30)) { io_err("corrupt BAM record (block_size %u)", bs); return -1; }
             rec.resize(bs);

@@ -2378,6 +2378,51 @@ static int upload(pv_ctx* ctx, const char* name, const T* h, size_t n, const T**
     return PV_OK;
 }
 
+// The arrays of a HOST batch -> the context's workspace (asynchronous copies on `stream`); `dev` receives the same struct with
+// DEVICE pointers, valid until the next upload on this context. The offset arrays are validated on the host first (cheap:
+// O(regions + reads)). totals4 = {n_reads, n_bases, n_cigar, n_ref_bytes}: what the *_dev entry points take next to the struct.
+extern "C" int pv_upload_batch(pv_ctx* ctx, const pv_batch_in* in, pv_batch_in* dev, int64_t* totals4, void* stream) {
+    PV_CHECK(ctx && in && dev && totals4, PV_ERR_INVALID, "null argument");
+    PV_HIP(hipSetDevice(ctx->device));
+    hipStream_t st = pv_pick_stream(ctx, stream);
+    const int G = in->n_regions;
+    PV_CHECK(G >= 0, PV_ERR_INVALID, "negative region count");
+    *dev = *in;
+    totals4[0] = totals4[1] = totals4[2] = totals4[3] = 0;
+    if (G == 0) return PV_OK;
+    const int64_t n_reads = in->read_off[G], n_cols = in->ref_off[G];
+    PV_CHECK(in->read_off[0] == 0 && in->ref_off[0] == 0 && n_reads >= 0, PV_ERR_INVALID, "offset arrays must start at 0");
+    for (int g = 0; g < G; g++) {
+        const int64_t R = in->ref_end[g] - in->ref_start[g] + 1;
+        PV_CHECK(R >= 1 && in->ref_off[g + 1] - in->ref_off[g] >= R, PV_ERR_INVALID,
+                 "region %d: reference shorter than ref_end-ref_start+1", g);
+        PV_CHECK(in->read_off[g + 1] >= in->read_off[g], PV_ERR_INVALID, "read_off not monotone");
+    }
+    const int64_t n_bases = n_reads ? in->base_off[n_reads] : 0, n_cigar = n_reads ? in->cigar_off[n_reads] : 0;
+    for (int64_t r = 0; r < n_reads; r++)
+        PV_CHECK(in->base_off[r + 1] >= in->base_off[r] && in->cigar_off[r + 1] >= in->cigar_off[r], PV_ERR_INVALID,
+                 "read %lld: offsets not monotone", (long long)r);
+    pv_batch_in& d = *dev;
+    int rc;
+    if ((rc = upload(ctx, "in.ref_start", in->ref_start, G, &d.ref_start, st))) return rc;
+    if ((rc = upload(ctx, "in.ref_end", in->ref_end, G, &d.ref_end, st))) return rc;
+    if ((rc = upload(ctx, "in.cand_start", in->cand_start, G, &d.cand_start, st))) return rc;
+    if ((rc = upload(ctx, "in.cand_end", in->cand_end, G, &d.cand_end, st))) return rc;
+    if ((rc = upload(ctx, "in.ref_off", in->ref_off, G + 1, &d.ref_off, st))) return rc;
+    if ((rc = upload(ctx, "in.ref", in->ref, n_cols, &d.ref, st))) return rc;
+    if ((rc = upload(ctx, "in.read_off", in->read_off, G + 1, &d.read_off, st))) return rc;
+    if ((rc = upload(ctx, "in.read_pos", in->read_pos, n_reads, &d.read_pos, st))) return rc;
+    if ((rc = upload(ctx, "in.read_flags", in->read_flags, n_reads, &d.read_flags, st))) return rc;
+    if ((rc = upload(ctx, "in.read_mapq", in->read_mapq, n_reads, &d.read_mapq, st))) return rc;
+    if ((rc = upload(ctx, "in.base_off", in->base_off, n_reads + 1, &d.base_off, st))) return rc;
+    if ((rc = upload(ctx, "in.bases", in->bases, n_bases, &d.bases, st))) return rc;
+    if ((rc = upload(ctx, "in.quals", in->quals, n_bases, &d.quals, st))) return rc;
+    if ((rc = upload(ctx, "in.cigar_off", in->cigar_off, n_reads + 1, &d.cigar_off, st))) return rc;
+    if ((rc = upload(ctx, "in.cigar", in->cigar, n_cigar, &d.cigar, st))) return rc;
+    totals4[0] = n_reads; totals4[1] = n_bases; totals4[2] = n_cigar; totals4[3] = n_cols;
+    return PV_OK;
+}
+
 static int summarize_host(pv_ctx* ctx, const pv_batch_in* in, const pv_params* params, pv_batch_out* out, bool hp,
                           const int32_t* read_hp);
 extern "C" int pv_summarize_regions(pv_ctx* ctx, const pv_batch_in* in, const pv_params* params, pv_batch_out* out) {
@@ -2400,37 +2445,11 @@ static int summarize_host(pv_ctx* ctx, const pv_batch_in* in, const pv_params* p
     out->str_bytes = 0;
     if (out->capacity > 0 && out->cand_off) out->cand_off[0] = 0;
     if (G <= 0) return PV_OK;
-    // host-side validation of the offset arrays (cheap: O(regions + reads))
-    const int64_t n_reads = in->read_off[G], n_cols = in->ref_off[G];
-    PV_CHECK(in->read_off[0] == 0 && in->ref_off[0] == 0 && n_reads >= 0, PV_ERR_INVALID, "offset arrays must start at 0");
-    for (int g = 0; g < G; g++) {
-        const int64_t R = in->ref_end[g] - in->ref_start[g] + 1;
-        PV_CHECK(R >= 1 && in->ref_off[g + 1] - in->ref_off[g] >= R, PV_ERR_INVALID,
-                 "region %d: reference shorter than ref_end-ref_start+1", g);
-        PV_CHECK(in->read_off[g + 1] >= in->read_off[g], PV_ERR_INVALID, "read_off not monotone");
-    }
-    const int64_t n_bases = n_reads ? in->base_off[n_reads] : 0, n_cigar = n_reads ? in->cigar_off[n_reads] : 0;
-    for (int64_t r = 0; r < n_reads; r++)
-        PV_CHECK(in->base_off[r + 1] >= in->base_off[r] && in->cigar_off[r + 1] >= in->cigar_off[r], PV_ERR_INVALID,
-                 "read %lld: offsets not monotone", (long long)r);
-
-    pv_batch_in d = *in;
-    int rc;
-    if ((rc = upload(ctx, "in.ref_start", in->ref_start, G, &d.ref_start, st))) return rc;
-    if ((rc = upload(ctx, "in.ref_end", in->ref_end, G, &d.ref_end, st))) return rc;
-    if ((rc = upload(ctx, "in.cand_start", in->cand_start, G, &d.cand_start, st))) return rc;
-    if ((rc = upload(ctx, "in.cand_end", in->cand_end, G, &d.cand_end, st))) return rc;
-    if ((rc = upload(ctx, "in.ref_off", in->ref_off, G + 1, &d.ref_off, st))) return rc;
-    if ((rc = upload(ctx, "in.ref", in->ref, n_cols, &d.ref, st))) return rc;
-    if ((rc = upload(ctx, "in.read_off", in->read_off, G + 1, &d.read_off, st))) return rc;
-    if ((rc = upload(ctx, "in.read_pos", in->read_pos, n_reads, &d.read_pos, st))) return rc;
-    if ((rc = upload(ctx, "in.read_flags", in->read_flags, n_reads, &d.read_flags, st))) return rc;
-    if ((rc = upload(ctx, "in.read_mapq", in->read_mapq, n_reads, &d.read_mapq, st))) return rc;
-    if ((rc = upload(ctx, "in.base_off", in->base_off, n_reads + 1, &d.base_off, st))) return rc;
-    if ((rc = upload(ctx, "in.bases", in->bases, n_bases, &d.bases, st))) return rc;
-    if ((rc = upload(ctx, "in.quals", in->quals, n_bases, &d.quals, st))) return rc;
-    if ((rc = upload(ctx, "in.cigar_off", in->cigar_off, n_reads + 1, &d.cigar_off, st))) return rc;
-    if ((rc = upload(ctx, "in.cigar", in->cigar, n_cigar, &d.cigar, st))) return rc;
+    pv_batch_in d;
+    int64_t totals[4];
+    int rc = pv_upload_batch(ctx, in, &d, totals, st);
+    if (rc) return rc;
+    const int64_t n_reads = totals[0], n_bases = totals[1], n_cigar = totals[2], n_cols = totals[3];
     const int32_t* d_hp = nullptr;
     if (hp && read_hp)
         if ((rc = upload(ctx, "in.read_hp", read_hp, n_reads, &d_hp, st))) return rc;

@@ -297,24 +297,20 @@ def process_candidates(prediction_dir: str, fasta_path: str, sample_name: str, o
     return counts
 
 
-def main(argv=None):
-    import argparse
-    ap = argparse.ArgumentParser(prog="find_candidates")
-    ap.add_argument("-i", "--input_dir", required=True)
-    ap.add_argument("-f", "--fasta", required=True)
-    ap.add_argument("-o", "--output_dir", required=True)
-    ap.add_argument("-s", "--sample_name", default="SAMPLE")
-    g = ap.add_mutually_exclusive_group(required=True)
-    for name in CANDIDATE_PRESETS:
-        g.add_argument("--" + name, action="store_true")
-    add_candidate_arguments(ap)
-    args = ap.parse_args(argv)
-    preset = next(n for n in CANDIDATE_PRESETS if getattr(args, n))
+def run(args):
+    import sys
+    from . import cli
+    preset = cli.preset_of(args)
     c = process_candidates(args.input_dir, args.fasta, args.sample_name, args.output_dir,
                            candidate_options_from_args(args, preset))
-    import sys
     sys.stderr.write("INFO: FINISHED PROCESSING, TOTAL CANDIDATES FOUND: %d (PEPPER %d, RE-GENOTYPING %d: SNP %d INDEL %d)\n" %
                      (c["total"], c["pepper"], c["variant_calling"], c["snp"], c["indel"]))
+    return 0
+
+
+def main(argv=None):
+    from . import cli
+    return run(cli.find_candidates_parser().parse_args(argv))
 
 
 if __name__ == "__main__":

@@ -73,13 +73,54 @@ def parse_region(region: str):
     return contig, int(a), int(b)
 
 
-def list_intervals(fasta, bam, region: str = None, region_size: int = 100_000) -> List[Tuple[str, int, int]]:
+def expand_region_names(region: str) -> List[str]:
+    """the `-r` grammar of ImageGenerationUtils.get_chromosome_list (ImageGenerationUI.py:131-169): a comma list of `name`
+    or `name:start-end`; a name containing '-' is a RANGE (`chr1-22`, `1-22`): prefix = its leading non-digits, the numbers
+    of its pieces sorted, every contig prefix + n for n in first..last, each with the same `:start-end` if one was given"""
+    out = []
+    for part in region.strip().split(","):
+        part = part.strip()
+        if not part:
+            continue
+        name, span = (part.split(":") + [None])[:2] if ":" in part else (part, None)
+        pieces = name.split("-")
+        if len(pieces) > 1:
+            prefix = ""
+            for ch in name:
+                if ch.isdigit():
+                    break
+                prefix += ch
+            nums = sorted(int("".join(c for c in piece if c.isdigit())) for piece in pieces)
+            names = ["%s%d" % (prefix, k) for k in range(nums[0], nums[-1] + 1)]
+        else:
+            names = [name]
+        out += [n if span is None else n + ":" + span for n in names]
+    return out
+
+
+def read_bed(path: str):
+    """`--region_bed` (ImageGenerationUI.py:171-185): tab-separated contig, start, end per line -> {contig: [[lo, hi], ...]}.
+    The reference consults the list in TRAIN mode only (AlignmentSummarizer.py:78-91: truth regions); an inference run parses
+    the file (a malformed one still stops it) and then ignores it - and so does this one."""
+    out = {}
+    with open(path) as fh:
+        for line in fh:
+            if not line.strip():
+                continue
+            f = line.rstrip().split("\t")
+            out.setdefault(f[0], []).append(sorted([int(f[1]), int(f[2])]))
+    return out
+
+
+def list_intervals(fasta, bam, region: str = None, region_size: int = 100_000, region_bed: str = None) -> List[Tuple[str, int, int]]:
     """the interval list of generate_images (ImageGenerationUI.py:286-316): a whole contig is [0, length-1], a user region is
     clamped to [max(0, start), min(end, length-1)], both cut into region_size pieces that share their boundary position"""
+    if region_bed:
+        read_bed(region_bed)   # validated, not applied: see read_bed
     todo = []
     if region:
-        for part in region.split(","):
-            contig, a, b = parse_region(part.strip())
+        for part in expand_region_names(region):
+            contig, a, b = parse_region(part)
             last = fasta.get_chromosome_sequence_length(contig) - 1
             if a is None:
                 a, b = 0, last
@@ -87,29 +128,29 @@ def list_intervals(fasta, bam, region: str = None, region_size: int = 100_000) -
                 a, b = max(0, a), min(b, last)
             todo += split_intervals(contig, a, b, region_size)
     else:
+        # contigs common to FASTA and BAM, natural-sorted (ImageGenerationUI.py:111-130; the reference also drops the names of
+        # its 3417-entry EXCLUDED_HUMAN_CONTIGS table of decoys / alts, which this build does not carry: pass -r to restrict)
+        import re
         in_bam = set(bam.get_chromosome_sequence_names())
-        for n in fasta.get_chromosome_names():
-            if n in in_bam:
-                todo += split_intervals(n, 0, fasta.get_chromosome_sequence_length(n) - 1, region_size)
+        common = [n for n in fasta.get_chromosome_names() if n in in_bam]
+        for n in sorted(common, key=lambda s_: [int(x) if x.isdigit() else x for x in re.split(r"(\d+)", s_)]):
+            todo += split_intervals(n, 0, fasta.get_chromosome_sequence_length(n) - 1, region_size)
     return todo
 
 
-def generate_images(ctx, bam_path: str, fasta_path: str, output_dir: str, params: Params, region: str = None,
-                    region_size: int = 100_000, min_mapq: int = 5, include_supplementary: bool = False,
-                    downsample_rate: float = 1.0, intervals_per_call: int = 16, rank: int = 0, world: int = 1,
-                    reader_threads: int = None, timers: dict = None, intervals_per_read: int = 1,
-                    use_hp_info: bool = False) -> int:
-    """generate_images (ImageGenerationUI.py:277-345) on the MI355X path: intervals of region_size, interval i handled
-    by rank i % world (:211), `intervals_per_call` intervals per builder launch chain, one HDF5 file per rank.
+def region_batches(bam_path: str, fasta_path: str, region: str = None, region_size: int = 100_000, min_mapq: int = 5,
+                   include_supplementary: bool = False, downsample_rate: float = 1.0, intervals_per_call: int = 16,
+                   rank: int = 0, world: int = 1, reader_threads: int = None, intervals_per_read: int = 1, T: dict = None,
+                   region_bed: str = None):
+    """The reader side of generate_images (ImageGenerationUI.py:277-345) as a generator of (RegionBatch, interval of every
+    batch region) pairs, `intervals_per_call` intervals per batch; interval i belongs to rank i % world (:211).
 
     The reference gives every worker PROCESS its own BAM/FASTA handles and lets it fetch, summarise and write one interval
-    at a time (:222-260). Here `reader_threads` threads (default: the CPU share, at most 16) each own a handle pair and fill
+    at a time (:222-260). Here `reader_threads` threads (default: the CPU share) each own a handle pair and fill
     `intervals_per_read` intervals at a time straight into the flat pv_batch_in arrays in native code (bamio.fill_batch, GIL
-    released), running ahead of the GPU; the calling thread merges `intervals_per_call` of them per builder launch chain
-    (array concatenation), hands them to the builder and writes the HDF5 groups.
-    `timers` (optional dict) receives the stage times in seconds.
-    use_hp_info (`-hp`, ImageGenerationUI.py:48-71,206-207): the haplotag-aware builder (AlignmentSummarizerHP.py:176-233:
-    the same fetch, RegionalSummaryGeneratorHP with window 20 / 48 planes, the reads' HP tags); the file name gets "_hp"."""
+    released), running ahead of the consumer; the consuming thread merges `intervals_per_call` of them per batch (array
+    concatenation). The arrays of a yielded batch stay valid until the generator is resumed.
+    T (optional dict) accumulates the reader-side stage times."""
     import os
     import threading
     import time
@@ -117,15 +158,19 @@ def generate_images(ctx, bam_path: str, fasta_path: str, output_dir: str, params
     from concurrent.futures import ThreadPoolExecutor
     from .bamio import BamHandler, FastaHandler, fill_batch
     from .batch import merge_batches
-    from .hdf5io import ImageStore
-    t_start = time.perf_counter()
+    T = T if T is not None else {}
+    for k in ("read_inflate_cpu_s", "read_decode_cpu_s", "reader_stall_s", "merge_s"):
+        T.setdefault(k, 0.0)
+    for k in ("bytes_inflated", "bases", "reads"):
+        T.setdefault(k, 0)
     bam, fasta = BamHandler(bam_path), FastaHandler(fasta_path)
-    todo = list_intervals(fasta, bam, region, region_size)
+    todo = list_intervals(fasta, bam, region, region_size, region_bed)
     mine = [iv for i, iv in enumerate(todo) if i % world == rank]
     ipr = max(1, min(int(intervals_per_read), int(intervals_per_call)))
     groups = [mine[k:k + ipr] for k in range(0, len(mine), ipr)]
     reads_per_call = max(1, int(intervals_per_call) // ipr)
-    n_thr = max(1, min(int(reader_threads or min(16, len(os.sched_getaffinity(0)))), max(len(groups), 1)))
+    n_thr = max(1, min(int(reader_threads or len(os.sched_getaffinity(0))), max(len(groups), 1)))
+    T["reader_threads"], T["intervals"] = n_thr, len(mine)
     tls = threading.local()
 
     def read_group(ivs):
@@ -133,19 +178,10 @@ def generate_images(ctx, bam_path: str, fasta_path: str, output_dir: str, params
             tls.h = (BamHandler(bam_path), FastaHandler(fasta_path))   # one handle pair per reader thread
         return fill_batch(tls.h[0], tls.h[1], ivs, min_mapq, include_supplementary, downsample_rate, REGION_SAFE_BASES)
 
-    os.makedirs(output_dir, exist_ok=True)
-    T = dict(read_inflate_cpu_s=0.0, read_decode_cpu_s=0.0, reader_stall_s=0.0, merge_s=0.0, builder_call_s=0.0, hdf5_write_s=0.0,
-             bytes_inflated=0, reader_threads=n_thr, intervals=len(mine), bases=0, reads=0)
-    n_windows = 0
-    if use_hp_info:
-        from .batch import hp_params
-        params = hp_params(params)
-    fname = "pepper_variants_images_thread_%d%s.hdf5" % (rank, "_hp" if use_hp_info else "")
-    with ImageStore(os.path.join(output_dir, fname), "w") as store, \
-            ThreadPoolExecutor(n_thr) as pool:
+    with ThreadPoolExecutor(n_thr) as pool:
         pending = deque()
         nxt = 0
-        ahead = reads_per_call + n_thr + 2                           # reads in flight: one builder call's worth + the pool
+        ahead = reads_per_call + n_thr + 2                           # reads in flight: one batch's worth + the pool
         while nxt < len(groups) and len(pending) < ahead:
             pending.append(pool.submit(read_group, groups[nxt]))
             nxt += 1
@@ -167,12 +203,40 @@ def generate_images(ctx, bam_path: str, fasta_path: str, output_dir: str, params
             t0 = time.perf_counter()
             batch = merge_batches([fb.batch for fb in fbs])
             T["merge_s"] += time.perf_counter() - t0
-            if batch.n_regions == 0:                                 # "no group when no reads" (AlignmentSummarizer.py:212-213)
-                for fb in fbs:
-                    fb.close()
-                continue
-            T["bases"] += batch.n_bases
-            T["reads"] += batch.n_reads
+            if batch.n_regions:                                      # "no group when no reads" (AlignmentSummarizer.py:212-213)
+                T["bases"] += batch.n_bases
+                T["reads"] += batch.n_reads
+                yield batch, names
+            del batch
+            for fb in fbs:
+                fb.close()
+
+
+def generate_images(ctx, bam_path: str, fasta_path: str, output_dir: str, params: Params, region: str = None,
+                    region_size: int = 100_000, min_mapq: int = 5, include_supplementary: bool = False,
+                    downsample_rate: float = 1.0, intervals_per_call: int = 16, rank: int = 0, world: int = 1,
+                    reader_threads: int = None, timers: dict = None, intervals_per_read: int = 1,
+                    use_hp_info: bool = False, region_bed: str = None) -> int:
+    """generate_images (ImageGenerationUI.py:277-345) on the MI355X path: intervals of region_size, interval i handled
+    by rank i % world (:211), `intervals_per_call` intervals per builder launch chain, one HDF5 file per rank; the readers
+    are `region_batches` above. `timers` (optional dict) receives the stage times in seconds.
+    use_hp_info (`-hp`, ImageGenerationUI.py:48-71,206-207): the haplotag-aware builder (AlignmentSummarizerHP.py:176-233:
+    the same fetch, RegionalSummaryGeneratorHP with window 20 / 48 planes, the reads' HP tags); the file name gets "_hp"."""
+    import os
+    import time
+    from .hdf5io import ImageStore
+    t_start = time.perf_counter()
+    os.makedirs(output_dir, exist_ok=True)
+    T = dict(builder_call_s=0.0, hdf5_write_s=0.0)
+    n_windows = 0
+    if use_hp_info:
+        from .batch import hp_params
+        params = hp_params(params)
+    fname = "pepper_variants_images_thread_%d%s.hdf5" % (rank, "_hp" if use_hp_info else "")
+    with ImageStore(os.path.join(output_dir, fname), "w") as store:
+        for batch, names in region_batches(bam_path, fasta_path, region, region_size, min_mapq, include_supplementary,
+                                           downsample_rate, intervals_per_call, rank, world, reader_threads, intervals_per_read, T,
+                                           region_bed):
             t0 = time.perf_counter()
             out = ctx.summarize_hp(batch, params) if use_hp_info else ctx.summarize(batch, params)
             T["builder_call_s"] += time.perf_counter() - t0
@@ -185,9 +249,6 @@ def generate_images(ctx, bam_path: str, fasta_path: str, output_dir: str, params
                                     [[out.candidates[j]] for j in sel], out.cand_freq[sel].reshape(-1, 1), out.images[sel])
             T["hdf5_write_s"] += time.perf_counter() - t0
             n_windows += len(out)
-            del batch
-            for fb in fbs:
-                fb.close()
     T["wall_s"] = time.perf_counter() - t_start
     T["windows"] = n_windows
     if timers is not None:
@@ -222,38 +283,25 @@ def image_options_from_args(args, preset: str):
     return params, (PRESET_MIN_MAPQ[preset] if mq is None else int(mq))
 
 
-def main(argv=None):
-    import argparse
-    import os
-    from .batch import PRESETS
-    from .runtime import Context
-    ap = argparse.ArgumentParser(prog="make_images")
-    ap.add_argument("-b", "--bam", required=True)
-    ap.add_argument("-f", "--fasta", required=True)
-    ap.add_argument("-o", "--output_dir", required=True)
-    ap.add_argument("-r", "--region", default=None)
-    ap.add_argument("--region_size", type=int, default=100_000)
-    ap.add_argument("-d", "--downsample_rate", type=float, default=1.0)
-    ap.add_argument("--include_supplementary", action="store_true")
-    ap.add_argument("--min_mapq", type=int, default=None, help="default: the platform preset's value (SetParameters.py)")
-    ap.add_argument("-t", "--threads", type=int, default=1)
-    ap.add_argument("-hp", "--use_hp_info", action="store_true", default=False,
-                    help="haplotag-aware images (48 planes x 21 rows) from the reads' HP tags")
-    g = ap.add_mutually_exclusive_group(required=True)
-    for name in PRESETS:
-        g.add_argument("--" + name, action="store_true")
-    add_image_arguments(ap)
-    args = ap.parse_args(argv)
-    preset = next(n for n in PRESETS if getattr(args, n))
-    params, args.min_mapq = image_options_from_args(args, preset)
-    rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
-    ctx = Context(int(os.environ.get("LOCAL_RANK", "0")))
-    n = generate_images(ctx, args.bam, args.fasta, args.output_dir, params, args.region, args.region_size,
-                        args.min_mapq, args.include_supplementary, args.downsample_rate, rank=rank, world=world,
-                        use_hp_info=args.use_hp_info)
-    ctx.close()
+def run(args):
     import sys
+    from . import cli
+    from .runtime import Context
+    preset = cli.preset_of(args)
+    params, min_mapq = image_options_from_args(args, preset)
+    rank, world, device = cli.rank_world_device(args)
+    ctx = Context(device)
+    n = generate_images(ctx, args.bam, args.fasta, args.output_dir, params, args.region, args.region_size,
+                        min_mapq, args.include_supplementary, args.downsample_rate, rank=rank, world=world,
+                        reader_threads=args.threads, use_hp_info=args.use_hp_info, region_bed=args.region_bed)
+    ctx.close()
     sys.stderr.write("INFO: FINISHED IMAGE GENERATION: %d WINDOWS\n" % n)
+    return 0
+
+
+def main(argv=None):
+    from . import cli
+    return run(cli.make_images_parser().parse_args(argv))
 
 
 if __name__ == "__main__":

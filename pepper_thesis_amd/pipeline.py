@@ -1,0 +1,144 @@
+"""The fused call_variant path: BAM -> pileup windows -> genotype probabilities with the windows never leaving HBM.
+
+The reference chains make_images -> run_inference through image HDF5 files on disk (pepper_variant/modules/python/
+CallVariant.py:84-104: every window is written as int8 [33,26], read back by dataloader_predict.py:46-78 and copied to the
+device batch by batch, predict_distributed_gpu.py:58-69). Here a builder launch chain (`intervals_per_call` intervals) leaves
+its windows in a device buffer (pv_summarize_regions_dev) and the P1 network reads that very buffer (pv_rnn_forward_p1_dev);
+only the per-window records the consumer needs (contig, position, depth, allele key, allele frequency) and the [n,3]
+probabilities come back to the host, where they are written as the reference's prediction file (DataStorePredict.py:49-66:
+`predictions/batch_<k>` groups of `batch_size` windows) by a writer thread. Image files are written only on request
+(`keep_images_dir`), from a copy of the same device windows.
+
+Ranks: interval i belongs to rank i % world (ImageGenerationUI.py:211) and every rank writes its own
+`pepper_prediction_<rank>.hdf` (RunInference.py:101-116); find_candidates globs the directory (FindCandidates.py:145-166).
+"""
+import os
+import queue
+import threading
+import time
+from typing import Optional
+
+import numpy as np
+
+from . import _ffi
+from .batch import Params
+
+
+def _writer_loop(q: "queue.Queue", pred_path: str, image_path: Optional[str], batch_size: int, T: dict, err: list):
+    from .hdf5io import ImageStore, PredictionStore
+    try:
+        with PredictionStore(pred_path, "w") as out:
+            img = ImageStore(image_path, "w") if image_path else None
+            try:
+                batch_no = 0
+                while True:
+                    item = q.get()
+                    if item is None:
+                        break
+                    t0 = time.perf_counter()
+                    names, rec, probs, images = item
+                    n = len(rec["positions"])
+                    for i in range(0, n, batch_size):
+                        sl = slice(i, i + batch_size)
+                        out.write_prediction(batch_no, rec["contigs"][sl], rec["positions"][sl], rec["depths"][sl], rec["candidates"][sl],
+                                             rec["candidate_frequency"][sl], probs[sl].astype(np.float64))
+                        batch_no += 1
+                    if img is not None:
+                        for g, (contig, start, end) in enumerate(names):
+                            sel = np.flatnonzero(rec["region"] == g)
+                            img.write_summary("%s_%d_%d" % (contig, start, end), [contig] * sel.size, rec["positions"][sel], rec["depths"][sel],
+                                              [[rec["candidates"][j, 0]] for j in sel], rec["candidate_frequency"][sel], images[sel])
+                    T["hdf5_write_s"] += time.perf_counter() - t0
+            finally:
+                if img is not None:
+                    img.close()
+    except BaseException as e:   # surfaced by the producer
+        err.append(e)
+        while q.get() is not None:   # keep draining so that the producer never blocks on a full queue
+            pass
+
+
+def call_variant_fused(ctx, state_dict: dict, bam_path: str, fasta_path: str, pred_path: str, params: Params, region: str = None,
+                       region_size: int = 100_000, min_mapq: int = 5, include_supplementary: bool = False,
+                       downsample_rate: float = 1.0, batch_size: int = 512, intervals_per_call: int = 16, rank: int = 0,
+                       world: int = 1, reader_threads: int = None, keep_images_path: Optional[str] = None, timers: dict = None,
+                       dtype: int = _ffi.PV_DTYPE_F32, region_bed: str = None) -> int:
+    """-> number of windows predicted. One prediction file at `pred_path` (and one image file at `keep_images_path`, if given)
+    for the intervals of this rank."""
+    import torch
+    from .device import DeviceOut
+    from .make_images import region_batches
+    from .predict import Predictor
+    t_start = time.perf_counter()
+    dev = "cuda:%d" % ctx.device_id
+    T = dict(upload_s=0.0, device_call_s=0.0, readback_s=0.0, hdf5_write_s=0.0, builder_retries=0)
+    Predictor(ctx, state_dict, "p1", dtype)
+    T["load_weights_s"] = time.perf_counter() - t_start
+    q: "queue.Queue" = queue.Queue(maxsize=4)
+    werr: list = []
+    os.makedirs(os.path.dirname(os.path.abspath(pred_path)), exist_ok=True)
+    if keep_images_path:
+        os.makedirs(os.path.dirname(os.path.abspath(keep_images_path)), exist_ok=True)
+    writer = threading.Thread(target=_writer_loop, args=(q, pred_path, keep_images_path, int(batch_size), T, werr), daemon=True)
+    writer.start()
+    n_windows = 0
+    cap, scap = 0, 0
+    dout = probs = None
+    try:
+        for batch, names in region_batches(bam_path, fasta_path, region, region_size, min_mapq, include_supplementary,
+                                           downsample_rate, intervals_per_call, rank, world, reader_threads, 1, T, region_bed):
+            if werr:
+                break
+            t0 = time.perf_counter()
+            up = ctx.upload_batch(batch)   # asynchronous copies on the context's stream, the builder is queued behind them
+            T["upload_s"] += time.perf_counter() - t0
+            want = max(4096, 1024 * batch.n_regions)
+            while True:
+                if dout is None or cap < want:
+                    cap, scap = want, 16 * want
+                    dout = DeviceOut(cap, scap, dev)
+                    probs = torch.zeros((cap, 3), dtype=torch.float32, device=dev)
+                    torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                ctx.summarize_uploaded(up, params, dout, batch.max_region_len)
+                ctx.synchronize(check=False)
+                n_out, str_bytes, status = (int(v) for v in dout.counts[:3].tolist())
+                if status != _ffi.PV_OK:
+                    raise _ffi.PepperHipError(status, "image builder reported status %d for intervals %s..%s" % (status, names[0], names[-1]))
+                if n_out > cap or str_bytes > scap:   # more windows than the buffers hold: grow and run the chain again
+                    want = max(n_out, (str_bytes + 15) // 16) * 5 // 4
+                    T["builder_retries"] += 1
+                    T["device_call_s"] += time.perf_counter() - t0
+                    continue
+                if n_out:
+                    ctx.forward_p1_dev(dout.images.data_ptr(), n_out, probs.data_ptr())
+                    ctx.synchronize()   # raises if a split-form exchange timed out (the probabilities are then NaN)
+                T["device_call_s"] += time.perf_counter() - t0
+                break
+            t0 = time.perf_counter()
+            region_idx = dout.region[:n_out].cpu().numpy()
+            offs = dout.cand_off[:n_out + 1].cpu().numpy()
+            blob = dout.cand_str[:int(offs[-1]) if n_out else 0].cpu().numpy().tobytes()
+            cands = np.empty((n_out, 1), dtype=object)
+            for i in range(n_out):
+                cands[i, 0] = blob[offs[i]:offs[i + 1]].decode()
+            contigs = np.array([names[g][0] for g in region_idx], dtype="S") if n_out else np.zeros(0, dtype="S1")
+            rec = dict(region=region_idx, contigs=contigs, positions=dout.position[:n_out].cpu().numpy().astype(np.int32),
+                       depths=dout.depth[:n_out].cpu().numpy(), candidates=cands,
+                       candidate_frequency=dout.cand_freq[:n_out].cpu().numpy().reshape(-1, 1))
+            p = probs[:n_out].cpu().numpy()
+            imgs = dout.images[:n_out].cpu().numpy() if keep_images_path else None
+            T["readback_s"] += time.perf_counter() - t0
+            q.put((names, rec, p, imgs))
+            n_windows += n_out
+            del up
+    finally:
+        q.put(None)
+        writer.join()
+    if werr:
+        raise werr[0]
+    T["wall_s"] = time.perf_counter() - t_start
+    T["windows"] = n_windows
+    if timers is not None:
+        timers.update(T)
+    return n_windows

@@ -14,15 +14,15 @@ from .runtime import Context
 
 
 class Predictor:
-    def __init__(self, ctx: Context, state_dict: dict, plan: str = "p1"):
+    def __init__(self, ctx: Context, state_dict: dict, plan: str = "p1", dtype: int = 0):
         """state_dict: the checkpoint's 'model_state_dict' with the 'module.' prefixes stripped
         (ModelHander.py:30-41) as numpy arrays (or anything np.asarray accepts, e.g. CPU torch tensors)."""
         self.ctx, self.plan = ctx, plan
         w = {k[7:] if k.startswith("module.") else k: np.asarray(v, dtype=np.float32) for k, v in state_dict.items()}
         if plan == "p1":
-            ctx.load_p1(w)
+            ctx.load_p1(w, dtype)
         elif plan == "p2":
-            ctx.load_p2(w)
+            ctx.load_p2(w, dtype)
         else:
             raise ValueError(plan)
 

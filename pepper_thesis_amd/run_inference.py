@@ -37,7 +37,7 @@ def load_state_dict(model_path: str) -> dict:
     return {k: v.detach().cpu().numpy() for k, v in sd.items()}
 
 
-def predict_files(ctx, state_dict, input_files, output_file, batch_size=512, callers=16, timers=None):
+def predict_files(ctx, state_dict, input_files, output_file, batch_size=512, callers=16, timers=None, dtype=0):
     """predict() of predict_distributed_gpu.py:19-74 for a list of image files -> one prediction file.
     `timers` (optional dict) receives the stage times in seconds."""
     import time
@@ -45,7 +45,7 @@ def predict_files(ctx, state_dict, input_files, output_file, batch_size=512, cal
     from .predict import Predictor
     T = dict(hdf5_read_s=0.0, predict_call_s=0.0, hdf5_write_s=0.0)
     t_start = time.perf_counter()
-    predictor = Predictor(ctx, state_dict, "p1")
+    predictor = Predictor(ctx, state_dict, "p1", dtype)
     T["load_weights_s"] = time.perf_counter() - t_start
     n_windows, batch_no = 0, 0
     with PredictionStore(output_file, "w") as out:
@@ -76,35 +76,37 @@ def predict_files(ctx, state_dict, input_files, output_file, batch_size=512, cal
     return n_windows
 
 
-def main(argv=None):
-    ap = argparse.ArgumentParser(prog="run_inference")
-    ap.add_argument("-i", "--image_dir", required=True)
-    ap.add_argument("-m", "--model_path", required=True)
-    ap.add_argument("-o", "--output_dir", required=True)
-    ap.add_argument("-bs", "--batch_size", type=int, default=512)
-    ap.add_argument("-per_gpu", "--callers_per_gpu", type=int, default=16)
-    ap.add_argument("-d_ids", "--device_ids", type=str, default=None)
-    ap.add_argument("-g", "--gpu", action="store_true", default=True)
-    ap.add_argument("-t", "--threads", type=int, default=8)
-    ap.add_argument("-w", "--num_workers", type=int, default=0)
-    args = ap.parse_args(argv)
+def run(args):
+    from . import _ffi, cli
     from .dist import shard_regions
     from .runtime import Context
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    devs = [int(d) for d in args.device_ids.split(",")] if args.device_ids else None
-    device = devs[rank % len(devs)] if devs else int(os.environ.get("LOCAL_RANK", "0"))
+    if args.dry:
+        sys.stderr.write("ERROR: --dry turns training labels into predictions (predict_distributed_cpu_fake.py:12-52); it needs labelled "
+                         "training images and is not part of this build.\n")
+        return 2
+    if args.use_hp_info:
+        sys.stderr.write("ERROR: run_inference -hp: the reference's network hard-codes 33-row images (simple_model.py:35); haplotag-aware "
+                         "images have 21 rows and cannot be predicted by it.\n")
+        return 2
+    rank, world, device = cli.rank_world_device(args)
     files = sorted(glob.glob(os.path.join(args.image_dir, "*.hdf5")))
-    mine = [files[i] for i in shard_regions(len(files), rank, world)]
+    mine = [files[i] for i in shard_regions(len(files), rank, world)]   # files to callers i % callers (RunInference.py:101-106)
     os.makedirs(args.output_dir, exist_ok=True)
     name = "pepper_prediction.hdf" if world == 1 else "pepper_prediction_%d.hdf" % rank
     t0 = time.time()
     log("INFERENCE STARTING ON DEVICE %d: %d FILES" % (device, len(mine)))
     ctx = Context(device)
     n = predict_files(ctx, load_state_dict(args.model_path), mine, os.path.join(args.output_dir, name),
-                      args.batch_size, args.callers_per_gpu)
+                      args.batch_size, max(1, int(args.callers_per_gpu)) * 4,
+                      dtype=_ffi.PV_DTYPE_BF16_INPUT_GEMM if args.bf16 else _ffi.PV_DTYPE_F32)
     ctx.close()
     log("FINISHED PREDICTION: %d WINDOWS IN %.2f SEC" % (n, time.time() - t0))
+    return 0
+
+
+def main(argv=None):
+    from . import cli
+    return run(cli.run_inference_parser().parse_args(argv))
 
 
 if __name__ == "__main__":

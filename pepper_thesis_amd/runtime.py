@@ -233,6 +233,22 @@ class Context:
             self.handle, C.byref(dbatch.c), C.byref(cp), dbatch.n_reads, dbatch.n_bases, dbatch.n_cigar,
             dbatch.n_ref_bytes, dbatch.max_region_len, C.byref(dout.c), dout.counts.data_ptr(), stream or None))
 
+    def upload_batch(self, batch: RegionBatch, stream: int = 0):
+        """host batch -> the context's workspace (pv_upload_batch); returns (pv_batch_in with device pointers, totals) for
+        summarize_uploaded. Valid until the next upload on this context."""
+        cin = batch.as_c()
+        dev = _ffi.pv_batch_in()
+        totals = (C.c_int64 * 4)()
+        _ffi.check(self.lib.pv_upload_batch(self.handle, C.byref(cin), C.byref(dev), totals, stream or None))
+        return dev, [int(v) for v in totals], cin   # cin keeps the host arrays referenced until the copies are done
+
+    def summarize_uploaded(self, uploaded, params: Params, dout: "DeviceOut", max_region_len: int = 0, stream: int = 0):
+        """the device-resident builder on a batch staged with upload_batch; counters land in dout.counts"""
+        dev, (n_reads, n_bases, n_cigar, n_ref), _ = uploaded
+        cp = params.as_c()
+        _ffi.check(self.lib.pv_summarize_regions_dev(self.handle, C.byref(dev), C.byref(cp), n_reads, n_bases, n_cigar, n_ref,
+                                                     int(max_region_len), C.byref(dout.c), dout.counts.data_ptr(), stream or None))
+
     def summarize_hp_dev(self, dbatch: "DeviceBatch", params: Params, dout: "DeviceOut", stream: int = 0):
         """asynchronous, device-resident haplotag-aware builder: dout.images must be an int8 [capacity,21,48] tensor"""
         cp = params.as_c()

@@ -246,3 +246,58 @@ def test_vcf_gz_and_tabix_roundtrip(tmp_path):
                 assert (beg >> 16) < len(raw) and beg < end
         n_intv = struct.unpack_from("<i", tbi, off)[0]; off += 4 + 8 * n_intv
     assert off == len(tbi)
+
+
+def test_libdeflate_and_zlib_backends_are_byte_identical(tmp_path):
+    """BGZF blocks inflate through libdeflate (dlopen) when the host has it, zlib otherwise: the same reads, byte for byte, and
+    the same inflated stream; PEPPER_INFLATE / pvio_set_inflate_backend switch"""
+    build.build_io()
+    rng = np.random.default_rng(9)
+    recs = bw.random_records(rng, 400, 8000, tid=0, mean_len=700, allow_skip=False)
+    fa, bam, _ = _small_files(tmp_path, recs)
+    got = {}
+    have = bamio.set_inflate_backend(True)
+    for use in ([True] if have else []) + [False]:
+        assert bamio.set_inflate_backend(use) == (use and have)
+        assert bamio.inflate_backend() == ("libdeflate" if use and have else "zlib")
+        reads = bamio.BamHandler(bam).get_reads("c1", 0, 8000, True, 0, 0)
+        got[use] = ([(r.pos, r.pos_end, r.bases, r.quals.tolist(), r.cigar.tolist(), r.mapq) for r in reads], bamio.bgzf_read_all(bam))
+    assert len(got[False][0]) > 100
+    if have:
+        assert got[True] == got[False]
+    bamio.set_inflate_backend(True)
+
+
+def test_corrupt_block_in_the_middle_of_a_query_is_an_error(tmp_path):
+    """a flipped byte inside a BGZF block's payload: the CRC32 trailer (or the inflate) catches it and the region query FAILS - it
+    must not come back with the reads before the damage as if the file ended there (both inflate backends)"""
+    build.build_io()
+    rng = np.random.default_rng(10)
+    recs = bw.random_records(rng, 3000, 60000, tid=0, mean_len=900, allow_skip=False)
+    fa, bam, _ = _small_files(tmp_path, recs)
+    raw = bytearray(open(bam, "rb").read())
+    # walk the blocks; damage one in the middle of the file
+    offs, p = [], 0
+    while p < len(raw):
+        offs.append(p)
+        p += int.from_bytes(raw[p + 16:p + 18], "little") + 1
+    assert len(offs) >= 6
+    victim = offs[len(offs) // 2]
+    n_good = len(bamio.BamHandler(bam).get_reads("c1", 0, 60000, True, 0, 0))
+    for kind in ("payload", "crc"):
+        bad = bytearray(raw)
+        if kind == "payload":
+            bad[victim + 18 + 40] ^= 0x5A
+        else:
+            nxt = victim + int.from_bytes(raw[victim + 16:victim + 18], "little") + 1
+            bad[nxt - 8] ^= 0xFF      # first byte of the CRC32 trailer
+        pth = str(tmp_path / ("bad_%s.bam" % kind))
+        open(pth, "wb").write(bytes(bad))
+        open(pth + ".bai", "wb").write(open(bam + ".bai", "rb").read())
+        for use in (True, False):
+            bamio.set_inflate_backend(use)
+            with pytest.raises(IOError) as ei:
+                bamio.BamHandler(pth).get_reads("c1", 0, 60000, True, 0, 0)
+            assert "BGZF" in str(ei.value) or "inflate" in str(ei.value) or "corrupt" in str(ei.value)
+    bamio.set_inflate_backend(True)
+    assert n_good > 1000

@@ -156,8 +156,46 @@ def test_call_variant_bam_to_vcf(hip_ctx, oracle_lib, tmp_path):
     w = synth.make_weights_p1(3, 3.0)
     np.savez(str(tmp_path / "model.npz"), **w)
     out = tmp_path / "out"
-    counts = call_variant.main(["-b", str(tmp_path / "reads.bam"), "-f", str(tmp_path / "ref.fa"), "-m", str(tmp_path / "model.npz"),
-                                "-o", str(out), "-s", "HG003", "--ont_r9_guppy5_sup", "-r", "chr20:2000-38000", "--region_size", "12000"])
+    base = ["-b", str(tmp_path / "reads.bam"), "-f", str(tmp_path / "ref.fa"), "-m", str(tmp_path / "model.npz"), "-s", "HG003",
+            "--ont_r9_guppy5_sup", "-r", "chr20:2000-38000", "--region_size", "12000"]
+    counts = call_variant.main(base + ["-o", str(out), "--keep_images"])   # the default, fused form (+ the image file for the checks below)
+    # the reference's three steps through image HDF5 files give the same files bit for bit: predictions, images, VCF text
+    out2 = tmp_path / "out_steps"
+    counts2 = call_variant.main(base + ["-o", str(out2), "--no_fused"])
+    assert counts2 == counts
+
+    def only(d, prefix):
+        (name,) = [p for p in os.listdir(d) if p.startswith(prefix)]
+        return d / name
+    with hdf5io.PredictionStore(str(only(out, "predictions_") / "pepper_prediction.hdf"), "r") as a, \
+            hdf5io.PredictionStore(str(only(out2, "predictions_") / "pepper_prediction.hdf"), "r") as b:
+        ba, bb = list(a.batches()), list(b.batches())
+    # (the two-step form reads the image groups back in HDF5 name order, the fused form writes them in interval order: the
+    # same records, bit for bit, under their keys)
+    def keyed(batches):
+        d = {}
+        for _, bt in batches:
+            for i in range(len(bt["positions"])):
+                key = (bytes(bt["contigs"][i]), int(bt["positions"][i]), str(bt["candidates"][i][0]))
+                assert key not in d
+                d[key] = (int(bt["depths"][i]), int(bt["candidate_frequency"][i][0]), bt["base_prediction"][i].tobytes())
+            assert bt["base_prediction"].dtype == np.float64 and bt["positions"].dtype == np.int32
+        return d
+    assert len(ba) == len(bb) >= 1 and keyed(ba) == keyed(bb) and len(keyed(ba)) > 100
+    with hdf5io.ImageStore(str(only(out, "images_") / "pepper_variants_images_thread_0.hdf5"), "r") as a, \
+            hdf5io.ImageStore(str(only(out2, "images_") / "pepper_variants_images_thread_0.hdf5"), "r") as b:
+        assert a.summaries() == b.summaries()
+        for nm in a.summaries():
+            x, y = a.read_summary(nm), b.read_summary(nm)
+            for key in x:
+                assert x[key].tolist() == y[key].tolist(), (nm, key)
+    import gzip as _gz
+    for fn in ("PEPPER_VARIANT_FULL.vcf.gz", "PEPPER_VARIANT_OUTPUT_VARIANT_CALLING.vcf.gz"):
+        assert _gz.open(out / fn, "rt").read() == _gz.open(out2 / fn, "rt").read()
+    # without --keep_images the fused form writes no image directory at all
+    out3 = tmp_path / "out_noimg"
+    assert call_variant.main(base + ["-o", str(out3)]) == counts
+    assert not [p for p in os.listdir(out3) if p.startswith("images_")]
     assert counts["total"] > 20 and counts["total"] == counts["pepper"] + counts["variant_calling"]
     import gzip
     vcf_text = gzip.open(out / "PEPPER_VARIANT_FULL.vcf.gz", "rt").read()

@@ -90,3 +90,86 @@ def test_interval_list_rules(tmp_path):
     assert make_images.list_intervals(f, b, None, 1000) == [("c1", 0, 1000), ("c1", 1000, 2000), ("c1", 2000, 2499)]
     assert make_images.list_intervals(f, b, "c1:500-9000", 1000) == [("c1", 500, 1500), ("c1", 1500, 2499)]
     assert make_images.list_intervals(f, b, "c1", 5000) == [("c1", 0, 2499)]
+
+
+# ---- the reference's command line (pepper_variant.py:34-91): every option name of its argparse definitions parses here ----------
+# (long / short names typed from pepper_variant/modules/argparse/{CallVariants,MakeImages,RunInference,FindCandidates}Arguments.py)
+_IMG = [("-d", "0.5"), ("--downsample_rate", "0.5"), ("-r", "chr20:1-1000"), ("--region", "chr1-22"), ("--region_size", "50000"),
+        ("--region_bed", "x.bed"), ("-rb", "x.bed"), ("-hp", None), ("--use_hp_info", None), ("--include_supplementary", None),
+        ("--min_mapq", "3"), ("--min_snp_baseq", "2"), ("--min_indel_baseq", "2"), ("--snp_frequency", "0.2"), ("--insert_frequency", "0.2"),
+        ("--delete_frequency", "0.2"), ("--min_coverage_threshold", "4"), ("--candidate_support_threshold", "3"),
+        ("--snp_candidate_frequency_threshold", "0.2"), ("--indel_candidate_frequency_threshold", "0.2"), ("--skip_indels", None)]
+_INF = [("-bs", "256"), ("--batch_size", "256"), ("-g", None), ("--gpu", None), ("-per_gpu", "2"), ("--callers_per_gpu", "2"),
+        ("-d_ids", "0,1"), ("--device_ids", "0"), ("--quantized", None), ("--no_quantized", None), ("-w", "4"), ("--num_workers", "4")]
+_CAND = [("--allowed_multiallelics", "2")] + [("--" + n, "0.5") for n in (
+    "snp_p_value", "insert_p_value", "delete_p_value", "snp_p_value_in_lc", "insert_p_value_in_lc", "delete_p_value_in_lc", "snp_q_cutoff",
+    "indel_q_cutoff", "snp_q_cutoff_in_lc", "indel_q_cutoff_in_lc", "report_snp_above_freq", "report_indel_above_freq")]
+_PLATFORMS = ["--ont_r9_guppy5_sup", "--ont_r9_guppy4_hac", "--ont_r10_q20", "--hifi", "--clr"]
+
+
+def _each(parser_fn, required, options):
+    for opt, val in options:
+        argv = list(required) + [opt] + ([val] if val is not None else [])
+        a = parser_fn().parse_args(argv)
+        assert a is not None, opt
+
+
+def test_call_variant_accepts_every_reference_option():
+    from pepper_thesis_amd import cli
+    req = ["-b", "x.bam", "-f", "x.fa", "-m", "m.pkl", "-o", "out", "-s", "S", "-t", "8", "--ont_r9_guppy5_sup"]
+    _each(cli.call_variant_parser, req, _IMG + _INF + _CAND)
+    for pf in _PLATFORMS:
+        cli.call_variant_parser().parse_args(["--bam", "x.bam", "--fasta", "x.fa", "--model_path", "m", "--output_dir", "o", "--sample_name", "S",
+                                              "--threads", "4", pf])
+    with pytest.raises(SystemExit):   # exactly one platform flag is required (CallVariantsArguments.py: mutually exclusive group)
+        cli.call_variant_parser().parse_args(req[:-1])
+    with pytest.raises(SystemExit):
+        cli.call_variant_parser().parse_args(req + ["--hifi"])
+    a = cli.call_variant_parser().parse_args(req)
+    assert (a.batch_size, a.callers_per_gpu, a.region_size, a.downsample_rate, a.num_workers, a.quantized) == (512, 4, 100000, 1.0, 0, False)
+    assert a.fused and not a.keep_images
+
+
+def test_make_images_run_inference_find_candidates_accept_every_reference_option():
+    from pepper_thesis_amd import cli
+    _each(cli.make_images_parser, ["-b", "x.bam", "-f", "x.fa", "-o", "out", "-t", "4", "--hifi"], _IMG)
+    _each(cli.run_inference_parser, ["-i", "img", "-m", "m.pkl", "-o", "out"],
+          _INF + [("-t", "8"), ("--threads", "8"), ("-hp", None), ("--use_hp_info", None), ("--dry", None), ("--ont_r9_guppy5_sup", None)])
+    _each(cli.find_candidates_parser, ["-i", "pred", "-b", "x.bam", "-f", "x.fa", "-s", "S", "-o", "out", "-t", "4", "--clr"],
+          _CAND + [("-hp", None), ("--freq_based", None), ("--freq", "0.2")])
+
+
+def test_dispatcher_and_refusals(capsys):
+    """`python -m pepper_thesis_amd <sub-command>` (pepper_variant.py:34-91): --version, unknown / missing sub-command, --dry refused"""
+    from pepper_thesis_amd import cli
+    assert cli.main(["--version"]) == 0
+    assert "PEPPER VERSION" in capsys.readouterr().out
+    assert cli.main([]) == 2
+    assert cli.main(["merge_variants"]) == 2
+    assert cli.main(["run_inference", "-i", "img", "-m", "m", "-o", "out", "--dry"]) == 2
+    assert "--dry" in capsys.readouterr().err
+    assert cli.main(["call_variant", "-b", "x", "-f", "x", "-m", "m", "-o", "o", "--hifi", "-hp"]) == 2
+
+
+def test_region_grammar():
+    """-r: comma lists, name:start-end, ranges chr1-22 (ImageGenerationUI.py:131-169); --region_bed is parsed (train-mode only use)"""
+    e = make_images.expand_region_names
+    assert e("chr20") == ["chr20"] and e("chr20:1-1000000") == ["chr20:1-1000000"]
+    assert e("chr1-3") == ["chr1", "chr2", "chr3"] and e("3-1") == ["1", "2", "3"]
+    assert e("chr1-2:5-10, chrX") == ["chr1:5-10", "chr2:5-10", "chrX"]
+    assert len(e("chr1-22")) == 22
+
+
+def test_region_bed_is_validated_not_applied(tmp_path):
+    build.build_io()
+    bw.write_fasta(str(tmp_path / "r.fa"), [("c1", "ACGT" * 625)])
+    bw.write_bam(str(tmp_path / "r.bam"), [("c1", 2500)], [])
+    b, f = bamio.BamHandler(str(tmp_path / "r.bam")), bamio.FastaHandler(str(tmp_path / "r.fa"))
+    bed = tmp_path / "hc.bed"
+    bed.write_text("c1\t100\t200\nc1\t900\t300\n")
+    assert make_images.read_bed(str(bed)) == {"c1": [[100, 200], [300, 900]]}
+    assert make_images.list_intervals(f, b, "c1", 1000, str(bed)) == make_images.list_intervals(f, b, "c1", 1000)
+    bad = tmp_path / "bad.bed"
+    bad.write_text("c1\tabc\t5\n")
+    with pytest.raises(ValueError):
+        make_images.list_intervals(f, b, "c1", 1000, str(bad))

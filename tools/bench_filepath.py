@@ -1,5 +1,7 @@
-"""bench.py secondary leg: the REAL-FILE path — BAM + BAI / FASTA + FAI on disk -> make_images (native readers on a thread
-pool, HIP image builder, image HDF5) -> run_inference (image HDF5 -> HIP RNN -> prediction HDF5) — with stage timers.
+"""bench.py secondary leg: the REAL-FILE path with stage timers. Primary figure: the FUSED form call_variant runs by default
+(pipeline.call_variant_fused: BAM + BAI / FASTA + FAI on disk -> native readers on a thread pool -> HIP image builder -> the
+windows stay in HBM -> HIP RNN -> prediction HDF5 on a writer thread). Beside it the reference's two steps through image HDF5
+files: make_images (image HDF5) -> run_inference (image HDF5 -> HIP RNN -> prediction HDF5).
 The BAM is synthetic (SURVEY 8(d) shape: one contig of >= 1 Mbp at 60x, 10 kb reads, planted sites) and is written here
 with the library's own BAM writer (pvio_write_bam); nothing under oracle/ is used. Not part of `value`.
 
@@ -46,45 +48,57 @@ def make_files(dirname, contig_len, depth=60, read_len=10_000, site_every=198, s
     bam = os.path.join(dirname, "reads.bam")
     bamio.write_bam(bam, [("chr20", contig_len)], np.zeros(b.n_reads, np.int32), b, level=1)
     return bam, fa, dict(reads=b.n_reads, bases=b.n_bases, synth_and_write_s=time.perf_counter() - t0,
-                         bam_bytes=os.path.getsize(bam))
+                         bam_bytes=os.path.getsize(bam), inflate_backend=bamio.inflate_backend())
 
 
 def run(ctx, weights, dev=None, mbp=3.2, keep_dir=None):
-    from pepper_thesis_amd import make_images, run_inference
+    from pepper_thesis_amd import make_images, pipeline, run_inference
     from pepper_thesis_amd.batch import PRESETS
     d = keep_dir or tempfile.mkdtemp(prefix="pv_filepath_")
     try:
         contig_len = int(mbp * 1_000_000)
         bam, fa, info = make_files(d, contig_len)
         P = PRESETS["ont_r9_guppy5_sup"]
+        swept = contig_len / 1e6
         # warm the page cache and the workspaces with a small region (untimed)
-        make_images.generate_images(ctx, bam, fa, os.path.join(d, "warm"), P, region="chr20:0-50000", min_mapq=5)
+        pipeline.call_variant_fused(ctx, weights, bam, fa, os.path.join(d, "warm", "p.hdf"), P, region="chr20:0-50000", min_mapq=5)
+        t_f = {}
+        n = pipeline.call_variant_fused(ctx, weights, bam, fa, os.path.join(d, "pred_fused", "pepper_prediction.hdf"), P, min_mapq=5, timers=t_f)
+        gpu_f = t_f["upload_s"] + t_f["device_call_s"] + t_f["readback_s"]
+        out = {
+            "workload": "synthetic chr20 of %.2f Mbp at 60x (10 kb reads): %d reads, %.1f M bases, BAM %.1f MB; %d intervals of 100 kb"
+                        % (swept, info["reads"], info["bases"] / 1e6, info["bam_bytes"] / 1e6, t_f["intervals"]),
+            "form": "fused (call_variant default): windows stay in HBM between the builder and the network, no image files",
+            "windows": n, "mbp_per_s": swept / t_f["wall_s"], "windows_per_s": n / t_f["wall_s"], "wall_s": t_f["wall_s"],
+            "reader_threads": t_f["reader_threads"], "inflate_backend": info.get("inflate_backend"),
+            "bgzf_inflate_cpu_s": t_f["read_inflate_cpu_s"], "record_decode_clip_cpu_s": t_f["read_decode_cpu_s"],
+            "inflate_MBps_per_thread": t_f["bytes_inflated"] / max(t_f["read_inflate_cpu_s"], 1e-9) / 1e6,
+            "main_thread_waiting_for_readers_s": t_f["reader_stall_s"], "merge_s": t_f["merge_s"], "upload_s": t_f["upload_s"],
+            "device_call_s(builder+rnn kernels)": t_f["device_call_s"], "readback_s": t_f["readback_s"],
+            "hdf5_write_s(writer thread)": t_f["hdf5_write_s"], "load_weights_s": t_f["load_weights_s"],
+            "host_share": 1.0 - gpu_f / t_f["wall_s"],
+            "note": "host share = 1 - (uploads + kernels + read-backs) / wall; the readers inflate BGZF on %d threads ahead of the GPU, "
+                    "the prediction file is written by its own thread" % t_f["reader_threads"],
+        }
+        # the reference's two steps through image files, for comparison
         t_img = {}
-        n = make_images.generate_images(ctx, bam, fa, os.path.join(d, "images"), P, min_mapq=5, timers=t_img)
+        n1 = make_images.generate_images(ctx, bam, fa, os.path.join(d, "images"), P, min_mapq=5, timers=t_img)
         t_inf = {}
         files = [os.path.join(d, "images", f) for f in sorted(os.listdir(os.path.join(d, "images"))) if f.endswith(".hdf5")]
         os.makedirs(os.path.join(d, "pred"), exist_ok=True)
         n2 = run_inference.predict_files(ctx, weights, files, os.path.join(d, "pred", "pepper_prediction.hdf"), 512, 16, timers=t_inf)
-        assert n2 == n, (n, n2)
-        swept = contig_len / 1e6
+        assert n2 == n1 == n, (n, n1, n2)
         wall = t_img["wall_s"] + t_inf["wall_s"]
-        gpu_calls = t_img["builder_call_s"] + t_inf["predict_call_s"]
-        return {
-            "workload": "synthetic chr20 of %.2f Mbp at 60x (10 kb reads): %d reads, %.1f M bases, BAM %.1f MB; %d intervals of 100 kb"
-                        % (swept, info["reads"], info["bases"] / 1e6, info["bam_bytes"] / 1e6, t_img["intervals"]),
-            "windows": n, "mbp_per_s": swept / wall, "windows_per_s": n / wall,
-            "make_images": {"wall_s": t_img["wall_s"], "mbp_per_s": swept / t_img["wall_s"], "reader_threads": t_img["reader_threads"],
-                            "bgzf_inflate_cpu_s": t_img["read_inflate_cpu_s"], "record_decode_clip_cpu_s": t_img["read_decode_cpu_s"],
-                            "inflate_MBps_per_thread": t_img["bytes_inflated"] / max(t_img["read_inflate_cpu_s"], 1e-9) / 1e6,
+        out["two_step"] = {
+            "mbp_per_s": swept / wall, "windows_per_s": n / wall,
+            "make_images": {"wall_s": t_img["wall_s"], "mbp_per_s": swept / t_img["wall_s"],
                             "main_thread_waiting_for_readers_s": t_img["reader_stall_s"],
-                            "merge_s": t_img["merge_s"], "builder_call_s(h2d+kernels+d2h)": t_img["builder_call_s"], "hdf5_write_s": t_img["hdf5_write_s"]},
-            "run_inference": {"wall_s": t_inf["wall_s"], "windows_per_s": n / t_inf["wall_s"], "hdf5_read_s": t_inf["hdf5_read_s"],
-                              "predict_call_s(h2d+kernels+d2h)": t_inf["predict_call_s"], "hdf5_write_s": t_inf["hdf5_write_s"],
-                              "load_weights_s": t_inf["load_weights_s"]},
-            "host_share": 1.0 - gpu_calls / wall,
-            "note": "host share = 1 - (time inside the builder and RNN calls, PCIe copies included) / wall; the readers inflate BGZF on "
-                    "%d threads ahead of the GPU" % t_img["reader_threads"],
+                            "builder_call_s(h2d+kernels+d2h)": t_img["builder_call_s"], "hdf5_write_s": t_img["hdf5_write_s"]},
+            "run_inference": {"wall_s": t_inf["wall_s"], "hdf5_read_s": t_inf["hdf5_read_s"],
+                              "predict_call_s(h2d+kernels+d2h)": t_inf["predict_call_s"], "hdf5_write_s": t_inf["hdf5_write_s"]},
+            "host_share": 1.0 - (t_img["builder_call_s"] + t_inf["predict_call_s"]) / wall,
         }
+        return out
     finally:
         if keep_dir is None:
             shutil.rmtree(d, ignore_errors=True)
