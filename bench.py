@@ -7,9 +7,10 @@ offline, so inputs are the synthetic shapes SURVEY.md 8(d) fixes (R = 100 200 co
 10 kb reads, planted sites for ~500 windows per region; random-init weights of the pepper_variant
 architecture).
 
-One STEP = one 100.2 kb region through the image builder + one 512-window batch through the RNN
-(every window the region yields is inferred; the batch is topped up to exactly 512 with resident
-synthetic windows; `windows_from_builder_per_s` counts only what the builder produced). Like the
+One STEP = one 100.2 kb region through the image builder + one 512-window batch through the RNN. The
+planted sites give every region a few more than 512 windows (~527) and the builder's output capacity is
+512 per step, so EVERY counted window was produced by the image builder in the same chain and inferred
+(the builder does the work for the ~3 % it then drops); nothing is topped up. Like the
 reference's `callers_per_gpu` (RunInferenceArguments.py:67-74) the host loop keeps CALLERS = 16 steps in
 flight by fusing them into ONE launch chain (16 regions per builder call, 8192 windows per RNN call).
 
@@ -44,7 +45,7 @@ CALLERS = int(os.environ.get("PV_BENCH_CALLERS", "16"))  # steps fused per launc
 REGION_LEN = 100_200             # 100 kb interval + 2 x 100 safe bases (AlignmentSummarizer.py:181-182)
 DEPTH = 60
 READ_LEN = 10_000
-SITE_EVERY = int(os.environ.get("PV_BENCH_SITE_EVERY", "198"))  # planted sites: ~495-505 windows per region (~500)
+SITE_EVERY = int(os.environ.get("PV_BENCH_SITE_EVERY", "188"))  # planted sites: ~525-535 windows per region (~500): >= 512 each
 FLOP_PER_WINDOW = 161_328_128
 FLOP_DEC_PER_WINDOW = 103_809_024
 FLOP_ENC_PER_WINDOW = 38_117_376
@@ -155,22 +156,25 @@ def pmc_traffic():
         return {}
     out = {"note": "HBM bytes/launch from %s (FETCH_SIZE x2 + WRITE_SIZE; the x2 of the guide's wide-load correction over-counts "
                    "where raw FETCH_SIZE already equals the input bytes)" % os.path.basename(files[-1])}
-    builder = 0.0
+    builder = builder_raw = 0.0
     for row in csv.DictReader(open(files[-1])):
         k = row["kernel"]
         b = float(row["hbm_read_bytes_x2(gfx950 wide loads)"]) + float(row["hbm_write_bytes"])
+        braw = float(row["hbm_read_bytes_raw"]) + float(row["hbm_write_bytes"])
         if "k_lstm_layer<512" in k:
             out["k_lstm_layer<512"] = b
         if any(t in k for t in ("k_cigar_scan", "k_tile_fill", "k_pileup", "k_site", "k_collect", "k_write_windows", "k_scan")):
             builder += b
+            builder_raw += braw
     out["builder"] = builder
+    out["builder_raw"] = builder_raw
     return out
 
 
 def bf16_secondary(device_id, weights, dbatch, P, dev, pad, groups=6):
     """BASELINE configs[2] flavour: the same step (1 region + 512 windows, 16 fused per launch chain) with
-    PV_DTYPE_BF16_INPUT_GEMM: decoder input projection and linear_1 on the bf16 MFMA as a 3-term hi/lo split
-    (softmax still within 1e-4 of the reference), recurrence fp32. Not part of `value`."""
+    PV_DTYPE_BF16_INPUT_GEMM: EVERY matrix product of the two LSTM layers and linear_1 on the bf16 MFMA as 3-term hi/lo
+    splits (softmax within 1e-4 of the reference: tests/test_rnn_gpu.py), cell updates and linear_2..5 fp32. Not part of `value`."""
     import torch
     from pepper_thesis_amd import _ffi, runtime
     from pepper_thesis_amd.device import DeviceOut
@@ -195,7 +199,8 @@ def bf16_secondary(device_id, weights, dbatch, P, dev, pad, groups=6):
     prof = c2.profile_end()
     c2.close()
     gname = next((k for k in prof if k.startswith("k_gemm_bf16x3_dec")), None)
-    out = {"value": groups * CALLERS * BATCH / dt, "unit": "windows/s", "dtype": "bf16x3 input GEMMs + f32 recurrence",
+    out = {"value": groups * CALLERS * BATCH / dt, "unit": "windows/s", "dtype": "bf16x3 (3-term split bf16 MFMA, fp32 accumulate) for the input "
+                                                                                   "projections, the recurrent products and linear_1",
            "steps": groups * CALLERS, "ms_per_step": dt / (groups * CALLERS) * 1e3,
            "kernel_ms": {k: v[0] / max(v[1], 1) for k, v in prof.items() if k.startswith("k_") and "summary" not in k}}
     if gname:
@@ -204,6 +209,14 @@ def bf16_secondary(device_id, weights, dbatch, P, dev, pad, groups=6):
         out["input_gemm"] = {"kernel": "%s (decoder input projection, M=%d N=2048 K=512, 3 bf16 MFMA terms)" % (gname, CALLERS * BATCH * 33),
                              "launch_ms": gemm_ms, "achieved": flop / gemm_ms / 1e9, "peak": PEAK_BF16_TFLOPS,
                              "unit": "TFLOP/s (bf16 MFMA)", "frac": flop / gemm_ms / 1e9 / PEAK_BF16_TFLOPS}
+        out["frac"] = out["input_gemm"]["frac"]
+    rec = [k for k in prof if k.startswith("k_rec_bf16_lstm_dec")]
+    if rec:
+        ms = prof[rec[0]][0] / prof[rec[0]][1]
+        flop = 3 * 2.0 * (CALLERS * BATCH * 33) * 2048 * 256   # h . W_hh^T, both directions, three bf16 terms
+        out["recurrence"] = {"kernel": "k_rec_bf16<LSTM, decoder> (h . W_hh^T on the bf16 MFMA, 64-row tiles)", "launch_ms": ms,
+                             "achieved": flop / ms / 1e9, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s (bf16 MFMA)",
+                             "frac": flop / ms / 1e9 / PEAK_BF16_TFLOPS}
     return out
 
 
@@ -232,7 +245,7 @@ def p2_secondary(ctx, dev):
                                   "windows_100col_per_s": 1000 / dt, "kernel_ms": kms,
                                   "kernel_tflops": 80_435_200 * 1000 / kms / 1e9 if kms > 0 else None,
                                   "frac_of_f32_peak": 80_435_200 * 1000 / kms / 1e9 / PEAK_F32_TFLOPS if kms > 0 else None}
-    for B in (64, 1000, 8192):
+    for B in (64, 1000, 2048, 4096, 8192):
         x = torch.from_numpy(synth.synth_p2_images(7, B)).to(dev)
         labels = torch.zeros((B, 1000), dtype=torch.uint8, device=dev)
         _ffi.check(lib.pv_rnn_forward_p2_dev(ctx.handle, x.data_ptr(), B, labels.data_ptr(), None, None))
@@ -245,6 +258,51 @@ def p2_secondary(ctx, dev):
         out["B%d" % B] = {"ms": ms, "chunks_per_s": B / ms * 1e3, "windows_100col_per_s": 19 * B / ms * 1e3,
                           "tflops": 80_435_200 * 19 * B / ms / 1e9, "frac_of_f32_peak": 80_435_200 * 19 * B / ms / 1e9 / PEAK_F32_TFLOPS}
         del x, labels
+    # the same model with every matrix product on the bf16 MFMA (PV_DTYPE_BF16_INPUT_GEMM: layer-wise path, per-window GEMM)
+    try:
+        from pepper_thesis_amd import runtime
+        cb = runtime.Context(ctx.device_id)
+        cb.load_p2(synth.make_weights_p2(4321), _ffi.PV_DTYPE_BF16_INPUT_GEMM)
+        bf = {"dtype": "bf16x3 (3-term split bf16 MFMA, fp32 accumulate) for input projections and recurrent products"}
+        cb.forward_p2_window(xw)
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            cb.forward_p2_window(xw)
+        dtw = (time.perf_counter() - t0) / reps
+        bf["single_window_B1000"] = {"ms_per_call": dtw * 1e3, "windows_100col_per_s": 1000 / dtw}
+        for B in (64, 1000, 2048, 4096, 8192):
+            x = torch.from_numpy(synth.synth_p2_images(7, B)).to(dev)
+            labels = torch.zeros((B, 1000), dtype=torch.uint8, device=dev)
+            _ffi.check(lib.pv_rnn_forward_p2_dev(cb.handle, x.data_ptr(), B, labels.data_ptr(), None, None))
+            cb.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(2):
+                _ffi.check(lib.pv_rnn_forward_p2_dev(cb.handle, x.data_ptr(), B, labels.data_ptr(), None, None))
+            cb.synchronize()
+            ms = (time.perf_counter() - t0) / 2 * 1e3
+            cb.profile_begin()
+            _ffi.check(lib.pv_rnn_forward_p2_dev(cb.handle, x.data_ptr(), B, labels.data_ptr(), None, None))
+            prof = cb.profile_end()
+            bf["B%d" % B] = {"ms": ms, "windows_100col_per_s": 19 * B / ms * 1e3, "speedup_over_f32_form": out["B%d" % B]["ms"] / ms,
+                             "kernel_ms_sum": {k: v[0] for k, v in prof.items()}}
+            gk = [k for k in prof if k.startswith("k_gemm_bf16x3")]
+            if gk:
+                gms = prof[gk[0]][0] / prof[gk[0]][1]
+                bp = (B + 31) // 32 * 32 if B * 2 <= 64 * 2 * 256 else (B + 63) // 64 * 64
+                flop = 3 * 2.0 * (100 * bp) * 768 * 256
+                bf["B%d" % B]["input_gemm"] = {"launch_ms": gms, "achieved": flop / gms / 1e9, "peak": PEAK_BF16_TFLOPS,
+                                               "unit": "TFLOP/s (bf16 MFMA)", "frac": flop / gms / 1e9 / PEAK_BF16_TFLOPS}
+            del x, labels
+        cb.close()
+        out["bf16_mode"] = bf
+    except Exception as e:  # noqa: BLE001
+        out["bf16_mode"] = {"error": repr(e)}
+    # the polisher chain: summary images of 8 regions -> their chunks through the bi-GRU without leaving HBM (tools/bench_polish.py)
+    try:
+        from tools import bench_polish
+        out["polish_chain"] = bench_polish.run(ctx, dev)
+    except Exception as e:  # noqa: BLE001
+        out["polish_chain"] = {"error": repr(e)}
     return out
 
 
@@ -527,8 +585,8 @@ def main(argv=None):
         ctx.summarize_dev(db, P, douts[0], stream=s_build.cuda_stream)
         s_build.synchronize()
         assert douts[0].status() == 0, "device status %d" % douts[0].status()
-        n_out_batch.append(douts[0].n_out())
-        assert n_out_batch[-1] <= CALLERS * BATCH, "regions yield %d windows > %d: raise PV_BENCH_SITE_EVERY" % (n_out_batch[-1], CALLERS * BATCH)
+        n_out_batch.append(douts[0].n_out())   # windows the regions yield; those beyond the capacity (512 per step) are dropped
+        assert n_out_batch[-1] >= CALLERS * BATCH, "regions yield %d windows < %d: lower PV_BENCH_SITE_EVERY" % (n_out_batch[-1], CALLERS * BATCH)
     ctx.forward_p1_dev(wins[0].data_ptr(), CALLERS * BATCH, probs_holder["t"][0].data_ptr(), stream=s_rnn.cuda_stream)  # RNN workspace at full size
     s_rnn.synchronize()
     # image-builder roofline: measured in isolation (16 regions per launch chain), cold inputs (round-robin batches)
@@ -544,7 +602,7 @@ def main(argv=None):
     eb1.record(s_build)
     eb1.synchronize()
     builder_chain_ms = eb0.elapsed_time(eb1) / 12
-    n_windows_region = n_out_batch[0]
+    n_windows_region = n_out_batch[0]                    # yielded by the 16 regions of batch 0 (written: at most 512 per step)
     for g, nc in enumerate(wchains):
         group(g, nc)
     drain()
@@ -624,7 +682,7 @@ def main(argv=None):
     if rank == 0:
         total_windows = total_steps * BATCH * world
         value = total_windows / dt
-        builder_windows = sum(n_out_batch[g % NBATCH] for g in range(n_chains)) * world   # what the builder really produced
+        builder_windows = sum(min(n_out_batch[g % NBATCH], CALLERS * BATCH) for g in range(n_chains)) * world   # == total_windows
         dec_ms, dec_n = prof.get("k_lstm_layer_dec", (0.0, 0))
         dec_launch_ms = dec_ms / max(dec_n, 1)
         flop_per_launch = FLOP_DEC_PER_WINDOW * CALLERS * BATCH
@@ -632,7 +690,7 @@ def main(argv=None):
         sum_ms, sum_n = prof_builder.get("summary_pipeline", (0.0, 0))
         pile_ms, pile_n = prof_builder.get("k_pileup", (0.0, 0))
         traffic = pmc_traffic()
-        alg_bytes = batch.algorithmic_bytes(n_windows_region)
+        alg_bytes = batch.algorithmic_bytes(min(n_windows_region, CALLERS * BATCH))
         out = {
             "metric": "pileup windows/sec (whole node) + Mbp/sec inferred, HG003 chr20 ONT R9",
             "value": value, "unit": "windows/s", "n_gpus": world, "steps": K, "warmup": W,
@@ -641,6 +699,8 @@ def main(argv=None):
             "repeats": R, "timed_steps": total_steps, "timed_seconds": dt,
             "median_chain_ms": median_chain_ms, "windows_per_s_from_median_chain": CALLERS * BATCH * world / (median_chain_ms / 1e3),
             "windows_from_builder_per_s": builder_windows / dt,
+            "windows_note": "every counted window was written by the image builder of the same launch chain (capacity 512 per step; the "
+                            "regions yield %.1f per step, the surplus is dropped after the builder's work for it) and inferred" % (n_windows_region / CALLERS),
             "config": {"workload": "configs[1]: HG003-chr20-shaped ONT R9 synthetic, batch=512 windows/step, fp32 bi-LSTM P1, "
                                    "1 region (R=100200, 60x, 10 kb reads) per step, %d steps fused per launch chain" % CALLERS,
                        "batch": BATCH, "callers": CALLERS, "region_len": REGION_LEN, "depth": DEPTH,
@@ -658,7 +718,10 @@ def main(argv=None):
                                  "achieved": alg_bytes / (builder_chain_ms / 1e3) / 1e9,
                                  "peak": PEAK_HBM_GBS, "unit": "GB/s",
                                  "frac": alg_bytes / (builder_chain_ms / 1e3) / 1e9 / PEAK_HBM_GBS,
-                                 "traffic": traffic.get("builder"), "launch_ms": builder_chain_ms,
+                                 "traffic": traffic.get("builder"), "traffic_raw": traffic.get("builder_raw"),
+                                 "traffic_raw_note": "FETCH_SIZE as counted + WRITE_SIZE (the builder's loads are dwords and bytes, for which the guide's "
+                                                     "x2 of wide coalesced loads does not apply)",
+                                 "launch_ms": builder_chain_ms,
                                  "launch_ms_with_kernel_events": sum_ms / max(sum_n, 1),
                                  "k_pileup_ms": pile_ms / max(pile_n, 1),
                                  "measured": "in isolation, before the timed region: 12 launch chains back to back (launch_ms), and the "
