@@ -99,6 +99,9 @@ typedef struct pv_params {
  *   cigar words use BAM packing: (length << 4) | op.
  *   bases are normally the upper-case symbols bam_handler.cpp emits (seq_nt16_str "=ACMGRSVTWYHKDBN"),
  *   but ANY byte is handled exactly as the reference would (raw-byte SNP keys, toupper for planes). */
+/* Limits: a region may hold at most 32767 reads (the per-column counters are 16-bit; the reference's caller keeps at most
+ * MAX_READS_IN_REGION = 5000, pepper_variant/modules/python/Options.py:98, AlignmentSummarizer.py:191-208). Beyond that the
+ * host-buffer forms return PV_ERR_LIMIT and the device-resident forms report status PV_ERR_LIMIT in d_counts[2]. */
 typedef struct pv_batch_in {
     int32_t n_regions;
     int32_t reserved;

@@ -5,7 +5,8 @@
 // regions per call. It is an HBM-bound integer pipeline; nothing here is GEMM-shaped.
 //
 // Data layout in HBM (column = one reference position; global column id = ref_off[g] + i):
-//   cnt[NCNT][n_cols] int32, PLANE-MAJOR, so that the 64 lanes of a wave that walk 64 consecutive
+//   cnt[NCNT][n_cols] int16 (cnt_t: a count is bounded by the reads of its region, which k_init holds to <= 32767 - the
+//   reference's caller keeps at most MAX_READS_IN_REGION = 5000, pepper_variant/modules/python/Options.py:98), PLANE-MAJOR, so that the 64 lanes of a wave that walk 64 consecutive
 //   read bases touch 64 consecutive ints of one plane (coalesced atomics / loads):
 //     0 coverage  1 snp_count  2 insert_count  3 delete_count  4 rare-event count
 //     5 + 8*strand + {0 REF, 1 A, 2 C, 3 G, 4 T, 5 I, 6 D, 7 *}   (the 16 accumulated planes of the
@@ -35,6 +36,8 @@
 namespace {
 
 constexpr int NCNT = 21;
+typedef int16_t cnt_t;               // element of the global counter planes (they were int32: half the flush and gather bytes)
+constexpr int MAX_REGION_READS = 32767;
 constexpr int C_COV = 0, C_SNP = 1, C_INS = 2, C_DEL = 3, C_RARE = 4, C_PLANE = 5;
 // haplotag-aware builder (region_summary_hp.cpp): the same four site counters, then 4 groups (set 1 fwd, set 1 rev,
 // set 2 fwd, set 2 rev) x {REF count, A, C, G, T, I, D, *} holding the FINAL signed plane values (window plane
@@ -47,6 +50,7 @@ constexpr int TILE_COLS = 512;  // columns per pileup tile (one workgroup accumu
 
 enum { D_SPARE = 8 };
 enum { D_NSITES = 0, D_NEVENTS = 1, D_NOUT = 2, D_STRBYTES = 3, D_STATUS = 4, D_NPAIRS = 5, D_NINS = 6, D_NROWS = 7, D_NCHUNKS = 8, D_NBIG = 9, D_NDIAG = 10 };
+enum { D_DEPTH = D_NDIAG + 7 };      // set (with status PV_ERR_LIMIT) when a region holds more reads than the 16-bit planes can count
 
 struct Event {  // 16 B
     int64_t src;  // index into bases (kind 1) or ref (kind 2)
@@ -118,7 +122,7 @@ struct SumArgs {
     int64_t n_tiles;
     int64_t max_pairs;
     int32_t qmin_snp;    // smallest integer quality q with (double)q >= min_snp_baseq (exact: q is an integer)
-    int32_t* cnt;
+    cnt_t* cnt;
     uint8_t* flags;
     int32_t* blk_cnt;
     int32_t* site_col;
@@ -986,7 +990,7 @@ __global__ __launch_bounds__(PT_THREADS, HP ? 2 : 4) void k_pileup_tiles(SumArgs
 #pragma unroll
                 for (int st = 0; st < 2; st++) {
                     const int grp = 2 * set + st;
-                    int32_t* dst = a.cnt + (int64_t)(HC_PLANE + 8 * grp) * NC + g;
+                    cnt_t* dst = a.cnt + (int64_t)(HC_PLANE + 8 * grp) * NC + g;
                     dst[0] = -(s_cnt[HL_REFC + 2 * (1 + set) + st][SW(lc)] + s_cnt[HL_REFC + 2 * 3 + st][SW(lc)]);
                     const int m = s_cnt[HL_M + 2 * set + st][SW(lc)] + s_cnt[HL_M + 2 * 2 + st][SW(lc)];
 #pragma unroll
@@ -2203,11 +2207,7 @@ __global__ __launch_bounds__(256) void k_polish_chunks(SumArgs a) {
 // and two memsets)
 __global__ __launch_bounds__(256) void k_init(SumArgs a) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-#ifdef PV_PSTAMPS
     if (i < D_NDIAG + 8) a.diag[i] = 0;
-#else
-    if (i < D_NDIAG) a.diag[i] = 0;
-#endif
     if (i < a.n_tiles) {
         a.tile_cnt[i] = 0;
         a.tile_fill[i] = 0;
@@ -2215,6 +2215,16 @@ __global__ __launch_bounds__(256) void k_init(SumArgs a) {
             a.blk_cnt[i] = 0;
             a.tile_g0[i] = thread_count_le(a.in.ref_off, a.in.n_regions + 1, i * TILE_COLS) - 1;
         }
+    }
+}
+
+// a read reaches a column at most once, so a region's read count bounds every counter of its columns: the 16-bit planes are
+// exact while it stays within MAX_REGION_READS. (Runs behind k_init, which zeroes the status words.)
+__global__ __launch_bounds__(256) void k_check_depth(SumArgs a) {
+    const int g = blockIdx.x * 256 + threadIdx.x;
+    if (g < a.in.n_regions && a.in.read_off[g + 1] - a.in.read_off[g] > MAX_REGION_READS) {
+        a.diag[D_DEPTH] = 1;
+        set_status(a.diag, PV_ERR_LIMIT);
     }
 }
 
@@ -2289,6 +2299,7 @@ static int summarize_launch(pv_ctx* ctx, const pv_batch_in* in, const pv_params*
 
     pv_prof_scope ps_all(ctx, "summary_pipeline", st);
     k_init<<<grid_for(std::max<int64_t>(a.n_tiles, D_NDIAG + 8), 256), 256, 0, st>>>(a);
+    if (in->n_regions > 0) k_check_depth<<<grid_for(in->n_regions, 256), 256, 0, st>>>(a);
     if (n_reads > 0) { pv_prof_scope ps(ctx, "k_cigar_scan", st); k_cigar_scan<<<grid_for(n_reads, 4), 256, 0, st>>>(a); }
     k_scan_tiles<<<1, 1024, 0, st>>>(a);
     if (n_reads > 0) { pv_prof_scope ps(ctx, "k_tile_fill", st); k_tile_fill<<<grid_for(n_reads, 4), 256, 0, st>>>(a); }
@@ -2445,6 +2456,10 @@ static int summarize_host(pv_ctx* ctx, const pv_batch_in* in, const pv_params* p
     out->str_bytes = 0;
     if (out->capacity > 0 && out->cand_off) out->cand_off[0] = 0;
     if (G <= 0) return PV_OK;
+    for (int g = 0; g < G; g++)
+        PV_CHECK(in->read_off[g + 1] - in->read_off[g] <= MAX_REGION_READS, PV_ERR_LIMIT,
+                 "region %d holds %lld reads: the counter planes are 16-bit (at most %d reads per region; the reference's caller "
+                 "down-samples to 5000)", g, (long long)(in->read_off[g + 1] - in->read_off[g]), MAX_REGION_READS);
     pv_batch_in d;
     int64_t totals[4];
     int rc = pv_upload_batch(ctx, in, &d, totals, st);

@@ -114,6 +114,38 @@ def test_depth_5000_max_reads(hip_ctx, oracle_lib):
     assert int(o.depth.max()) == 125
 
 
+def test_region_read_limit_of_the_16_bit_planes(hip_ctx, oracle_lib):
+    """the per-column counters are 16-bit: a region with 32767 reads (every one over the same columns: coverage 32767, planes
+    at -32767) is still exact, one more read is refused with PV_ERR_LIMIT by the host form and reported as status by the
+    device-resident form"""
+    import torch
+    from pepper_thesis_amd import _ffi
+    from pepper_thesis_amd.batch import Read, Region
+    from pepper_thesis_amd.device import DeviceBatch, DeviceOut
+    rng = np.random.default_rng(12)
+    R = 120
+    ref = rng.choice(np.frombuffer(b"ACGT", np.uint8), size=R).astype(np.uint8)
+    alt = ref.copy()
+    alt[60] = ord("A") if ref[60] != ord("A") else ord("C")
+
+    def region(n):
+        reads = [Read.make(1000, "%dM" % R, (alt if i % 3 == 0 else ref).tobytes(), 20, is_reverse=bool(i & 1)) for i in range(n)]
+        return Region(1000, 1000 + R - 1, ref.tobytes(), reads, 1000, 1000 + R - 1)
+    P = PRESETS["ont_r9_guppy5_sup"]
+    b = pack_regions([region(32767)])
+    o = hip_ctx.summarize(b, P, True)
+    assert_summary_equal(o, summary_as_expected(oracle_lib.summarize(b, P, True)), "32767 reads")
+    assert len(o) == 1 and int(o.images_i32[0, 16, 4]) == -16384   # REFF: the 16384 forward reads (un-clamped plane), exact in 16 bits
+    big = pack_regions([region(32768)])
+    with pytest.raises(_ffi.PepperHipError) as e:
+        hip_ctx.summarize(big, P)
+    assert e.value.code == _ffi.PV_ERR_LIMIT and "32767" in str(e.value)
+    dout = DeviceOut(64, 1024)
+    hip_ctx.summarize_dev(DeviceBatch(big), P, dout)
+    hip_ctx.synchronize()
+    assert dout.status() == _ffi.PV_ERR_LIMIT
+
+
 def test_every_column_a_site_triggers_workspace_retry(hip_ctx, oracle_lib):
     """far more sites than the default workspace heuristic expects: the host entry point retries with exact bounds"""
     from pepper_thesis_amd.batch import Read, Region
