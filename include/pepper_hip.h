@@ -168,6 +168,11 @@ int pv_summarize_regions_dev(pv_ctx* ctx, const pv_batch_in* in, const pv_params
  * pv_summarize_regions_dev takes. With pv_summarize_regions_dev and pv_rnn_forward_p1_dev behind it this is the fused
  * call_variant step: reads in, probabilities out, windows never on the host. */
 int pv_upload_batch(pv_ctx* ctx, const pv_batch_in* host, pv_batch_in* dev, int64_t* totals4, void* stream);
+/* The same for a batch that arrives in n_parts host batches (e.g. one per interval from reader threads): their regions are laid
+ * end to end in part order; the large arrays are copied part by part to their offsets on the device, so the caller never
+ * concatenates them on the host. The previous upload's copies must have completed (synchronise the stream) before the next
+ * call on the same context. */
+int pv_upload_batches(pv_ctx* ctx, int n_parts, const pv_batch_in* const* parts, pv_batch_in* dev, int64_t* totals4, void* stream);
 
 /* ---- haplotag-aware image builder (`make_images -hp`) --------------------------------------------
  * Replaces PEPPER_VARIANT.RegionalSummaryGeneratorHP (pybind_api.h:64-71; region_summary_hp.cpp:350-663 populate_summary_matrix,

@@ -152,6 +152,7 @@ SYMBOLS = [
      [C.c_void_p, C.POINTER(pv_batch_in), C.POINTER(pv_params), C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int64,
       C.POINTER(pv_batch_out), C.c_void_p, C.c_void_p]),
     ("pv_upload_batch", C.c_int, [C.c_void_p, C.POINTER(pv_batch_in), C.POINTER(pv_batch_in), C.POINTER(C.c_int64), C.c_void_p]),
+    ("pv_upload_batches", C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.POINTER(pv_batch_in)), C.POINTER(pv_batch_in), C.POINTER(C.c_int64), C.c_void_p]),
     ("pv_summarize_regions_hp", C.c_int,
      [C.c_void_p, C.POINTER(pv_batch_in), C.POINTER(C.c_int32), C.POINTER(pv_params), C.POINTER(pv_batch_out)]),
     ("pv_summarize_regions_hp_dev", C.c_int,

@@ -123,6 +123,8 @@ struct pv_ctx {
     pv_prof prof;
     hipStream_t capture_stream = nullptr;   // pv_graph_begin .. pv_graph_end
     pv_opts opt;
+    std::vector<int64_t> upload_i64;        // host staging of pv_upload_batches' rebased small arrays (alive until the next upload:
+    std::vector<uint8_t> upload_u8;         // the copies out of them are asynchronous)
 };
 
 // RAII bracket: { pv_prof_scope ps(ctx, "k_name", stream); kernel<<<...>>>(...); }

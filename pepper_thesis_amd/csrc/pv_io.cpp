@@ -338,10 +338,20 @@ struct RefIndex {
 };
 
 // flat read storage shared by get_reads (one region) and fill_batch (many regions)
+// vector<uint8_t> whose resize() leaves new bytes uninitialised: the base / quality arrays (12 MB per 100 kb interval at 60x)
+// are overwritten right after they grow, and value-initialising them first was two more passes over that memory
+template <class T> struct raw_alloc : std::allocator<T> {
+    template <class U> struct rebind { typedef raw_alloc<U> other; };
+    template <class U> void construct(U* p) noexcept { ::new ((void*)p) U; }
+    template <class U, class... A> void construct(U* p, A&&... a) { ::new ((void*)p) U(std::forward<A>(a)...); }
+};
+typedef std::vector<uint8_t, raw_alloc<uint8_t>> ByteVec;
+
 struct ReadSink {
     std::vector<int64_t> pos, pos_end, base_off, cigar_off, name_off;
     std::vector<uint16_t> flag;
-    std::vector<uint8_t> is_rev, mapq, bases, quals;
+    std::vector<uint8_t> is_rev, mapq;
+    ByteVec bases, quals;
     std::vector<int32_t> hp;
     std::vector<uint32_t> cigar;
     std::vector<char> names;
@@ -573,11 +583,16 @@ static int clip_append(const RecView& v, int64_t start, int64_t stop, ReadSink& 
         o.bases.resize(at + (size_t)n);
         o.quals.resize(at + (size_t)n);
         memcpy(&o.quals[at], v.qual + idx0, (size_t)n);
+        // 4-bit codes -> letters, two per packed byte through a 256-entry table of letter pairs
+        static const struct PairLut { uint16_t t[256]; PairLut() { for (int b = 0; b < 256; b++) t[b] = (uint16_t)((uint8_t)NT16[b >> 4] | ((uint8_t)NT16[b & 15] << 8)); } } lut;
         uint8_t* dst = &o.bases[at];
-        for (int64_t i = 0; i < n; i++) {
-            const int64_t q = idx0 + i;
-            dst[i] = (uint8_t)NT16[(v.seq[q >> 1] >> ((~q & 1) << 2)) & 0xF];
+        int64_t i = 0, q = idx0;
+        if (n > 0 && (q & 1)) { dst[i++] = (uint8_t)NT16[v.seq[q >> 1] & 0xF]; q++; }
+        for (; i + 2 <= n; i += 2, q += 2) {
+            const uint16_t two = lut.t[v.seq[q >> 1]];
+            memcpy(dst + i, &two, 2);
         }
+        if (i < n) dst[i] = (uint8_t)NT16[v.seq[q >> 1] >> 4];
     };
     for (int64_t k = 0; k < v.n_cigar; k++) {
         const uint32_t c = v.cigar[k];

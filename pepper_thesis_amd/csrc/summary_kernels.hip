@@ -2434,6 +2434,99 @@ extern "C" int pv_upload_batch(pv_ctx* ctx, const pv_batch_in* in, pv_batch_in* 
     return PV_OK;
 }
 
+// The same for a batch that arrives in PARTS (e.g. one part per interval from the reader threads): the parts are laid end to
+// end on the device - the large arrays (reference, bases, qualities, CIGAR) are copied part by part straight to their offsets,
+// only the small per-region / per-read arrays are rebased on the host - so the caller never concatenates ~15 MB per interval.
+extern "C" int pv_upload_batches(pv_ctx* ctx, int n_parts, const pv_batch_in* const* parts, pv_batch_in* dev, int64_t* totals4, void* stream) {
+    PV_CHECK(ctx && parts && dev && totals4 && n_parts >= 0, PV_ERR_INVALID, "null argument");
+    PV_HIP(hipSetDevice(ctx->device));
+    hipStream_t st = pv_pick_stream(ctx, stream);
+    int64_t G = 0, n_reads = 0, n_bases = 0, n_cigar = 0, n_cols = 0;
+    for (int k = 0; k < n_parts; k++) {
+        const pv_batch_in* in = parts[k];
+        PV_CHECK(in && in->n_regions >= 0, PV_ERR_INVALID, "part %d: bad region count", k);
+        const int g = in->n_regions;
+        if (g == 0) continue;
+        PV_CHECK(in->read_off[0] == 0 && in->ref_off[0] == 0 && in->read_off[g] >= 0, PV_ERR_INVALID, "part %d: offset arrays must start at 0", k);
+        for (int i = 0; i < g; i++) {
+            const int64_t R = in->ref_end[i] - in->ref_start[i] + 1;
+            PV_CHECK(R >= 1 && in->ref_off[i + 1] - in->ref_off[i] >= R, PV_ERR_INVALID, "part %d region %d: reference shorter than ref_end-ref_start+1", k, i);
+            PV_CHECK(in->read_off[i + 1] >= in->read_off[i], PV_ERR_INVALID, "read_off not monotone");
+        }
+        const int64_t nr = in->read_off[g];
+        for (int64_t r = 0; r < nr; r++)
+            PV_CHECK(in->base_off[r + 1] >= in->base_off[r] && in->cigar_off[r + 1] >= in->cigar_off[r], PV_ERR_INVALID, "part %d read %lld: offsets not monotone", k, (long long)r);
+        G += g; n_reads += nr; n_cols += in->ref_off[g];
+        n_bases += nr ? in->base_off[nr] : 0; n_cigar += nr ? in->cigar_off[nr] : 0;
+    }
+    PV_CHECK(G < (1ll << 31), PV_ERR_LIMIT, "too many regions");
+    memset(dev, 0, sizeof(*dev));
+    dev->n_regions = (int32_t)G;
+    totals4[0] = n_reads; totals4[1] = n_bases; totals4[2] = n_cigar; totals4[3] = n_cols;
+    if (G == 0) return PV_OK;
+    // small arrays: rebased on the host into one staging vector per array (kept alive in the context until the next upload)
+    std::vector<int64_t>& hs = ctx->upload_i64;
+    std::vector<uint8_t>& hb = ctx->upload_u8;
+    const size_t n64 = (size_t)(4 * G + 2 * (G + 1) + n_reads + 2 * (n_reads + 1));
+    hs.resize(n64);
+    hb.resize((size_t)(2 * n_reads));
+    int64_t* h_ref_start = hs.data(); int64_t* h_ref_end = h_ref_start + G; int64_t* h_cand_start = h_ref_end + G; int64_t* h_cand_end = h_cand_start + G;
+    int64_t* h_ref_off = h_cand_end + G; int64_t* h_read_off = h_ref_off + (G + 1); int64_t* h_read_pos = h_read_off + (G + 1);
+    int64_t* h_base_off = h_read_pos + n_reads; int64_t* h_cigar_off = h_base_off + (n_reads + 1);
+    uint8_t* h_flags = hb.data(); uint8_t* h_mapq = h_flags + n_reads;
+    uint8_t *d_ref = nullptr, *d_bases = nullptr, *d_quals = nullptr;
+    uint32_t* d_cigar = nullptr;
+    int rc;
+    if ((rc = pv_get(ctx, "in.ref", (size_t)std::max<int64_t>(n_cols, 1), &d_ref)) || (rc = pv_get(ctx, "in.bases", (size_t)std::max<int64_t>(n_bases, 1), &d_bases)) ||
+        (rc = pv_get(ctx, "in.quals", (size_t)std::max<int64_t>(n_bases, 1), &d_quals)) || (rc = pv_get(ctx, "in.cigar", (size_t)std::max<int64_t>(n_cigar, 1), &d_cigar)))
+        return rc;
+    int64_t g0 = 0, r0 = 0, b0 = 0, c0 = 0, col0 = 0;
+    h_ref_off[0] = 0; h_read_off[0] = 0; h_base_off[0] = 0; h_cigar_off[0] = 0;
+    for (int k = 0; k < n_parts; k++) {
+        const pv_batch_in* in = parts[k];
+        const int g = in->n_regions;
+        if (g == 0) continue;
+        const int64_t nr = in->read_off[g], nb = nr ? in->base_off[nr] : 0, nc = nr ? in->cigar_off[nr] : 0, ncol = in->ref_off[g];
+        for (int i = 0; i < g; i++) {
+            h_ref_start[g0 + i] = in->ref_start[i]; h_ref_end[g0 + i] = in->ref_end[i];
+            h_cand_start[g0 + i] = in->cand_start[i]; h_cand_end[g0 + i] = in->cand_end[i];
+            h_ref_off[g0 + i + 1] = col0 + in->ref_off[i + 1];
+            h_read_off[g0 + i + 1] = r0 + in->read_off[i + 1];
+        }
+        for (int64_t r = 0; r < nr; r++) {
+            h_read_pos[r0 + r] = in->read_pos[r];
+            h_flags[r0 + r] = in->read_flags[r]; h_mapq[r0 + r] = in->read_mapq[r];
+            h_base_off[r0 + r + 1] = b0 + in->base_off[r + 1];
+            h_cigar_off[r0 + r + 1] = c0 + in->cigar_off[r + 1];
+        }
+        if (ncol) PV_HIP(hipMemcpyAsync(d_ref + col0, in->ref, (size_t)ncol, hipMemcpyHostToDevice, st));
+        if (nb) {
+            PV_HIP(hipMemcpyAsync(d_bases + b0, in->bases, (size_t)nb, hipMemcpyHostToDevice, st));
+            PV_HIP(hipMemcpyAsync(d_quals + b0, in->quals, (size_t)nb, hipMemcpyHostToDevice, st));
+        }
+        if (nc) PV_HIP(hipMemcpyAsync(d_cigar + c0, in->cigar, (size_t)nc * sizeof(uint32_t), hipMemcpyHostToDevice, st));
+        g0 += g; r0 += nr; b0 += nb; c0 += nc; col0 += ncol;
+    }
+    dev->ref = d_ref; dev->bases = d_bases; dev->quals = d_quals; dev->cigar = d_cigar;
+    if ((rc = upload(ctx, "in.ref_start", h_ref_start, G, &dev->ref_start, st))) return rc;
+    if ((rc = upload(ctx, "in.ref_end", h_ref_end, G, &dev->ref_end, st))) return rc;
+    if ((rc = upload(ctx, "in.cand_start", h_cand_start, G, &dev->cand_start, st))) return rc;
+    if ((rc = upload(ctx, "in.cand_end", h_cand_end, G, &dev->cand_end, st))) return rc;
+    if ((rc = upload(ctx, "in.ref_off", h_ref_off, G + 1, &dev->ref_off, st))) return rc;
+    if ((rc = upload(ctx, "in.read_off", h_read_off, G + 1, &dev->read_off, st))) return rc;
+    if ((rc = upload(ctx, "in.read_pos", h_read_pos, n_reads, &dev->read_pos, st))) return rc;
+    if ((rc = upload(ctx, "in.base_off", h_base_off, n_reads + 1, &dev->base_off, st))) return rc;
+    if ((rc = upload(ctx, "in.cigar_off", h_cigar_off, n_reads + 1, &dev->cigar_off, st))) return rc;
+    {
+        const uint8_t* t = nullptr;
+        if ((rc = upload(ctx, "in.read_flags", (const uint8_t*)h_flags, n_reads, &t, st))) return rc;
+        dev->read_flags = t;
+        if ((rc = upload(ctx, "in.read_mapq", (const uint8_t*)h_mapq, n_reads, &t, st))) return rc;
+        dev->read_mapq = t;
+    }
+    return PV_OK;
+}
+
 static int summarize_host(pv_ctx* ctx, const pv_batch_in* in, const pv_params* params, pv_batch_out* out, bool hp,
                           const int32_t* read_hp);
 extern "C" int pv_summarize_regions(pv_ctx* ctx, const pv_batch_in* in, const pv_params* params, pv_batch_out* out) {

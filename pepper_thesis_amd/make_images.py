@@ -138,10 +138,31 @@ def list_intervals(fasta, bam, region: str = None, region_size: int = 100_000, r
     return todo
 
 
+def cpu_share() -> int:
+    """CPUs this process may actually use: the affinity mask, capped by the cgroup's CPU quota where one is set (a container
+    with a 16-core quota on a 256-thread host reports 256 in its mask; 32 reader threads there ran at half the rate of 16)"""
+    import os
+    n = len(os.sched_getaffinity(0))
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as fh:                      # cgroup v2: "<quota> <period>" or "max <period>"
+            q, per = fh.read().split()[:2]
+            if q != "max":
+                n = min(n, max(1, int(int(q) / int(per) + 0.5)))
+    except (OSError, ValueError):
+        try:
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as fq, open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as fp:   # v1
+                q, per = int(fq.read()), int(fp.read())
+                if q > 0 and per > 0:
+                    n = min(n, max(1, int(q / per + 0.5)))
+        except (OSError, ValueError):
+            pass
+    return n
+
+
 def region_batches(bam_path: str, fasta_path: str, region: str = None, region_size: int = 100_000, min_mapq: int = 5,
                    include_supplementary: bool = False, downsample_rate: float = 1.0, intervals_per_call: int = 16,
                    rank: int = 0, world: int = 1, reader_threads: int = None, intervals_per_read: int = 1, T: dict = None,
-                   region_bed: str = None):
+                   region_bed: str = None, merge: bool = True):
     """The reader side of generate_images (ImageGenerationUI.py:277-345) as a generator of (RegionBatch, interval of every
     batch region) pairs, `intervals_per_call` intervals per batch; interval i belongs to rank i % world (:211).
 
@@ -150,6 +171,9 @@ def region_batches(bam_path: str, fasta_path: str, region: str = None, region_si
     `intervals_per_read` intervals at a time straight into the flat pv_batch_in arrays in native code (bamio.fill_batch, GIL
     released), running ahead of the consumer; the consuming thread merges `intervals_per_call` of them per batch (array
     concatenation). The arrays of a yielded batch stay valid until the generator is resumed.
+    merge=False yields the LIST of per-read batches instead of their concatenation (Context.upload_batches lays them end to
+    end on the device: no host copy of the ~15 MB per interval). A short job (fewer than four full calls' worth of intervals)
+    gets smaller calls, so that the device starts on the first intervals while the last are still being read.
     T (optional dict) accumulates the reader-side stage times."""
     import os
     import threading
@@ -166,10 +190,11 @@ def region_batches(bam_path: str, fasta_path: str, region: str = None, region_si
     bam, fasta = BamHandler(bam_path), FastaHandler(fasta_path)
     todo = list_intervals(fasta, bam, region, region_size, region_bed)
     mine = [iv for i, iv in enumerate(todo) if i % world == rank]
+    intervals_per_call = max(1, min(int(intervals_per_call), max(4, (len(mine) + 3) // 4)))
     ipr = max(1, min(int(intervals_per_read), int(intervals_per_call)))
     groups = [mine[k:k + ipr] for k in range(0, len(mine), ipr)]
     reads_per_call = max(1, int(intervals_per_call) // ipr)
-    n_thr = max(1, min(int(reader_threads or len(os.sched_getaffinity(0))), max(len(groups), 1)))
+    n_thr = max(1, min(int(reader_threads or min(cpu_share(), 16)), max(len(groups), 1)))   # (beyond 16 the readers stop scaling)
     T["reader_threads"], T["intervals"] = n_thr, len(mine)
     tls = threading.local()
 
@@ -201,11 +226,15 @@ def region_batches(bam_path: str, fasta_path: str, region: str = None, region_si
                 T["bytes_inflated"] += fb.bytes_inflated
                 names += [fb.intervals[int(i)] for i in fb.interval_index]
             t0 = time.perf_counter()
-            batch = merge_batches([fb.batch for fb in fbs])
+            if merge:
+                batch = merge_batches([fb.batch for fb in fbs])
+            else:
+                batch = [fb.batch for fb in fbs if fb.batch.n_regions]
             T["merge_s"] += time.perf_counter() - t0
-            if batch.n_regions:                                      # "no group when no reads" (AlignmentSummarizer.py:212-213)
-                T["bases"] += batch.n_bases
-                T["reads"] += batch.n_reads
+            n_reg = batch.n_regions if merge else len(names)
+            if n_reg:                                                # "no group when no reads" (AlignmentSummarizer.py:212-213)
+                T["bases"] += batch.n_bases if merge else sum(b.n_bases for b in batch)
+                T["reads"] += batch.n_reads if merge else sum(b.n_reads for b in batch)
                 yield batch, names
             del batch
             for fb in fbs:

@@ -85,14 +85,16 @@ def call_variant_fused(ctx, state_dict: dict, bam_path: str, fasta_path: str, pr
     cap, scap = 0, 0
     dout = probs = None
     try:
-        for batch, names in region_batches(bam_path, fasta_path, region, region_size, min_mapq, include_supplementary,
-                                           downsample_rate, intervals_per_call, rank, world, reader_threads, 1, T, region_bed):
+        for parts, names in region_batches(bam_path, fasta_path, region, region_size, min_mapq, include_supplementary,
+                                           downsample_rate, intervals_per_call, rank, world, reader_threads, 1, T, region_bed,
+                                           merge=False):
             if werr:
                 break
             t0 = time.perf_counter()
-            up = ctx.upload_batch(batch)   # asynchronous copies on the context's stream, the builder is queued behind them
+            up = ctx.upload_batches(parts)   # the readers' per-interval arrays go straight to their offsets on the device
             T["upload_s"] += time.perf_counter() - t0
-            want = max(4096, 1024 * batch.n_regions)
+            want = max(4096, 1024 * len(names))
+            max_region_len = max(b.max_region_len for b in parts)
             while True:
                 if dout is None or cap < want:
                     cap, scap = want, 16 * want
@@ -100,7 +102,7 @@ def call_variant_fused(ctx, state_dict: dict, bam_path: str, fasta_path: str, pr
                     probs = torch.zeros((cap, 3), dtype=torch.float32, device=dev)
                     torch.cuda.synchronize()
                 t0 = time.perf_counter()
-                ctx.summarize_uploaded(up, params, dout, batch.max_region_len)
+                ctx.summarize_uploaded(up, params, dout, max_region_len)
                 ctx.synchronize(check=False)
                 n_out, str_bytes, status = (int(v) for v in dout.counts[:3].tolist())
                 if status != _ffi.PV_OK:

@@ -242,6 +242,16 @@ class Context:
         _ffi.check(self.lib.pv_upload_batch(self.handle, C.byref(cin), C.byref(dev), totals, stream or None))
         return dev, [int(v) for v in totals], cin   # cin keeps the host arrays referenced until the copies are done
 
+    def upload_batches(self, batches, stream: int = 0):
+        """several host batches (e.g. one per interval) laid end to end on the device without a host-side concatenation
+        (pv_upload_batches); same return value as upload_batch"""
+        cins = [b.as_c() for b in batches if b.n_regions]
+        arr = (C.POINTER(_ffi.pv_batch_in) * max(len(cins), 1))(*[C.pointer(c) for c in cins])
+        dev = _ffi.pv_batch_in()
+        totals = (C.c_int64 * 4)()
+        _ffi.check(self.lib.pv_upload_batches(self.handle, len(cins), arr, C.byref(dev), totals, stream or None))
+        return dev, [int(v) for v in totals], (cins, arr)
+
     def summarize_uploaded(self, uploaded, params: Params, dout: "DeviceOut", max_region_len: int = 0, stream: int = 0):
         """the device-resident builder on a batch staged with upload_batch; counters land in dout.counts"""
         dev, (n_reads, n_bases, n_cigar, n_ref), _ = uploaded
