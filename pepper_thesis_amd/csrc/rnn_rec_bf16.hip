@@ -48,7 +48,7 @@ template <int NG, bool ENC, int MT = 1> struct RecCfg {
     static constexpr int NSLOT = (XRES ? 0 : KS_X * NG) + KS_H * NG;   // (gate, k-step) slots of the weight stream per step
     // ring depth (NSLOT % D == 0): 8 register sets where they fit; 4 for the 64-row LSTM forms (128 accumulator + 32 state
     // registers of 256) and the GRU encoder (its x-part fragments stay resident)
-    static constexpr int D = ((NG == 3 && ENC) || (NG == 4 && MT == 2)) ? 4 : 8;
+    static constexpr int D = ((NG == 3 && ENC) || (NG == 4 && MT == 2)) ? 4 : 8;   // (8 sets in the 64-row decoder: 14 spills, no faster)
     static constexpr int NA = NG + ((NG == 3 && ENC) ? 1 : 0);  // accumulators per M-tile (GRU keeps the n gate's x-part apart)
     static constexpr int HS = HID * 4 + 16;                     // LDS row stride of the split8 h tile: (HS / 4) % 64 == 4
     static constexpr int XS = XK * 2 + 16;                      // LDS row stride of the bf16 x tile
