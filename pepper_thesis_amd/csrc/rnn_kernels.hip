@@ -26,6 +26,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdlib>
+#include <mutex>
 
 namespace {
 
@@ -767,6 +768,7 @@ struct GemmArgs {
     int tiles_m, tiles_n; // 256 x 256 output tiles
     int items;            // tiles_m * tiles_n * splits work items, walked by persistent workgroups
     int c_quads;
+    const unsigned* iota; // [1024] = 0 .. 1023: the source of the completion-flag transfers (below)
 };
 
 // C = A . W^T (+ bias) with 3-term split-bf16 products (a_hi.w_hi + a_hi.w_lo + a_lo.w_hi) on v_mfma_f32_32x32x16_bf16.
@@ -780,6 +782,14 @@ struct GemmArgs {
 // XCDs in groups of one XCD's workgroups, so the CUs of an XCD work on the same few A row tiles at the same time. The next
 // item's first K step is requested BEFORE the epilogue stores (32 dwordx4 stores per wave in the quad layout), so it travels
 // while they are issued; its first K step then waits for everything the wave has in flight.
+#ifdef PV_GEMM_STAMPS
+// diagnostic build: cycle sums of the K loop's phases (workgroup 0, every wave adds): {wait for the transfers, barrier, MFMA block,
+// epilogue + next tile's set-up}, and the K steps counted; read by pv_debug_gemm_stamps
+__device__ unsigned long long g_gemm_stamps[8];
+#define GSTAMP(i) { unsigned long long now_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(now_) :: "memory"); gs_acc[i] += now_ - gs_last; gs_last = now_; }
+#else
+#define GSTAMP(i)
+#endif
 __global__ __launch_bounds__(512, 2) void k_gemm_bf16x3(GemmArgs g) {
     constexpr int BM = 256, BN = 256, BK = 32;
     constexpr int ARR = BM * BK * 2;          // bytes of one bf16 operand image (16 KB); buffer = [A_hi | A_lo | W_hi | W_lo]
@@ -822,17 +832,18 @@ __global__ __launch_bounds__(512, 2) void k_gemm_bf16x3(GemmArgs g) {
         }
     };
     // 8 LDS-DMA pieces of this wave for K step kt into buffer buf
-    auto dma = [&](int kt, int buf) {
+    // piece j = 0..7 of this wave for K step kt into buffer buf: (p = j >> 2) x {A_hi, A_lo, W_hi, W_lo}
+    auto dma_piece = [&](int kt, int buf, int j) {
         typedef __attribute__((address_space(3))) void* lds_ptr;
         unsigned char* base = smg + buf * 4 * ARR + wv * 1024;
         const unsigned so = (unsigned)(kt * BK * 4);
+        const int p = j >> 2, arr = j & 3;
+        if (arr < 2) __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_ptr)(base + arr * ARR + p * 8192), 16, la[p], so + (arr & 1 ? 16u : 0u), 0, 0);
+        else __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_ptr)(base + arr * ARR + p * 8192), 16, lw[p], so + (arr & 1 ? 16u : 0u), 0, 0);
+    };
+    auto dma = [&](int kt, int buf) {
 #pragma unroll
-        for (int p = 0; p < 2; p++) {
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_ptr)(base + p * 8192), 16, la[p], so, 0, 0);
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_ptr)(base + ARR + p * 8192), 16, la[p], so + 16u, 0, 0);
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_ptr)(base + 2 * ARR + p * 8192), 16, lw[p], so, 0, 0);
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_ptr)(base + 3 * ARR + p * 8192), 16, lw[p], so + 16u, 0, 0);
-        }
+        for (int j = 0; j < 8; j++) dma_piece(kt, buf, j);
     };
 
     // the bias of an item's 256 columns also arrives by LDS-DMA (one 1 KB piece, wave 0) into a slot behind the two operand
@@ -844,6 +855,39 @@ __global__ __launch_bounds__(512, 2) void k_gemm_bf16x3(GemmArgs g) {
         if (g.bias && wv == 0)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(make_rsrc(g.bias + nt_ * BN), (lds_ptr)sbias, 16, (unsigned)lane * 16u, 0, 0, 0);
     };
+#ifndef PV_GEMM_VMCNT
+    // Completion of a K step's transfers WITHOUT s_waitcnt vmcnt: the counter also holds the epilogue stores of the previous
+    // tile (256 KB per workgroup), which the first K step of the next tile then waits for as well. Loads complete in issue
+    // order, so behind the pieces of a K step every wave issues one more LDS-DMA that copies the word iota[seq] into its own
+    // flag slot, and polls that slot in LDS until the word is there: the pieces before it have landed, whatever the stores are
+    // doing. (Measured: no change by itself - 1.59 ms either way for the decoder projection: what an epilogue costs is the ISSUE
+    // of its 32 stores per wave at the ~19 B/clk a CU's store path takes, 13.8 k cycles per tile by the phase stamps of
+    // -DPV_GEMM_STAMPS, not their completion. Kept: it removes the only wait in the kernel that depends on stores.)
+    unsigned* sflag = reinterpret_cast<unsigned*>(smg + 2 * 4 * ARR + 1024) + wv * 64;   // 256 B per wave
+    sflag[lane] = 0xFFFFFFFFu;
+    unsigned seq = 0;
+    const __amdgpu_buffer_rsrc_t riota = make_rsrc(g.iota);
+    auto dma_flag = [&]() {
+        typedef __attribute__((address_space(3))) void* lds_ptr;
+        seq = (seq + 1u) & 1023u;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(riota, (lds_ptr)sflag, 4, 0u, seq * 4u, 0, 0);
+    };
+    // (the poll is a ds_read_b32 from inline asm: a C++ load of LDS that may alias an LDS-DMA target makes hipcc wait for
+    // vmcnt(0) in front of it - the very wait this replaces - and a volatile one becomes a flat load)
+    const unsigned flag_addr = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned*)(sflag + lane);
+    auto dma_wait = [&]() {
+        while (true) {
+            unsigned v;
+            asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(flag_addr) : "memory");
+            if (__builtin_amdgcn_ballot_w64(v != seq) == 0) break;
+            __builtin_amdgcn_s_sleep(1);
+        }
+    };
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#else
+    auto dma_flag = [&]() {};
+    auto dma_wait = [&]() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); };
+#endif
     int q = 0;                                    // group q of per_xcd consecutive items goes to the XCD class q % 8
     int it = (xcd + 8 * q) * per_xcd + slot;
     int mt = 0, nt = 0, sp = 0;
@@ -852,7 +896,12 @@ __global__ __launch_bounds__(512, 2) void k_gemm_bf16x3(GemmArgs g) {
         item_setup(mt, nt, sp);
         dma(0, 0);
         dma_bias(nt);
+        dma_flag();
     }
+#ifdef PV_GEMM_STAMPS
+    unsigned long long gs_acc[5] = {0, 0, 0, 0, 0}, gs_last;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(gs_last) :: "memory");
+#endif
     while (it < g.items) {
         f32x16 acc[4][2];
 #pragma unroll
@@ -867,11 +916,19 @@ __global__ __launch_bounds__(512, 2) void k_gemm_bf16x3(GemmArgs g) {
             // (a counted wait that lets the previous item's epilogue stores stay in flight is NOT safe here: vmcnt retires loads
             // in order among loads and stores among stores, but a store may retire before an older LDS-DMA load, so "at most 32
             // outstanding" does not imply the DMAs have landed. It gave a sporadic 1e-4 error in one of five full test runs.)
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            GSTAMP(3)
+            dma_wait();
+            GSTAMP(0)
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
-            if (kt + 1 < nk) dma(kt + 1, buf ^ 1);
+            GSTAMP(1)
+#ifdef PV_GEMM_DMA_BURST
+            if (kt + 1 < nk) { dma(kt + 1, buf ^ 1); dma_flag(); }
+#endif
             const unsigned char* base = smg + buf * 4 * ARR;
+            // the next step's eight pieces are issued one per (ks, mi) block of this step's MFMAs instead of as a burst behind
+            // the barrier: an LDS-DMA costs its wave ~100-150 issue cycles, and the two waves of a SIMD - phase-locked by the
+            // barrier - both paid the eight of them before either issued an MFMA (~1200 of a K step's ~4300 cycles)
 #pragma unroll
             for (int ks = 0; ks < 2; ks++) {
                 const unsigned ch = (unsigned)(((2 * ks + (lane >> 5)) ^ f_swz) * 16);
@@ -885,6 +942,12 @@ __global__ __launch_bounds__(512, 2) void k_gemm_bf16x3(GemmArgs g) {
                 for (int mi = 0; mi < 4; mi++) {
                     const bf16x8 ah = *reinterpret_cast<const bf16x8*>(base + fa_l + mi * 32 * 64 + ch);
                     const bf16x8 al = *reinterpret_cast<const bf16x8*>(base + ARR + fa_l + mi * 32 * 64 + ch);
+#ifndef PV_GEMM_DMA_BURST
+                    if (kt + 1 < nk) {
+                        dma_piece(kt + 1, buf ^ 1, ks * 4 + mi);
+                        if (ks == 1 && mi == 3) dma_flag();
+                    }
+#endif
 #pragma unroll
                     for (int ni = 0; ni < 2; ni++) {
                         acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh[ni], acc[mi][ni], 0, 0, 0);
@@ -893,6 +956,10 @@ __global__ __launch_bounds__(512, 2) void k_gemm_bf16x3(GemmArgs g) {
                     }
                 }
             }
+            GSTAMP(2)
+#ifdef PV_GEMM_STAMPS
+            gs_acc[4]++;
+#endif
         }
         // C tile as a sized buffer resource: rows beyond M fall outside it and are dropped by the bounds check; the
         // address of every store is (tile resource) + (lane offset) + (scalar offset of (wave, mi, ni, r))
@@ -915,6 +982,7 @@ __global__ __launch_bounds__(512, 2) void k_gemm_bf16x3(GemmArgs g) {
             item_setup(mt, nt, sp);
             dma(0, 0);
             dma_bias(nt);
+            dma_flag();
         }
         if (g.c_quads) {
             // [M/4][N][4]: accumulator registers 4g..4g+3 of a lane are four consecutive rows of one column: one 16-byte store
@@ -958,6 +1026,10 @@ __global__ __launch_bounds__(512, 2) void k_gemm_bf16x3(GemmArgs g) {
                                       (unsigned)(((128 * wr + 32 * mi + (r & 3) + 8 * (r >> 2)) * g.N + 64 * wc + 32 * ni) * 4));
         }
     }
+#ifdef PV_GEMM_STAMPS
+    if (blockIdx.x == 0 && lane == 0)
+        for (int i = 0; i < 5; i++) atomicAdd(&g_gemm_stamps[i], gs_acc[i]);
+#endif
 }
 
 // ---- host-side weight packing -----------------------------------------------------------------------
@@ -1040,7 +1112,7 @@ static constexpr int64_t P1_BF16_MAX_BATCH = 16384;
 template <int KP> constexpr size_t lds_lstm_split() { return (size_t)(16 * (KP + 4) + 2 * 16 * (H + 4)) * sizeof(float); }
 static constexpr int SP_MAX_TILES = 64;   // 16-row tiles the exchange buffers are sized for (1024 windows)
 template <int KP, int TR> constexpr size_t lds_lstm() { return (size_t)(TR * (KP + 4) + 2 * TR * (H + 4)) * sizeof(float); }
-static constexpr size_t LDS_GEMM = (size_t)2 * 4 * 256 * 32 * 2 + 1024;   // 2 buffers x {A_hi, A_lo, W_hi, W_lo} x 256 rows x 32 bf16 = 128 KB, + bias slot
+static constexpr size_t LDS_GEMM = (size_t)2 * 4 * 256 * 32 * 2 + 1024 + 2048;   // 2 buffers x {A_hi, A_lo, W_hi, W_lo} x 256 rows x 32 bf16 = 128 KB, + bias slot + completion flags
 static constexpr size_t LDS_SPLITK = (size_t)ROWS * (2 * H + 4) * sizeof(float);
 template <int TR> constexpr size_t lds_tail() { return (size_t)2 * TR * (HEAD_N + 4) * sizeof(float); }
 
@@ -1416,8 +1488,32 @@ extern "C" int pv_rnn_forward_p1(pv_ctx* ctx, const int8_t* images, int64_t B, f
     return pv_rnn_forward_p1_debug(ctx, images, B, probs, nullptr, nullptr);
 }
 
+// iota[1024] per device (allocated once, never freed: 4 KB), the source of k_gemm_bf16x3's completion-flag transfers
+static const unsigned* gemm_iota() {
+    static std::mutex mu;
+    static std::map<int, unsigned*> per_dev;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+    std::lock_guard<std::mutex> lk(mu);
+    auto it = per_dev.find(dev);
+    if (it != per_dev.end()) return it->second;
+    unsigned h[1024];
+    for (unsigned i = 0; i < 1024; i++) h[i] = i;
+    unsigned* d = nullptr;
+    if (hipMalloc((void**)&d, sizeof h) != hipSuccess || hipMemcpy(d, h, sizeof h, hipMemcpyHostToDevice) != hipSuccess) return nullptr;
+    per_dev[dev] = d;
+    return d;
+}
+
+static void gemm_launch(pv_ctx* ctx, GemmArgs& g, hipStream_t st) {
+    g.tiles_m = (int)((g.M + 255) / 256); g.tiles_n = g.N / 256; g.items = g.tiles_m * g.tiles_n * g.splits;
+    const unsigned grid = (unsigned)(std::min((g.items + 7) / 8 * 8, (ctx->num_cu + 7) / 8 * 8));
+    k_gemm_bf16x3<<<grid, 512, LDS_GEMM, st>>>(g);
+}
+
 int pv_gemm_bf16x3_prepare() {
     PV_HIP(hipFuncSetAttribute((const void*)k_gemm_bf16x3, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_GEMM));
+    PV_CHECK(gemm_iota() != nullptr, PV_ERR_HIP, "allocation of the GEMM's flag table failed");
     return PV_OK;
 }
 
@@ -1430,10 +1526,11 @@ int pv_gemm_bf16x3_async(pv_ctx* ctx, const pv_gemm_desc& d, hipStream_t st) {
                  (!d.quads || d.splits == 1), PV_ERR_INVALID, "bad GEMM shape");
     GemmArgs g;
     g.A = d.A; g.W = d.W; g.bias = d.bias; g.C = d.C; g.M = d.M; g.N = d.N; g.K = d.K; g.splits = d.splits;
-    g.tiles_m = (int)((d.M + 255) / 256); g.tiles_n = d.N / 256; g.items = g.tiles_m * g.tiles_n * d.splits; g.c_quads = d.quads;
-    const unsigned grid = (unsigned)(std::min((g.items + 7) / 8 * 8, (ctx->num_cu + 7) / 8 * 8));
+    g.c_quads = d.quads;
+    g.iota = gemm_iota();
+    PV_CHECK(g.iota, PV_ERR_HIP, "GEMM flag table missing");
     pv_prof_scope ps(ctx, d.prof_name ? d.prof_name : "k_gemm_bf16x3", st);
-    k_gemm_bf16x3<<<grid, 512, LDS_GEMM, st>>>(g);
+    gemm_launch(ctx, g, st);
     PV_HIP(hipGetLastError());
     return PV_OK;
 }
@@ -1457,16 +1554,16 @@ extern "C" int pv_debug_gemm_bf16x3(pv_ctx* ctx, const float* A, const float* W,
     if (hipMalloc((void**)&dC, nc * sizeof(float)) != hipSuccess) { cleanup(); pv_set_error("hipMalloc failed"); return PV_ERR_HIP; }
     owned.push_back(dC);
     (void)hipMemset(dC, 0xff, nc * sizeof(float));
-    (void)hipFuncSetAttribute((const void*)k_gemm_bf16x3, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_GEMM);
+    if (pv_gemm_bf16x3_prepare() != PV_OK) { cleanup(); return PV_ERR_HIP; }
     GemmArgs g;
-    g.A = dA; g.W = dW; g.bias = dB; g.C = dC; g.M = M; g.N = N; g.K = K; g.splits = splits;
-    g.tiles_m = (int)((M + 255) / 256); g.tiles_n = N / 256; g.items = g.tiles_m * g.tiles_n * splits; g.c_quads = quads;
-    const unsigned grid = (unsigned)(std::min((g.items + 7) / 8 * 8, (ctx->num_cu + 7) / 8 * 8));
+    g.A = dA; g.W = dW; g.bias = dB; g.C = dC; g.M = M; g.N = N; g.K = K; g.splits = splits; g.c_quads = quads;
+    g.iota = gemm_iota();
+    if (!g.iota) { cleanup(); pv_set_error("GEMM flag table missing"); return PV_ERR_HIP; }
     hipEvent_t e0, e1;
     (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
-    k_gemm_bf16x3<<<grid, 512, LDS_GEMM, ctx->stream>>>(g);   // warm
+    gemm_launch(ctx, g, ctx->stream);   // warm
     (void)hipEventRecord(e0, ctx->stream);
-    k_gemm_bf16x3<<<grid, 512, LDS_GEMM, ctx->stream>>>(g);
+    gemm_launch(ctx, g, ctx->stream);
     (void)hipEventRecord(e1, ctx->stream);
     hipError_t er = hipStreamSynchronize(ctx->stream);
     float t = 0.f;
@@ -1481,3 +1578,13 @@ extern "C" int pv_debug_gemm_bf16x3(pv_ctx* ctx, const float* A, const float* W,
 
 // ---- P2 (bi-GRU polisher model): see rnn_gru.hip ----------------------------------------------------
 
+
+#ifdef PV_GEMM_STAMPS
+extern "C" int pv_debug_gemm_stamps(unsigned long long* out5) {
+    unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    PV_HIP(hipDeviceSynchronize());
+    PV_HIP(hipMemcpyFromSymbol(out5, HIP_SYMBOL(g_gemm_stamps), 5 * sizeof(unsigned long long)));
+    PV_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_gemm_stamps), z, sizeof z));
+    return PV_OK;
+}
+#endif
