@@ -51,6 +51,10 @@ const char* pvio_last_error(void);
 
 pv_bam* pvio_bam_open(const char* path); /* needs <path>.bai or <stem>.bai; NULL on failure */
 void pvio_bam_close(pv_bam* bam);
+/* n helper threads of this handle inflate BGZF blocks AHEAD of the thread that reads records from it (what hts_set_threads
+ * does for htslib's bam_handler); 0 (the default) = none, nothing is read ahead. Read-ahead stops at the end of the index
+ * chunk being walked. Returns the number of helpers now running, -1 on a null handle. Call it between queries only. */
+int pvio_bam_set_threads(pv_bam* bam, int n_helpers);
 int pvio_bam_nref(pv_bam* bam);
 const char* pvio_bam_ref_name(pv_bam* bam, int i);
 int64_t pvio_bam_ref_len(pv_bam* bam, int i);
@@ -83,6 +87,7 @@ typedef struct pvio_batch {
     double t_total;                /* ... and the whole call (record decode + clip + FASTA = t_total - t_inflate) */
     int64_t bytes_inflated;
     const int32_t* read_hp;        /* [n_reads] HP aux tag or 0: the `read_hp` argument of pv_summarize_regions_hp */
+    double t_helpers;              /* seconds the handle's helper threads spent inflating during the call (pvio_bam_set_threads) */
 } pvio_batch;
 int pvio_fill_batch(pv_bam* bam, pv_fasta* fa, int n_intervals, const char* const* contigs, const int64_t* starts,
                     const int64_t* ends, int safe_bases, int include_supplementary, int min_mapq, double downsample_rate,

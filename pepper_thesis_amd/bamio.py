@@ -36,7 +36,7 @@ class pvio_batch(C.Structure):
                 ("cigar_off", C.POINTER(C.c_int64)), ("cigar", C.POINTER(C.c_uint32)),
                 ("interval_index", C.POINTER(C.c_int64)), ("reads_seen", C.POINTER(C.c_int64)),
                 ("t_inflate", C.c_double), ("t_total", C.c_double), ("bytes_inflated", C.c_int64),
-                ("read_hp", C.POINTER(C.c_int32))]
+                ("read_hp", C.POINTER(C.c_int32)), ("t_helpers", C.c_double)]
 
 
 IO_SYMBOLS = [
@@ -45,6 +45,7 @@ IO_SYMBOLS = [
     ("pvio_set_inflate_backend", C.c_int, [C.c_int]),
     ("pvio_bam_open", C.c_void_p, [C.c_char_p]),
     ("pvio_bam_close", None, [C.c_void_p]),
+    ("pvio_bam_set_threads", C.c_int, [C.c_void_p, C.c_int]),
     ("pvio_bam_nref", C.c_int, [C.c_void_p]),
     ("pvio_bam_ref_name", C.c_char_p, [C.c_void_p, C.c_int]),
     ("pvio_bam_ref_len", C.c_int64, [C.c_void_p, C.c_int]),
@@ -106,6 +107,13 @@ class BamHandler:
 
     def __del__(self):
         self.close()
+
+    def set_threads(self, n_helpers: int) -> int:
+        """n helper threads inflate BGZF blocks ahead of the thread that reads from this handle (0 = none); -> helpers running"""
+        rc = load().pvio_bam_set_threads(self.h, int(n_helpers))
+        if rc < 0:
+            raise IOError("set_threads: " + _err())
+        return rc
 
     def get_chromosome_sequence_names(self) -> List[str]:
         L = load()
@@ -212,6 +220,7 @@ class FilledBatch:
         self.interval_index = view(v.interval_index, G, np.int64).copy()
         self.reads_seen = view(v.reads_seen, G, np.int64).copy()
         self.t_inflate, self.t_total, self.bytes_inflated = float(v.t_inflate), float(v.t_total), int(v.bytes_inflated)
+        self.t_helpers = float(v.t_helpers)
         self.batch = RegionBatch(
             G, view(v.ref_start, G, np.int64), view(v.ref_end, G, np.int64), view(v.cand_start, G, np.int64),
             view(v.cand_end, G, np.int64), view(v.ref_off, G + 1, np.int64), view(v.ref, int(v.n_ref_bytes), np.uint8),

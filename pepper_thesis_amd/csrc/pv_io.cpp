@@ -29,7 +29,9 @@
 #include <dlfcn.h>
 
 #include <atomic>
+#include <condition_variable>
 #include <mutex>
+#include <thread>
 
 #include <algorithm>
 #include <chrono>
@@ -37,11 +39,16 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
+#include <cstdlib>
+#include <new>
 #include <map>
 #include <string>
 #include <vector>
 
 #include "../../include/pepper_io.h"
+#if defined(__x86_64__)
+#include <immintrin.h>
+#endif
 
 static thread_local char g_ioerr[512] = "";
 static void io_err(const char* fmt, ...) {
@@ -104,42 +111,107 @@ extern "C" int pvio_set_inflate_backend(int use_libdeflate) {   // tests; return
 }
 
 // ---- BGZF reader ------------------------------------------------------------------------------------------------
+// The consuming thread reads the blocks of the file in order (raw bytes); they are inflated either by that thread itself, one
+// block at a time with nothing read ahead (the default), or - after set_helpers(n) - by n helper threads of the handle working
+// on a ring of blocks AHEAD of the consumer (what hts_set_threads does for htslib): the consumer then mostly parses records
+// while the next blocks are being inflated, so ONE interval is read at several cores' rate. Short jobs use it: with one thread
+// per interval all intervals of a wave complete at the same moment and the device has nothing to do until then.
+// Nothing is read ahead past `ahead_limit` (the end of the index chunk being walked), so at most the ring's depth in blocks is
+// inflated without being used when a query ends early.
 struct Bgzf {
     FILE* f = nullptr;
     int64_t block_coffset = -1;  // compressed offset of the block held in `buf`
     int64_t next_coffset = 0;
     std::vector<uint8_t> buf;    // uncompressed block
     size_t pos = 0;
-    std::vector<uint8_t> cbuf;
-    double t_inflate = 0.0;      // seconds spent reading + inflating blocks (stage timer)
+    double t_inflate = 0.0;      // consumer thread: seconds in load_block (file reads, its own inflates, waiting for helpers)
+    double t_helpers = 0.0;      // helper threads: seconds spent inflating (summed; guarded by m)
     int64_t bytes_inflated = 0;
     bool failed = false;         // a block could not be read for a reason OTHER than a clean end of file (message set)
-    int64_t fpos = -1;           // file position after the last read (-1 unknown): consecutive blocks need no seek, and an fseeko
-                                 // would throw the stdio buffer away every 20-64 KB
+    int64_t fpos = -1;           // file position (-1 unknown): consecutive blocks need no seek, and an fseeko would throw the
+                                 // stdio buffer away every 20-64 KB
     std::vector<char> iobuf;     // 1 MB stdio buffer (set on the first block)
-    void* ld = nullptr;          // libdeflate decompressor of this handle
-    ~Bgzf() { if (ld) libdeflate()->release(ld); }
+    void* ld = nullptr;          // libdeflate decompressor of the consuming thread
+    int64_t ahead_limit = INT64_MAX;   // blocks STARTING beyond this compressed offset are not read ahead
 
+    struct Slot {
+        int64_t coffset = -1, next = -1;
+        int clen = 0;
+        uint32_t isize = 0;
+        std::vector<uint8_t> cbuf, buf;
+        int state = 0;           // 0 free, 1 raw bytes loaded, 2 being inflated, 3 inflated, 4 failed (msg)
+        char msg[200];
+    };
+    std::vector<Slot> ring;      // slots head .. head + count - 1 (mod size) hold consecutive blocks of the file
+    size_t head = 0, count = 0;
+    int64_t file_next = 0;       // compressed offset of the block after the newest ring slot
+    bool ahead_eof = false;      // the file ended (or a raw read failed) at file_next
+    std::mutex m;                // guards slot states, head / count as seen by helpers, t_helpers, stop
+    std::condition_variable cv_work, cv_done;
+    std::vector<std::thread> helpers;
+    bool stop = false;
+    int sleepers = 0;            // helpers waiting for work (guarded by m)
+
+    ~Bgzf() {
+        stop_helpers();
+        if (ld) libdeflate()->release(ld);
+    }
     bool fail() { failed = true; return false; }
-    bool load_block(int64_t coffset) {
-        const double t0 = now_s();
-        if (iobuf.empty()) { iobuf.resize(1 << 20); setvbuf(f, iobuf.data(), _IOFBF, iobuf.size()); fpos = -1; }
-        if (coffset != fpos && fseeko(f, coffset, SEEK_SET) != 0) { io_err("seek to BGZF block at %lld failed", (long long)coffset); return fail(); }
-        fpos = -1;
-        uint8_t h[18];
-        const size_t got = fread(h, 1, 18, f);
-        if (got != 18) {   // nothing left at a block boundary = clean end of file; a partial header = truncated file
-            buf.clear(); pos = 0; block_coffset = coffset; next_coffset = coffset;
-            if (got != 0) { io_err("truncated BGZF block header at offset %lld", (long long)coffset); return fail(); }
+
+    // raw bytes of a slot -> its uncompressed bytes, CRC32 checked against the gzip trailer; `dec` = the calling thread's
+    // libdeflate decompressor (created on first use). On failure the message is left in the slot.
+    static bool inflate_slot(Slot& s, void*& dec) {
+        s.buf.resize(s.isize);
+        uint32_t crc = 0;
+        if (want_libdeflate()) {
+            Deflate* L = libdeflate();
+            if (!dec && !(dec = L->alloc())) { snprintf(s.msg, sizeof(s.msg), "libdeflate_alloc_decompressor failed"); return false; }
+            if (s.isize) {
+                size_t actual = 0;
+                const int rc = L->decompress(dec, s.cbuf.data(), (size_t)s.clen, s.buf.data(), s.isize, &actual);
+                if (rc != 0 || actual != s.isize) { snprintf(s.msg, sizeof(s.msg), "inflate failed (libdeflate %d) at offset %lld", rc, (long long)s.coffset); return false; }
+            }
+            crc = L->crc(0, s.buf.data(), s.isize);
+        } else {
+            if (s.isize) {
+                z_stream zs;
+                memset(&zs, 0, sizeof(zs));
+                if (inflateInit2(&zs, -15) != Z_OK) { snprintf(s.msg, sizeof(s.msg), "inflateInit2 failed"); return false; }
+                zs.next_in = s.cbuf.data(); zs.avail_in = (uInt)s.clen;
+                zs.next_out = s.buf.data(); zs.avail_out = s.isize;
+                const int rc = inflate(&zs, Z_FINISH);
+                inflateEnd(&zs);
+                if (rc != Z_STREAM_END) { snprintf(s.msg, sizeof(s.msg), "inflate failed (%d) at offset %lld", rc, (long long)s.coffset); return false; }
+            }
+            crc = (uint32_t)crc32(crc32(0L, Z_NULL, 0), s.buf.data(), (uInt)s.isize);
+        }
+        if (crc != rd32(&s.cbuf[s.clen])) {   // cheap next to the inflate
+            snprintf(s.msg, sizeof(s.msg), "BGZF block at offset %lld: CRC32 mismatch (corrupt file)", (long long)s.coffset);
             return false;
         }
-        if (h[0] != 31 || h[1] != 139 || h[2] != 8 || !(h[3] & 4)) { io_err("not a BGZF block at offset %lld", (long long)coffset); return fail(); }
+        return true;
+    }
+
+    // header + payload of the block at the current file position (= coffset) -> slot. 1 ok, 0 clean end of file (nothing left at
+    // a block boundary), -1 error (message set: a partial header or payload = truncated file)
+    int read_raw(int64_t coffset, Slot& s) {
+        uint8_t h[18];
+        const size_t got = fread(h, 1, 18, f);
+        fpos = -1;
+        if (got != 18) {
+            if (got != 0) { io_err("truncated BGZF block header at offset %lld", (long long)coffset); return -1; }
+            return 0;
+        }
+        if (h[0] != 31 || h[1] != 139 || h[2] != 8 || !(h[3] & 4)) { io_err("not a BGZF block at offset %lld", (long long)coffset); return -1; }
         const int xlen = rd16(h + 10);
-        if (xlen < 6) { io_err("BGZF block without BC field"); return fail(); }
+        if (xlen < 6) { io_err("BGZF block without BC field"); return -1; }
         // find the BC subfield (it is the first one in practice; scan to be safe, never past the extra field)
-        std::vector<uint8_t> extra(xlen);
-        memcpy(extra.data(), h + 12, 6);
-        if (xlen > 6 && fread(extra.data() + 6, 1, xlen - 6, f) != (size_t)(xlen - 6)) { io_err("truncated BGZF header"); return fail(); }
+        uint8_t extra_small[64];
+        std::vector<uint8_t> extra_big;
+        uint8_t* extra = extra_small;
+        if (xlen > (int)sizeof(extra_small)) { extra_big.resize(xlen); extra = extra_big.data(); }
+        memcpy(extra, h + 12, 6);
+        if (xlen > 6 && fread(extra + 6, 1, xlen - 6, f) != (size_t)(xlen - 6)) { io_err("truncated BGZF header"); return -1; }
         int bsize = -1;
         for (int i = 0; i + 4 <= xlen;) {
             const int slen = rd16(&extra[i + 2]);
@@ -147,47 +219,152 @@ struct Bgzf {
             if (extra[i] == 'B' && extra[i + 1] == 'C' && slen == 2) bsize = rd16(&extra[i + 4]);
             i += 4 + slen;
         }
-        if (bsize < 0) { io_err("BGZF block without BC field"); return fail(); }
+        if (bsize < 0) { io_err("BGZF block without BC field"); return -1; }
         const int clen = bsize + 1 - 12 - xlen - 8;
-        if (clen < 0) { io_err("corrupt BGZF block size"); return fail(); }
-        cbuf.resize(clen + 8);
-        if (fread(cbuf.data(), 1, clen + 8, f) != (size_t)(clen + 8)) { io_err("truncated BGZF block"); return fail(); }
-        const uint32_t isize = rd32(&cbuf[clen + 4]);
-        if (isize > 65536) { io_err("corrupt BGZF block (ISIZE %u > 64 KiB)", isize); return fail(); }
-        buf.resize(isize);
-        uint32_t crc = 0;
-        if (want_libdeflate()) {
-            Deflate* L = libdeflate();
-            if (!ld && !(ld = L->alloc())) { io_err("libdeflate_alloc_decompressor failed"); return fail(); }
-            if (isize) {
-                size_t actual = 0;
-                const int rc = L->decompress(ld, cbuf.data(), (size_t)clen, buf.data(), isize, &actual);
-                if (rc != 0 || actual != isize) { io_err("inflate failed (libdeflate %d) at offset %lld", rc, (long long)coffset); return fail(); }
+        if (clen < 0) { io_err("corrupt BGZF block size"); return -1; }
+        s.cbuf.resize((size_t)clen + 8);
+        if (fread(s.cbuf.data(), 1, (size_t)clen + 8, f) != (size_t)(clen + 8)) { io_err("truncated BGZF block"); return -1; }
+        const uint32_t isize = rd32(&s.cbuf[clen + 4]);
+        if (isize > 65536) { io_err("corrupt BGZF block (ISIZE %u > 64 KiB)", isize); return -1; }
+        s.coffset = coffset; s.clen = clen; s.isize = isize;
+        s.next = coffset + bsize + 1;
+        fpos = s.next;
+        return 1;
+    }
+
+    Slot& at(size_t i) { return ring[(head + i) % ring.size()]; }
+    // raw blocks into the free slots of the ring (consumer thread). `must_one`: the block at file_next is wanted itself and is
+    // read whatever the read-ahead limit says.
+    void refill(bool must_one) {
+        size_t added = 0;
+        while (count < ring.size() && !ahead_eof) {
+            if (!(must_one && count == 0) && file_next > ahead_limit) break;
+            Slot& s = at(count);   // free: no helper looks at slots beyond `count`
+            const int rc = read_raw(file_next, s);
+            if (rc == 0) { ahead_eof = true; break; }
+            std::lock_guard<std::mutex> lk(m);
+            if (rc < 0) {          // reported when (if) the consumer gets there
+                s.coffset = file_next; s.state = 4; ahead_eof = true;
+                snprintf(s.msg, sizeof(s.msg), "%.*s", (int)sizeof(s.msg) - 1, g_ioerr);
+            } else {
+                s.state = 1; file_next = s.next;
             }
-            crc = L->crc(0, buf.data(), isize);
-        } else {
-            if (isize) {
-                z_stream zs;
-                memset(&zs, 0, sizeof(zs));
-                if (inflateInit2(&zs, -15) != Z_OK) { io_err("inflateInit2 failed"); return fail(); }
-                zs.next_in = cbuf.data(); zs.avail_in = clen;
-                zs.next_out = buf.data(); zs.avail_out = isize;
-                const int rc = inflate(&zs, Z_FINISH);
-                inflateEnd(&zs);
-                if (rc != Z_STREAM_END) { io_err("inflate failed (%d) at offset %lld", rc, (long long)coffset); return fail(); }
+            count++;
+            added++;
+        }
+        if (added && !helpers.empty()) {   // one wake-up per batch of blocks, and only if somebody sleeps: a futex call per block
+                                           // costs the consumer more than the block's share of the inflate
+            bool wake;
+            { std::lock_guard<std::mutex> lk(m); wake = sleepers > 0; }
+            if (wake) cv_work.notify_all();
+        }
+    }
+    void pop_locked() { at(0).state = 0; head = (head + 1) % ring.size(); count--; }
+    // forget everything buffered (helpers finish the blocks they are working on first)
+    void drain() {
+        std::unique_lock<std::mutex> lk(m);
+        for (size_t i = 0; i < count; i++) if (at(i).state == 1) at(i).state = 0;
+        for (size_t i = 0; i < count; i++) { while (at(i).state == 2) cv_done.wait(lk); at(i).state = 0; }
+        head = 0; count = 0;
+    }
+    void helper_main() {
+        void* dec = nullptr;
+        std::unique_lock<std::mutex> lk(m);
+        for (;;) {
+            Slot* job = nullptr;
+            for (;;) {
+                if (stop) break;
+                for (size_t i = 0; i < count && !job; i++) if (at(i).state == 1) job = &at(i);   // the oldest waiting block
+                if (job) break;
+                sleepers++;
+                cv_work.wait(lk);
+                sleepers--;
             }
-            crc = (uint32_t)crc32(crc32(0L, Z_NULL, 0), buf.data(), (uInt)isize);
+            if (stop) break;
+            job->state = 2;
+            lk.unlock();
+            const double t0 = now_s();
+            const bool ok = inflate_slot(*job, dec);
+            const double dt = now_s() - t0;
+            lk.lock();
+            job->state = ok ? 3 : 4;
+            t_helpers += dt;
+            cv_done.notify_all();
         }
-        if (crc != rd32(&cbuf[clen])) {   // the gzip trailer's CRC32 of the uncompressed bytes: cheap next to the inflate
-            io_err("BGZF block at offset %lld: CRC32 mismatch (corrupt file)", (long long)coffset);
-            return fail();
-        }
-        block_coffset = coffset;
-        next_coffset = coffset + bsize + 1;
-        fpos = next_coffset;
-        pos = 0;
+        lk.unlock();
+        if (dec) libdeflate()->release(dec);
+    }
+    void stop_helpers() {
+        if (helpers.empty()) return;
+        { std::lock_guard<std::mutex> lk(m); stop = true; }
+        cv_work.notify_all();
+        for (std::thread& t : helpers) t.join();
+        helpers.clear();
+        stop = false;
+    }
+    // n helper threads (0 = the consumer inflates every block itself and nothing is read ahead)
+    void set_helpers(int n) {
+        stop_helpers();
+        drain();
+        fpos = -1;
+        n = std::max(0, std::min(n, 64));
+        ring.clear();
+        ring.resize(n ? (size_t)(4 * n + 4) : 1);
+        head = count = 0;
+        for (int i = 0; i < n; i++) helpers.emplace_back([this] { helper_main(); });
+    }
+
+    bool load_block(int64_t coffset) {
+        const double t0 = now_s();
+        const bool ok = load_block_(coffset);
         t_inflate += now_s() - t0;
-        bytes_inflated += isize;
+        return ok;
+    }
+    bool load_block_(int64_t coffset) {
+        if (ring.empty()) ring.resize(1);
+        if (iobuf.empty()) { iobuf.resize(1 << 20); setvbuf(f, iobuf.data(), _IOFBF, iobuf.size()); fpos = -1; }
+        if (count > 0 && at(0).coffset < coffset && coffset < file_next) {   // a forward skip inside what is buffered
+            std::unique_lock<std::mutex> lk(m);
+            while (count > 0 && at(0).coffset < coffset) {
+                while (at(0).state == 2) cv_done.wait(lk);
+                pop_locked();
+            }
+        }
+        if (!(count > 0 && at(0).coffset == coffset)) {   // not the block the ring continues with: start again there
+            drain();
+            if (coffset != fpos && fseeko(f, coffset, SEEK_SET) != 0) { io_err("seek to BGZF block at %lld failed", (long long)coffset); return fail(); }
+            fpos = coffset;
+            file_next = coffset; ahead_eof = false;
+        }
+        if (count == 0) refill(true);   // (otherwise the ring is topped up in batches after a block has been taken, below)
+        if (count == 0) {   // clean end of file at a block boundary
+            buf.clear(); pos = 0; block_coffset = coffset; next_coffset = coffset;
+            return false;
+        }
+        Slot& s = at(0);
+        {
+            std::unique_lock<std::mutex> lk(m);
+            if (s.state == 1) {   // no helper has picked it up: the consumer inflates it
+                s.state = 2;
+                lk.unlock();
+                const bool ok = inflate_slot(s, ld);
+                lk.lock();
+                s.state = ok ? 3 : 4;
+            } else {
+                while (s.state == 2) cv_done.wait(lk);
+            }
+            if (s.state == 4) {
+                io_err("%s", s.msg);
+                pop_locked();
+                return fail();
+            }
+            buf.swap(s.buf);
+            block_coffset = s.coffset; next_coffset = s.next; pos = 0;
+            bytes_inflated += s.isize;
+            pop_locked();
+        }
+        if (!helpers.empty() && count * 2 <= ring.size()) refill(false);   // top up in batches, half a ring at a time: the helpers
+                                                                           // work on them while the consumer parses
         return true;
     }
     bool seek(uint64_t voffset) {
@@ -209,10 +386,7 @@ struct Bgzf {
         while (n) {
             if (pos >= buf.size()) {
                 if (!load_block(next_coffset)) return false;
-                if (buf.empty()) {  // empty block (EOF marker) — try the next one
-                    if (feof(f)) return false;
-                    continue;
-                }
+                if (buf.empty()) continue;   // empty block (the EOF marker): the next load reports the end of the file
             }
             const size_t k = std::min(n, buf.size() - pos);
             memcpy(d, buf.data() + pos, k);
@@ -338,14 +512,33 @@ struct RefIndex {
 };
 
 // flat read storage shared by get_reads (one region) and fill_batch (many regions)
-// vector<uint8_t> whose resize() leaves new bytes uninitialised: the base / quality arrays (12 MB per 100 kb interval at 60x)
-// are overwritten right after they grow, and value-initialising them first was two more passes over that memory
-template <class T> struct raw_alloc : std::allocator<T> {
-    template <class U> struct rebind { typedef raw_alloc<U> other; };
-    template <class U> void construct(U* p) noexcept { ::new ((void*)p) U; }
-    template <class U, class... A> void construct(U* p, A&&... a) { ::new ((void*)p) U(std::forward<A>(a)...); }
+// Growable byte array whose resize() leaves new bytes uninitialised and grows through realloc(): the base / quality arrays
+// (12 MB per 100 kb interval at 60x) are overwritten right after they grow. (std::vector spent more time in resize() than the
+// record decode took: value-initialisation, or with a no-op construct() an element loop the compiler keeps, plus a copy per
+// doubling; realloc() of a block this size is an mremap.)
+struct ByteVec {
+    uint8_t* p = nullptr;
+    size_t n = 0, cap = 0;
+    ByteVec() {}
+    ByteVec(const ByteVec&) = delete;
+    ByteVec& operator=(const ByteVec&) = delete;
+    ~ByteVec() { free(p); }
+    size_t size() const { return n; }
+    uint8_t* data() { return p; }
+    const uint8_t* data() const { return p; }
+    uint8_t& operator[](size_t i) { return p[i]; }
+    void clear() { n = 0; }
+    void reserve(size_t c) {
+        if (c <= cap) return;
+        size_t nc = cap ? cap : 4096;
+        while (nc < c) nc *= 2;
+        uint8_t* q = (uint8_t*)realloc(p, nc);
+        if (!q) throw std::bad_alloc();
+        p = q; cap = nc;
+    }
+    void resize(size_t m) { reserve(m); n = m; }
+    void append(const uint8_t* src, size_t k) { const size_t at = n; resize(n + k); if (k) memcpy(p + at, src, k); }
 };
-typedef std::vector<uint8_t, raw_alloc<uint8_t>> ByteVec;
 
 struct ReadSink {
     std::vector<int64_t> pos, pos_end, base_off, cigar_off, name_off;
@@ -460,6 +653,12 @@ extern "C" void pvio_bam_close(pv_bam* b) {
     if (b->z.f) fclose(b->z.f);
     delete b;
 }
+// n helper threads inflate BGZF blocks ahead of the reading thread (0, the default: none, nothing read ahead)
+extern "C" int pvio_bam_set_threads(pv_bam* b, int n_helpers) {
+    if (!b) { io_err("null argument"); return -1; }
+    b->z.set_helpers(n_helpers);
+    return (int)b->z.helpers.size();
+}
 extern "C" int pvio_bam_nref(pv_bam* b) { return b ? (int)b->ref_names.size() : 0; }
 extern "C" const char* pvio_bam_ref_name(pv_bam* b, int i) { return (b && i >= 0 && i < (int)b->ref_names.size()) ? b->ref_names[i].c_str() : nullptr; }
 extern "C" int64_t pvio_bam_ref_len(pv_bam* b, int i) { return (b && i >= 0 && i < (int)b->ref_lens.size()) ? b->ref_lens[i] : -1; }
@@ -573,27 +772,48 @@ static int32_t aux_hp(const RecView& v) {
     return hp;
 }
 
-// clip one record to [start, stop] and append it to the sink (:180-306). 1 = appended, 0 = nothing kept, -1 = corrupt
+// 4-bit codes [q0, q0 + n) of a packed SEQ field -> letters
+static const struct PairLut { uint16_t t[256]; PairLut() { for (int b = 0; b < 256; b++) t[b] = (uint16_t)((uint8_t)NT16[b >> 4] | ((uint8_t)NT16[b & 15] << 8)); } } g_pair_lut;
+static void unpack_pairs(const uint8_t* seq, int64_t q, int64_t n, uint8_t* dst) {   // q even: two letters per packed byte
+    int64_t i = 0;
+    for (; i + 2 <= n; i += 2, q += 2) {
+        const uint16_t two = g_pair_lut.t[seq[q >> 1]];
+        memcpy(dst + i, &two, 2);
+    }
+    if (i < n) dst[i] = (uint8_t)NT16[seq[q >> 1] >> 4];
+}
+#if defined(__x86_64__)
+__attribute__((target("ssse3"))) static void unpack_pairs_ssse3(const uint8_t* seq, int64_t q, int64_t n, uint8_t* dst) {
+    const __m128i lut = _mm_loadu_si128((const __m128i*)NT16), m4 = _mm_set1_epi8(0x0F);
+    int64_t i = 0;
+    for (; i + 32 <= n; i += 32, q += 32) {   // 16 packed bytes -> 32 letters
+        const __m128i p = _mm_loadu_si128((const __m128i*)(seq + (q >> 1)));
+        const __m128i hi = _mm_shuffle_epi8(lut, _mm_and_si128(_mm_srli_epi16(p, 4), m4)), lo = _mm_shuffle_epi8(lut, _mm_and_si128(p, m4));
+        _mm_storeu_si128((__m128i*)(dst + i), _mm_unpacklo_epi8(hi, lo));
+        _mm_storeu_si128((__m128i*)(dst + i + 16), _mm_unpackhi_epi8(hi, lo));
+    }
+    unpack_pairs(seq, q, n - i, dst + i);
+}
+static const bool g_have_ssse3 = __builtin_cpu_supports("ssse3");
+#endif
+static void unpack_seq(const uint8_t* seq, int64_t q, int64_t n, uint8_t* dst) {
+    if (n > 0 && (q & 1)) { *dst++ = (uint8_t)NT16[seq[q >> 1] & 0xF]; q++; n--; }
+#if defined(__x86_64__)
+    if (g_have_ssse3) { unpack_pairs_ssse3(seq, q, n, dst); return; }
+#endif
+    unpack_pairs(seq, q, n, dst);
+}
+
+// clip one record to [start, stop] and append it to the sink (:180-306). 1 = appended, 0 = nothing kept, -1 = corrupt.
+// The reference appends the bases of every kept operation as it walks the CIGAR; the kept operations of a read cover ONE
+// contiguous range of its SEQ (from the first aligned base inside the window every SEQ-consuming operation is kept until the
+// walk leaves the window), so the walk only tracks that range and the bases / qualities are copied once at the end - an ONT
+// read has thousands of operations of a few bases each.
 static int clip_append(const RecView& v, int64_t start, int64_t stop, ReadSink& o) {
-    const size_t base0 = o.bases.size(), cig0 = o.cigar.size();
+    const size_t cig0 = o.cigar.size();
     int64_t pos_start = -1, pos_endv = -1, cur_pos = v.pos, cur_idx = 0;
+    int64_t q_first = 0, q_end = 0;   // kept SEQ range
     const int64_t l_seq = v.l_seq;
-    auto push_bases = [&](int64_t idx0, int64_t n) {
-        const size_t at = o.bases.size();
-        o.bases.resize(at + (size_t)n);
-        o.quals.resize(at + (size_t)n);
-        memcpy(&o.quals[at], v.qual + idx0, (size_t)n);
-        // 4-bit codes -> letters, two per packed byte through a 256-entry table of letter pairs
-        static const struct PairLut { uint16_t t[256]; PairLut() { for (int b = 0; b < 256; b++) t[b] = (uint16_t)((uint8_t)NT16[b >> 4] | ((uint8_t)NT16[b & 15] << 8)); } } lut;
-        uint8_t* dst = &o.bases[at];
-        int64_t i = 0, q = idx0;
-        if (n > 0 && (q & 1)) { dst[i++] = (uint8_t)NT16[v.seq[q >> 1] & 0xF]; q++; }
-        for (; i + 2 <= n; i += 2, q += 2) {
-            const uint16_t two = lut.t[v.seq[q >> 1]];
-            memcpy(dst + i, &two, 2);
-        }
-        if (i < n) dst[i] = (uint8_t)NT16[v.seq[q >> 1] >> 4];
-    };
     for (int64_t k = 0; k < v.n_cigar; k++) {
         const uint32_t c = v.cigar[k];
         const int op = c & 0xF;
@@ -611,21 +831,21 @@ static int clip_append(const RecView& v, int64_t start, int64_t stop, ReadSink& 
                 // bases with pos <= stop are kept: a closed form of the reference's per-base loop
                 const int64_t n = std::max<int64_t>(0, std::min(len - i0, stop - cur_pos + 1));
                 if (n > 0) {
-                    if (cur_idx + n > l_seq) { io_err("CIGAR longer than SEQ in a BAM record"); return -1; }
-                    if (pos_start == -1) { pos_start = cur_pos; pos_endv = pos_start; }
-                    push_bases(cur_idx, n);
+                    if (cur_idx + n > l_seq) { io_err("CIGAR longer than SEQ in a BAM record"); o.cigar.resize(cig0); return -1; }
+                    if (pos_start == -1) { pos_start = cur_pos; pos_endv = pos_start; q_first = cur_idx; }
                     kept = n;
                     pos_endv += n;
                     cur_idx += n;
                     cur_pos += n;
+                    q_end = cur_idx;
                 }
                 break;
             }
             case 4: case 1:
                 if (cur_pos >= start && cur_pos <= stop && pos_start != -1) {
-                    if (cur_idx + len > l_seq) { io_err("CIGAR longer than SEQ in a BAM record"); return -1; }
-                    push_bases(cur_idx, len);
+                    if (cur_idx + len > l_seq) { io_err("CIGAR longer than SEQ in a BAM record"); o.cigar.resize(cig0); return -1; }
                     kept = len;
+                    q_end = cur_idx + len;
                 }
                 cur_idx += len;
                 break;
@@ -643,9 +863,17 @@ static int clip_append(const RecView& v, int64_t start, int64_t stop, ReadSink& 
         }
         if (kept > 0) o.cigar.push_back((uint32_t)((kept << 4) | (uint32_t)op));
     }
-    if (o.bases.size() == base0) {  // nothing kept: the read is not returned (:432)
+    if (pos_start == -1) {  // nothing kept: the read is not returned (:432)
         o.cigar.resize(cig0);
         return 0;
+    }
+    {
+        const int64_t n = q_end - q_first;
+        const size_t at = o.bases.size();
+        o.bases.resize(at + (size_t)n);
+        o.quals.resize(at + (size_t)n);
+        memcpy(&o.quals[at], v.qual + q_first, (size_t)n);
+        unpack_seq(v.seq, q_first, n, &o.bases[at]);
     }
     o.pos.push_back(pos_start);
     o.pos_end.push_back(pos_endv);
@@ -691,7 +919,15 @@ static int query_region(pv_bam* b, int tid, int64_t start, int64_t stop, int inc
     std::vector<uint8_t> rec;
     std::vector<uint32_t> cigbuf;
     bool done = false;
+    size_t run_end = 0;
     for (size_t ci = 0; ci < chunks.size() && !done; ci++) {
+        if (ci >= run_end) {   // helpers do not inflate past the run of chunks that follow each other in the file: a writer that
+                               // starts a new block rather than split a record (htslib's bgzf_flush_try) ends a chunk at the end of
+                               // one block and begins the next at offset 0 of the following block - consecutive, but not mergeable
+            run_end = ci + 1;
+            while (run_end < chunks.size() && (int64_t)(chunks[run_end].beg >> 16) - (int64_t)(chunks[run_end - 1].end >> 16) <= (1 << 17)) run_end++;
+            b->z.ahead_limit = (int64_t)(chunks[run_end - 1].end >> 16);
+        }
         if (!b->z.seek(chunks[ci].beg)) { if (!b->z.failed) io_err("seek failed in BAM"); return -1; }   // (a failed block keeps its own message)
         while (b->z.tell() < chunks[ci].end) {
             uint8_t h4[4];
@@ -802,21 +1038,33 @@ extern "C" int64_t pvio_fasta_fetch(pv_fasta* fa, const char* contig, int64_t st
     int64_t beg = start < 0 ? 0 : start, end = stop - 1;  // inclusive
     if (end >= e.len) end = e.len - 1;
     if (beg > end) return 0;
-    int64_t n = 0;
-    int64_t p = beg;
-    std::vector<char> buf;
-    while (p <= end) {
-        const int64_t line = p / e.linebases, col = p % e.linebases;
-        const int64_t take = std::min(end - p + 1, e.linebases - col);
-        if (fseeko(fa->f, e.offset + line * e.linewidth + col, SEEK_SET) != 0) { io_err("seek failed in FASTA"); return -1; }
-        buf.resize(take);
-        if (fread(buf.data(), 1, take, fa->f) != (size_t)take) { io_err("truncated FASTA"); return -1; }
-        for (int64_t i = 0; i < take; i++) {
-            char c = buf[i];
-            if (c >= 'a' && c <= 'z') c -= 32;
-            out[n++] = c;
+    // one seek, then sequential reads of the span (line ends included) in pieces of up to 4 MB; the line ends are dropped while
+    // copying: a seek per line would throw the stdio buffer away ~1800 times per 110 kb
+    const int64_t off0 = e.offset + (beg / e.linebases) * e.linewidth + beg % e.linebases;
+    const int64_t off1 = e.offset + (end / e.linebases) * e.linewidth + end % e.linebases;
+    if (fseeko(fa->f, off0, SEEK_SET) != 0) { io_err("seek failed in FASTA"); return -1; }
+    std::vector<char> buf((size_t)std::min<int64_t>(off1 - off0 + 1, 1 << 22));
+    int64_t n = 0, col = beg % e.linebases;   // col in [0, linewidth): columns >= linebases are the line terminator
+    for (int64_t left = off1 - off0 + 1; left > 0;) {
+        const size_t k = (size_t)std::min<int64_t>(left, (int64_t)buf.size());
+        if (fread(buf.data(), 1, k, fa->f) != k) { io_err("truncated FASTA"); return -1; }
+        left -= (int64_t)k;
+        for (size_t i = 0; i < k;) {
+            if (col >= e.linebases) {   // inside the terminator
+                const size_t skip = (size_t)std::min<int64_t>((int64_t)(k - i), e.linewidth - col);
+                i += skip; col += (int64_t)skip;
+                if (col == e.linewidth) col = 0;
+                continue;
+            }
+            const size_t take = (size_t)std::min<int64_t>((int64_t)(k - i), e.linebases - col);
+            for (size_t j = 0; j < take; j++) {
+                char c = buf[i + j];
+                if (c >= 'a' && c <= 'z') c -= 32;
+                out[n++] = c;
+            }
+            i += take; col += (int64_t)take;
+            if (col == e.linewidth) col = 0;
         }
-        p += take;
     }
     return n;
 }
@@ -896,6 +1144,8 @@ extern "C" int pvio_fill_batch(pv_bam* b, pv_fasta* fa, int n_intervals, const c
     *out = nullptr;
     const double t_begin = now_s();
     const double infl0 = b->z.t_inflate;
+    double help0;
+    { std::lock_guard<std::mutex> lk(b->z.m); help0 = b->z.t_helpers; }
     const int64_t inflb0 = b->z.bytes_inflated;
     pvio_batch_store* st = new pvio_batch_store();
     ReadSink& s = st->sink;
@@ -928,8 +1178,8 @@ extern "C" int pvio_fill_batch(pv_bam* b, pv_fasta* fa, int n_intervals, const c
                 const size_t r = r0 + (size_t)keep[q];
                 t.pos.push_back(s.pos[r]); t.pos_end.push_back(s.pos_end[r]); t.flag.push_back(s.flag[r]);
                 t.is_rev.push_back(s.is_rev[r]); t.mapq.push_back(s.mapq[r]); t.hp.push_back(s.hp[r]);
-                t.bases.insert(t.bases.end(), s.bases.begin() + s.base_off[r], s.bases.begin() + s.base_off[r + 1]);
-                t.quals.insert(t.quals.end(), s.quals.begin() + s.base_off[r], s.quals.begin() + s.base_off[r + 1]);
+                t.bases.append(s.bases.data() + s.base_off[r], (size_t)(s.base_off[r + 1] - s.base_off[r]));
+                t.quals.append(s.quals.data() + s.base_off[r], (size_t)(s.base_off[r + 1] - s.base_off[r]));
                 t.cigar.insert(t.cigar.end(), s.cigar.begin() + s.cigar_off[r], s.cigar.begin() + s.cigar_off[r + 1]);
                 t.base_off.push_back((int64_t)t.bases.size());
                 t.cigar_off.push_back((int64_t)t.cigar.size());
@@ -944,8 +1194,8 @@ extern "C" int pvio_fill_batch(pv_bam* b, pv_fasta* fa, int n_intervals, const c
                 s.cigar_off.push_back(c0 + t.cigar_off[q + 1]);
                 s.name_off.push_back(0);
             }
-            s.bases.insert(s.bases.end(), t.bases.begin(), t.bases.end());
-            s.quals.insert(s.quals.end(), t.quals.begin(), t.quals.end());
+            s.bases.append(t.bases.data(), t.bases.size());
+            s.quals.append(t.quals.data(), t.quals.size());
             s.cigar.insert(s.cigar.end(), t.cigar.begin(), t.cigar.end());
         }
         if (s.n_reads() == r0) continue;  // "no group when no reads" (:212-213)
@@ -984,6 +1234,7 @@ extern "C" int pvio_fill_batch(pv_bam* b, pv_fasta* fa, int n_intervals, const c
     v.cigar_off = s.cigar_off.data(); v.cigar = s.cigar.data();
     v.interval_index = st->interval_index.data(); v.reads_seen = st->reads_seen.data();
     v.t_inflate = b->z.t_inflate - infl0;
+    { std::lock_guard<std::mutex> lk(b->z.m); v.t_helpers = b->z.t_helpers - help0; }
     v.t_total = now_s() - t_begin;
     v.bytes_inflated = b->z.bytes_inflated - inflb0;
     v.read_hp = s.hp.data();

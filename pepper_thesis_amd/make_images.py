@@ -162,8 +162,8 @@ def cpu_share() -> int:
 def region_batches(bam_path: str, fasta_path: str, region: str = None, region_size: int = 100_000, min_mapq: int = 5,
                    include_supplementary: bool = False, downsample_rate: float = 1.0, intervals_per_call: int = 16,
                    rank: int = 0, world: int = 1, reader_threads: int = None, intervals_per_read: int = 1, T: dict = None,
-                   region_bed: str = None, merge: bool = True):
-    """The reader side of generate_images (ImageGenerationUI.py:277-345) as a generator of (RegionBatch, interval of every
+                   region_bed: str = None, merge: bool = True, inflate_helpers: int = None):
+    """The reader side of generate_images (ImageGenerationUI.py:277-345): returns an iterator of (RegionBatch, interval of every
     batch region) pairs, `intervals_per_call` intervals per batch; interval i belongs to rank i % world (:211).
 
     The reference gives every worker PROCESS its own BAM/FASTA handles and lets it fetch, summarise and write one interval
@@ -194,51 +194,76 @@ def region_batches(bam_path: str, fasta_path: str, region: str = None, region_si
     ipr = max(1, min(int(intervals_per_read), int(intervals_per_call)))
     groups = [mine[k:k + ipr] for k in range(0, len(mine), ipr)]
     reads_per_call = max(1, int(intervals_per_call) // ipr)
-    n_thr = max(1, min(int(reader_threads or min(cpu_share(), 16)), max(len(groups), 1)))   # (beyond 16 the readers stop scaling)
-    T["reader_threads"], T["intervals"] = n_thr, len(mine)
+    budget = max(1, int(reader_threads or min(cpu_share(), 16)))     # host threads (beyond 16 the readers stop scaling)
+    # Every thread of the budget reads its own interval. `inflate_helpers` > 0 instead gives every reader that many helper
+    # threads which inflate BGZF blocks ahead of it (BamHandler.set_threads; htslib's hts_set_threads): an interval is then
+    # read ~3x sooner and fewer are in flight. Measured on the MI355X box's 16-CPU quota (3.2 Mbp job, fused pipeline): 16 x 0
+    # 107-118 ms, 4 x 3 137-260 ms, 8 x 1 160-170 ms - helpers sleep and wake once per few blocks, and threads that hop between
+    # the host's CPUs strand the cgroup's quota slices, which starves the thread that feeds the GPU; so it stays opt-in.
+    inflate_helpers = max(0, int(inflate_helpers or 0))
+    n_thr = max(1, min(budget // (inflate_helpers + 1), max(len(groups), 1)))
+    T["reader_threads"], T["inflate_helpers"], T["intervals"] = n_thr, inflate_helpers, len(mine)
+    T.setdefault("read_helper_cpu_s", 0.0)
     tls = threading.local()
 
     def read_group(ivs):
         if not hasattr(tls, "h"):
             tls.h = (BamHandler(bam_path), FastaHandler(fasta_path))   # one handle pair per reader thread
+            if inflate_helpers:
+                tls.h[0].set_threads(inflate_helpers)
         return fill_batch(tls.h[0], tls.h[1], ivs, min_mapq, include_supplementary, downsample_rate, REGION_SAFE_BASES)
 
-    with ThreadPoolExecutor(n_thr) as pool:
-        pending = deque()
-        nxt = 0
-        ahead = reads_per_call + n_thr + 2                           # reads in flight: one batch's worth + the pool
-        while nxt < len(groups) and len(pending) < ahead:
-            pending.append(pool.submit(read_group, groups[nxt]))
-            nxt += 1
-        while pending:
-            fbs = []
-            t0 = time.perf_counter()
-            while pending and len(fbs) < reads_per_call:
-                fbs.append(pending.popleft().result())
-                if nxt < len(groups):
-                    pending.append(pool.submit(read_group, groups[nxt]))
-                    nxt += 1
-            T["reader_stall_s"] += time.perf_counter() - t0
-            names = []                                               # interval of every batch region, in batch order
-            for fb in fbs:
-                T["read_inflate_cpu_s"] += fb.t_inflate
-                T["read_decode_cpu_s"] += fb.t_total - fb.t_inflate
-                T["bytes_inflated"] += fb.bytes_inflated
-                names += [fb.intervals[int(i)] for i in fb.interval_index]
-            t0 = time.perf_counter()
-            if merge:
-                batch = merge_batches([fb.batch for fb in fbs])
-            else:
-                batch = [fb.batch for fb in fbs if fb.batch.n_regions]
-            T["merge_s"] += time.perf_counter() - t0
-            n_reg = batch.n_regions if merge else len(names)
-            if n_reg:                                                # "no group when no reads" (AlignmentSummarizer.py:212-213)
-                T["bases"] += batch.n_bases if merge else sum(b.n_bases for b in batch)
-                T["reads"] += batch.n_reads if merge else sum(b.n_reads for b in batch)
-                yield batch, names
-            del batch
-            for fb in fbs:
-                fb.close()
+    # the pool is started and the first reads are submitted HERE, not at the first next(): the caller can do its own set-up
+    # (load the model) while the first intervals are being read
+    pool = ThreadPoolExecutor(n_thr)
+    pending = deque()
+    nxt = 0
+    ahead = reads_per_call + n_thr + 2                               # reads in flight: one batch's worth + the pool
+    while nxt < len(groups) and len(pending) < ahead:
+        pending.append(pool.submit(read_group, groups[nxt]))
+        nxt += 1
+
+    def batches():
+        nonlocal nxt
+        try:
+            while pending:
+                fbs = []
+                t0 = time.perf_counter()
+                # the next read (waiting for it if need be) and whatever has completed behind it: when the readers are the
+                # slower side every interval goes to the device the moment it is there, when the device is, the calls fill up
+                # by themselves
+                while pending and len(fbs) < reads_per_call and (not fbs or pending[0].done()):
+                    fbs.append(pending.popleft().result())
+                    if nxt < len(groups):
+                        pending.append(pool.submit(read_group, groups[nxt]))
+                        nxt += 1
+                T["reader_stall_s"] += time.perf_counter() - t0
+                names = []                                           # interval of every batch region, in batch order
+                for fb in fbs:
+                    T["read_inflate_cpu_s"] += fb.t_inflate
+                    T["read_decode_cpu_s"] += fb.t_total - fb.t_inflate
+                    T["read_helper_cpu_s"] += fb.t_helpers
+                    T["bytes_inflated"] += fb.bytes_inflated
+                    names += [fb.intervals[int(i)] for i in fb.interval_index]
+                t0 = time.perf_counter()
+                if merge:
+                    batch = merge_batches([fb.batch for fb in fbs])
+                else:
+                    batch = [fb.batch for fb in fbs if fb.batch.n_regions]
+                T["merge_s"] += time.perf_counter() - t0
+                n_reg = batch.n_regions if merge else len(names)
+                if n_reg:                                            # "no group when no reads" (AlignmentSummarizer.py:212-213)
+                    T["bases"] += batch.n_bases if merge else sum(b.n_bases for b in batch)
+                    T["reads"] += batch.n_reads if merge else sum(b.n_reads for b in batch)
+                    yield batch, names
+                del batch
+                for fb in fbs:
+                    fb.close()
+        finally:
+            for f in pending:
+                f.cancel()
+            pool.shutdown(wait=True)
+    return batches()
 
 
 def generate_images(ctx, bam_path: str, fasta_path: str, output_dir: str, params: Params, region: str = None,

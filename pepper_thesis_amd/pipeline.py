@@ -31,18 +31,37 @@ def _writer_loop(q: "queue.Queue", pred_path: str, image_path: Optional[str], ba
             img = ImageStore(image_path, "w") if image_path else None
             try:
                 batch_no = 0
+                keys = ("contigs", "positions", "depths", "candidates", "candidate_frequency")
+                carry = None   # windows not yet written: the groups hold exactly `batch_size` windows whatever the calls' sizes were
+
+                def emit(rows, final):
+                    nonlocal batch_no
+                    n = len(rows["positions"])
+                    i = 0
+                    while n - i >= batch_size or (final and i < n):
+                        sl = slice(i, i + batch_size)
+                        out.write_prediction(batch_no, rows["contigs"][sl], rows["positions"][sl], rows["depths"][sl], rows["candidates"][sl],
+                                             rows["candidate_frequency"][sl], rows["probs"][sl].astype(np.float64))
+                        batch_no += 1
+                        i += batch_size
+                    return {k: v[i:] for k, v in rows.items()} if i < n else None
+
                 while True:
                     item = q.get()
                     if item is None:
+                        if carry is not None:
+                            emit(carry, True)
                         break
                     t0 = time.perf_counter()
                     names, rec, probs, images = item
-                    n = len(rec["positions"])
-                    for i in range(0, n, batch_size):
-                        sl = slice(i, i + batch_size)
-                        out.write_prediction(batch_no, rec["contigs"][sl], rec["positions"][sl], rec["depths"][sl], rec["candidates"][sl],
-                                             rec["candidate_frequency"][sl], probs[sl].astype(np.float64))
-                        batch_no += 1
+                    rows = {k: rec[k] for k in keys}
+                    rows["probs"] = probs
+                    if len(probs):
+                        if carry is not None:
+                            w = max(carry["contigs"].dtype.itemsize, rows["contigs"].dtype.itemsize)
+                            carry["contigs"], rows["contigs"] = carry["contigs"].astype("S%d" % w), rows["contigs"].astype("S%d" % w)
+                            rows = {k: np.concatenate([carry[k], rows[k]]) for k in rows}
+                        carry = emit(rows, False)
                     if img is not None:
                         for g, (contig, start, end) in enumerate(names):
                             sel = np.flatnonzero(rec["region"] == g)
@@ -62,7 +81,7 @@ def call_variant_fused(ctx, state_dict: dict, bam_path: str, fasta_path: str, pr
                        region_size: int = 100_000, min_mapq: int = 5, include_supplementary: bool = False,
                        downsample_rate: float = 1.0, batch_size: int = 512, intervals_per_call: int = 16, rank: int = 0,
                        world: int = 1, reader_threads: int = None, keep_images_path: Optional[str] = None, timers: dict = None,
-                       dtype: int = _ffi.PV_DTYPE_F32, region_bed: str = None) -> int:
+                       dtype: int = _ffi.PV_DTYPE_F32, region_bed: str = None, inflate_helpers: int = None) -> int:
     """-> number of windows predicted. One prediction file at `pred_path` (and one image file at `keep_images_path`, if given)
     for the intervals of this rank."""
     import torch
@@ -72,8 +91,17 @@ def call_variant_fused(ctx, state_dict: dict, bam_path: str, fasta_path: str, pr
     t_start = time.perf_counter()
     dev = "cuda:%d" % ctx.device_id
     T = dict(upload_s=0.0, device_call_s=0.0, readback_s=0.0, hdf5_write_s=0.0, builder_retries=0)
-    Predictor(ctx, state_dict, "p1", dtype)
-    T["load_weights_s"] = time.perf_counter() - t_start
+    # the readers start on the first intervals here; the model is loaded while they read
+    batches = region_batches(bam_path, fasta_path, region, region_size, min_mapq, include_supplementary, downsample_rate,
+                             intervals_per_call, rank, world, reader_threads, 1, T, region_bed, merge=False,
+                             inflate_helpers=inflate_helpers)
+    t0 = time.perf_counter()
+    try:
+        Predictor(ctx, state_dict, "p1", dtype)
+    except BaseException:
+        batches.close()
+        raise
+    T["load_weights_s"] = time.perf_counter() - t0
     q: "queue.Queue" = queue.Queue(maxsize=4)
     werr: list = []
     os.makedirs(os.path.dirname(os.path.abspath(pred_path)), exist_ok=True)
@@ -85,9 +113,7 @@ def call_variant_fused(ctx, state_dict: dict, bam_path: str, fasta_path: str, pr
     cap, scap = 0, 0
     dout = probs = None
     try:
-        for parts, names in region_batches(bam_path, fasta_path, region, region_size, min_mapq, include_supplementary,
-                                           downsample_rate, intervals_per_call, rank, world, reader_threads, 1, T, region_bed,
-                                           merge=False):
+        for parts, names in batches:
             if werr:
                 break
             t0 = time.perf_counter()
@@ -135,6 +161,7 @@ def call_variant_fused(ctx, state_dict: dict, bam_path: str, fasta_path: str, pr
             n_windows += n_out
             del up
     finally:
+        batches.close()   # (stops the readers if the loop was left early)
         q.put(None)
         writer.join()
     if werr:

@@ -301,3 +301,72 @@ def test_corrupt_block_in_the_middle_of_a_query_is_an_error(tmp_path):
             assert "BGZF" in str(ei.value) or "inflate" in str(ei.value) or "corrupt" in str(ei.value)
     bamio.set_inflate_backend(True)
     assert n_good > 1000
+
+
+def test_inflate_helper_threads_give_the_same_reads_and_the_same_errors(tmp_path):
+    """pvio_bam_set_threads: helper threads inflate blocks ahead of the reading thread. The reads of many queries (forward,
+    backward, overlapping: the read-ahead ring is restarted, skipped into and run to the end of the file) are identical to the
+    handle without helpers; a damaged block and a truncated file are errors with helpers as without."""
+    build.build_io()
+    rng = np.random.default_rng(12)
+    recs = bw.random_records(rng, 3000, 60000, tid=0, mean_len=900, allow_skip=False)
+    fa, bam, _ = _small_files(tmp_path, recs)
+    queries = [(0, 60000), (30000, 31000), (1000, 20000), (59000, 60000), (0, 500), (15000, 45000), (44000, 60000), (100, 200)]
+
+    def run(handle):
+        out = []
+        for a, b_ in queries:
+            out.append([(r.pos, r.pos_end, r.bases, r.quals.tolist(), r.cigar.tolist(), r.mapq, r.query_name) for r in handle.get_reads("c1", a, b_, True, 0, 0)])
+        return out
+    base = bamio.BamHandler(bam)
+    exp = run(base)
+    assert len(exp[0]) > 1000
+    for n in (1, 3, 6):
+        h = bamio.BamHandler(bam)
+        assert h.set_threads(n) == n
+        assert run(h) == exp
+        assert h.set_threads(0) == 0 and run(h) == exp      # back to the plain reader on the same handle
+        assert h.set_threads(2) == 2 and run(h)[3] == exp[3]
+        h.close()
+    f = bamio.FastaHandler(fa)
+    a = bamio.fill_batch(base, f, [("c1", 1000, 30000), ("c1", 30000, 60000)], 0, True, 1.0, 100)
+    h = bamio.BamHandler(bam)
+    h.set_threads(3)
+    b = bamio.fill_batch(h, f, [("c1", 1000, 30000), ("c1", 30000, 60000)], 0, True, 1.0, 100)
+    for k in ("bases", "quals", "cigar", "read_pos", "base_off", "cigar_off", "read_off", "ref"):
+        assert np.array_equal(getattr(a.batch, k), getattr(b.batch, k)), k
+    assert b.t_helpers > 0 and a.t_helpers == 0
+    a.close(); b.close(); h.close()
+    # a damaged block in the middle, and a file cut inside a block
+    raw = bytearray(open(bam, "rb").read())
+    offs, p = [], 0
+    while p < len(raw):
+        offs.append(p)
+        p += int.from_bytes(raw[p + 16:p + 18], "little") + 1
+    bad = bytearray(raw)
+    bad[offs[len(offs) // 2] + 18 + 40] ^= 0x5A
+    cut = raw[:offs[len(offs) // 2] + 100]
+    for name, data, words in (("bad.bam", bad, ("BGZF", "inflate", "corrupt")), ("cut.bam", cut, ("truncated",))):
+        pth = str(tmp_path / name)
+        open(pth, "wb").write(bytes(data))
+        open(pth + ".bai", "wb").write(open(bam + ".bai", "rb").read())
+        for n in (0, 3):
+            h = bamio.BamHandler(pth)
+            h.set_threads(n)
+            with pytest.raises(IOError) as ei:
+                h.get_reads("c1", 0, 60000, True, 0, 0)
+            assert any(w in str(ei.value) for w in words), str(ei.value)
+            assert [r.pos for r in h.get_reads("c1", 0, 500, True, 0, 0)] == [e[0] for e in exp[4]]   # the handle stays usable before the damage
+            h.close()
+
+
+def test_fasta_fetch_of_a_long_span(tmp_path):
+    """pvio_fasta_fetch reads a span with one seek and sequential pieces of 4 MB: a 9.5 Mbp fetch across piece boundaries, line
+    width not a divisor of the piece size, start and end inside lines"""
+    build.build_io()
+    rng = np.random.default_rng(13)
+    seq = "".join(rng.choice(list("ACGTacgt"), size=10_000_000))
+    bw.write_fasta(str(tmp_path / "big.fa"), [("c0", "ACGT" * 10), ("big", seq)], width=61)
+    f = bamio.FastaHandler(str(tmp_path / "big.fa"))
+    for a, b_ in [(123_456, 9_654_321), (0, 10_000_000), (4_194_300, 4_194_310), (60, 62), (9_999_990, 10_000_050)]:
+        assert f.get_reference_sequence("big", a, b_) == seq[a:b_].upper(), (a, b_)

@@ -62,23 +62,29 @@ def run(ctx, weights, dev=None, mbp=3.2, keep_dir=None):
         swept = contig_len / 1e6
         # warm the page cache and the workspaces with a small region (untimed)
         pipeline.call_variant_fused(ctx, weights, bam, fa, os.path.join(d, "warm", "p.hdf"), P, region="chr20:0-50000", min_mapq=5)
-        t_f = {}
-        n = pipeline.call_variant_fused(ctx, weights, bam, fa, os.path.join(d, "pred_fused", "pepper_prediction.hdf"), P, min_mapq=5, timers=t_f)
+        runs = []
+        for k in range(3):   # the median of three runs (a 3.2 Mbp job lasts ~0.1 s: thread wake-ups alone move it by several per cent)
+            t_k = {}
+            n = pipeline.call_variant_fused(ctx, weights, bam, fa, os.path.join(d, "pred_fused", "pepper_prediction.hdf"), P, min_mapq=5, timers=t_k)
+            runs.append(t_k)
+        walls = [r["wall_s"] for r in runs]
+        t_f = sorted(runs, key=lambda r: r["wall_s"])[1]
         gpu_f = t_f["upload_s"] + t_f["device_call_s"] + t_f["readback_s"]
         out = {
             "workload": "synthetic chr20 of %.2f Mbp at 60x (10 kb reads): %d reads, %.1f M bases, BAM %.1f MB; %d intervals of 100 kb"
                         % (swept, info["reads"], info["bases"] / 1e6, info["bam_bytes"] / 1e6, t_f["intervals"]),
             "form": "fused (call_variant default): windows stay in HBM between the builder and the network, no image files",
             "windows": n, "mbp_per_s": swept / t_f["wall_s"], "windows_per_s": n / t_f["wall_s"], "wall_s": t_f["wall_s"],
-            "reader_threads": t_f["reader_threads"], "inflate_backend": info.get("inflate_backend"),
-            "bgzf_inflate_cpu_s": t_f["read_inflate_cpu_s"], "record_decode_clip_cpu_s": t_f["read_decode_cpu_s"],
-            "inflate_MBps_per_thread": t_f["bytes_inflated"] / max(t_f["read_inflate_cpu_s"], 1e-9) / 1e6,
+            "wall_s_of_3_runs": walls,
+            "reader_threads": t_f["reader_threads"], "inflate_helpers_per_reader": t_f["inflate_helpers"], "inflate_backend": info.get("inflate_backend"),
+            "reader_in_bgzf_s": t_f["read_inflate_cpu_s"], "helper_inflate_cpu_s": t_f["read_helper_cpu_s"], "record_decode_clip_cpu_s": t_f["read_decode_cpu_s"],
+            "MB_inflated": t_f["bytes_inflated"] / 1e6,
             "main_thread_waiting_for_readers_s": t_f["reader_stall_s"], "merge_s": t_f["merge_s"], "upload_s": t_f["upload_s"],
             "device_call_s(builder+rnn kernels)": t_f["device_call_s"], "readback_s": t_f["readback_s"],
             "hdf5_write_s(writer thread)": t_f["hdf5_write_s"], "load_weights_s": t_f["load_weights_s"],
             "host_share": 1.0 - gpu_f / t_f["wall_s"],
-            "note": "host share = 1 - (uploads + kernels + read-backs) / wall; the readers inflate BGZF on %d threads ahead of the GPU, "
-                    "the prediction file is written by its own thread" % t_f["reader_threads"],
+            "note": "host share = 1 - (uploads + kernels + read-backs) / wall; %d reader threads with %d BGZF inflate helpers each run ahead of the GPU, "
+                    "the prediction file is written by its own thread" % (t_f["reader_threads"], t_f["inflate_helpers"]),
         }
         # the reference's two steps through image files, for comparison
         t_img = {}

@@ -14,12 +14,16 @@ print("one interval, one thread: %.1f ms total, inflate %.1f ms (%.0f MB/s), dec
     (time.perf_counter() - t0) * 1e3, fb.t_inflate * 1e3, fb.bytes_inflated / fb.t_inflate / 1e6, (fb.t_total - fb.t_inflate) * 1e3, fb.batch.n_reads, fb.batch.n_bases / 1e6), flush=True)
 for backend in (True, False):
     bamio.set_inflate_backend(backend)
-    for thr in (4, 8, 16, 32):
+    for thr, helpers in ((4, 0), (8, 0), (16, 0), (32, 0), (8, 3), (16, 3), (16, 1), (16, 7)):
         T = {}
         t0 = time.perf_counter()
         n = 0
-        for parts, names in make_images.region_batches(bam, fa, None, 100000, 5, False, 1.0, 16, 0, 1, thr, 1, T, None, merge=False):
+        first = None
+        for parts, names in make_images.region_batches(bam, fa, None, 100000, 5, False, 1.0, 16, 0, 1, thr, 1, T, None, merge=False, inflate_helpers=helpers):
+            if first is None:
+                first = time.perf_counter() - t0
             n += sum(p.n_reads for p in parts)
         w = time.perf_counter() - t0
-        print("%s threads %2d: wall %.3f s = %.1f Mbp/s; summed thread time inflate %.2f decode %.2f" % (bamio.inflate_backend(), thr, w, 3.2 / w, T["read_inflate_cpu_s"], T["read_decode_cpu_s"]), flush=True)
+        print("%s budget %2d (readers %d x helpers %d): wall %.3f s = %.1f Mbp/s, first interval after %.0f ms; summed thread time: reader in load_block %.2f, decode %.2f, helpers %.2f" % (
+            bamio.inflate_backend(), thr, T["reader_threads"], T["inflate_helpers"], w, 3.2 / w, first * 1e3, T["read_inflate_cpu_s"], T["read_decode_cpu_s"], T["read_helper_cpu_s"]), flush=True)
 shutil.rmtree(d)
