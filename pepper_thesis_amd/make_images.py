@@ -287,6 +287,20 @@ def generate_images(ctx, bam_path: str, fasta_path: str, output_dir: str, params
         from .batch import hp_params
         params = hp_params(params)
     fname = "pepper_variants_images_thread_%d%s.hdf5" % (rank, "_hp" if use_hp_info else "")
+    if not use_hp_info and intervals_per_read == 1:
+        # the builder stage of the fused call_variant pipeline with the image file as its only output: the readers' per-interval
+        # arrays go straight to the device (no host concatenation), every interval as soon as it is read, the file is written
+        # by its own thread
+        from . import pipeline
+        T2 = {}
+        n_windows = pipeline.call_variant_fused(ctx, None, bam_path, fasta_path, None, params, region, region_size, min_mapq,
+                                                include_supplementary, downsample_rate, 512, intervals_per_call, rank, world,
+                                                reader_threads, os.path.join(output_dir, fname), T2, region_bed=region_bed)
+        T2["builder_call_s"] = T2["upload_s"] + T2["device_call_s"] + T2["readback_s"]
+        T2["wall_s"] = time.perf_counter() - t_start
+        if timers is not None:
+            timers.update(T2)
+        return n_windows
     with ImageStore(os.path.join(output_dir, fname), "w") as store:
         for batch, names in region_batches(bam_path, fasta_path, region, region_size, min_mapq, include_supplementary,
                                            downsample_rate, intervals_per_call, rank, world, reader_threads, intervals_per_read, T,

@@ -25,9 +25,10 @@ from .batch import Params
 
 
 def _writer_loop(q: "queue.Queue", pred_path: str, image_path: Optional[str], batch_size: int, T: dict, err: list):
+    import contextlib
     from .hdf5io import ImageStore, PredictionStore
     try:
-        with PredictionStore(pred_path, "w") as out:
+        with (PredictionStore(pred_path, "w") if pred_path else contextlib.nullcontext()) as out:
             img = ImageStore(image_path, "w") if image_path else None
             try:
                 batch_no = 0
@@ -55,8 +56,8 @@ def _writer_loop(q: "queue.Queue", pred_path: str, image_path: Optional[str], ba
                     t0 = time.perf_counter()
                     names, rec, probs, images = item
                     rows = {k: rec[k] for k in keys}
-                    rows["probs"] = probs
-                    if len(probs):
+                    rows["probs"] = probs if probs is not None else np.zeros((0, 3), np.float32)
+                    if out is not None and len(probs):
                         if carry is not None:
                             w = max(carry["contigs"].dtype.itemsize, rows["contigs"].dtype.itemsize)
                             carry["contigs"], rows["contigs"] = carry["contigs"].astype("S%d" % w), rows["contigs"].astype("S%d" % w)
@@ -83,7 +84,7 @@ def call_variant_fused(ctx, state_dict: dict, bam_path: str, fasta_path: str, pr
                        world: int = 1, reader_threads: int = None, keep_images_path: Optional[str] = None, timers: dict = None,
                        dtype: int = _ffi.PV_DTYPE_F32, region_bed: str = None, inflate_helpers: int = None) -> int:
     """-> number of windows predicted. One prediction file at `pred_path` (and one image file at `keep_images_path`, if given)
-    for the intervals of this rank."""
+    for the intervals of this rank. state_dict None = images only (make_images): no model, no prediction file."""
     import torch
     from .device import DeviceOut
     from .make_images import region_batches
@@ -96,15 +97,20 @@ def call_variant_fused(ctx, state_dict: dict, bam_path: str, fasta_path: str, pr
                              intervals_per_call, rank, world, reader_threads, 1, T, region_bed, merge=False,
                              inflate_helpers=inflate_helpers)
     t0 = time.perf_counter()
-    try:
-        Predictor(ctx, state_dict, "p1", dtype)
-    except BaseException:
-        batches.close()
-        raise
+    predict = state_dict is not None
+    if predict:
+        try:
+            Predictor(ctx, state_dict, "p1", dtype)
+        except BaseException:
+            batches.close()
+            raise
+    else:
+        assert keep_images_path and not pred_path
     T["load_weights_s"] = time.perf_counter() - t0
     q: "queue.Queue" = queue.Queue(maxsize=4)
     werr: list = []
-    os.makedirs(os.path.dirname(os.path.abspath(pred_path)), exist_ok=True)
+    if pred_path:
+        os.makedirs(os.path.dirname(os.path.abspath(pred_path)), exist_ok=True)
     if keep_images_path:
         os.makedirs(os.path.dirname(os.path.abspath(keep_images_path)), exist_ok=True)
     writer = threading.Thread(target=_writer_loop, args=(q, pred_path, keep_images_path, int(batch_size), T, werr), daemon=True)
@@ -138,7 +144,7 @@ def call_variant_fused(ctx, state_dict: dict, bam_path: str, fasta_path: str, pr
                     T["builder_retries"] += 1
                     T["device_call_s"] += time.perf_counter() - t0
                     continue
-                if n_out:
+                if n_out and predict:
                     ctx.forward_p1_dev(dout.images.data_ptr(), n_out, probs.data_ptr())
                     ctx.synchronize()   # raises if a split-form exchange timed out (the probabilities are then NaN)
                 T["device_call_s"] += time.perf_counter() - t0
@@ -154,7 +160,7 @@ def call_variant_fused(ctx, state_dict: dict, bam_path: str, fasta_path: str, pr
             rec = dict(region=region_idx, contigs=contigs, positions=dout.position[:n_out].cpu().numpy().astype(np.int32),
                        depths=dout.depth[:n_out].cpu().numpy(), candidates=cands,
                        candidate_frequency=dout.cand_freq[:n_out].cpu().numpy().reshape(-1, 1))
-            p = probs[:n_out].cpu().numpy()
+            p = probs[:n_out].cpu().numpy() if predict else None
             imgs = dout.images[:n_out].cpu().numpy() if keep_images_path else None
             T["readback_s"] += time.perf_counter() - t0
             q.put((names, rec, p, imgs))
