@@ -838,6 +838,10 @@ __global__ __launch_bounds__(512, 2) void k_gemm_bf16x3(GemmArgs g) {
         unsigned char* base = smg + buf * 4 * ARR + wv * 1024;
         const unsigned so = (unsigned)(kt * BK * 4);
         const int p = j >> 2, arr = j & 3;
+#ifdef PV_GEMM_ABL   // timing experiment (wrong results): bit 0 drops the A pieces, bit 1 the W pieces
+        if (((PV_GEMM_ABL) & 1) && arr < 2) return;
+        if (((PV_GEMM_ABL) & 2) && arr >= 2) return;
+#endif
         if (arr < 2) __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_ptr)(base + arr * ARR + p * 8192), 16, la[p], so + (arr & 1 ? 16u : 0u), 0, 0);
         else __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_ptr)(base + arr * ARR + p * 8192), 16, lw[p], so + (arr & 1 ? 16u : 0u), 0, 0);
     };
