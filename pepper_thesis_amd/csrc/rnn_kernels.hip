@@ -779,9 +779,12 @@ struct GemmArgs {
 // lands lane-linear (wave base + 16 B per lane), so the XOR swizzle that makes the fragment ds_read_b128 conflict-free
 // (16-byte chunk index ^ ((row >> 2) & 3) inside each 64-byte row) is applied on the SOURCE address of every lane. One
 // barrier per K step; per step and wave 24 ds_read_b128 feed 48 MFMAs. Work items are ordered n-tile fastest and dealt to the
-// XCDs in groups of one XCD's workgroups, so the CUs of an XCD work on the same few A row tiles at the same time. The next
-// item's first K step is requested BEFORE the epilogue stores (32 dwordx4 stores per wave in the quad layout), so it travels
-// while they are issued; its first K step then waits for everything the wave has in flight.
+// XCDs in groups of one XCD's workgroups, so the CUs of an XCD work on the same few A row tiles at the same time. The K steps
+// of a workgroup form ONE stream across its items: the first K step of the next item is requested during the last K step of
+// this one like any other (buffer = step parity), so an item ends with its 32 dwordx4 stores per wave (quad layout) and the
+// next one's operands are there when they are done; item coordinates advance by a constant step (no division per item).
+// (Before: coordinates by division, resources, ten LDS-DMA issues and a barrier BETWEEN two items: 4.6 k + 1.1 k of the
+// 13.9 k cycles an item boundary cost, the stores 5.1 k: -DPV_GEMM_STAMPS.)
 #ifdef PV_GEMM_STAMPS
 // diagnostic build: cycle sums of the K loop's phases (workgroup 0, every wave adds): {wait for the transfers, barrier, MFMA block,
 // epilogue + next tile's set-up}, and the K steps counted; read by pv_debug_gemm_stamps
@@ -808,32 +811,29 @@ __global__ __launch_bounds__(512, 2) void k_gemm_bf16x3(GemmArgs g) {
     const int kslice = g.K / g.splits, nk = kslice / BK;
     const unsigned row_bytes = (unsigned)g.K * 4u;
 
-    __amdgpu_buffer_rsrc_t ra, rw;
-    unsigned la[2], lw[2];
-    auto item_coords = [&](int it, int& mt, int& nt, int& sp) {
-        nt = it % g.tiles_n;
-        const int r = it / g.tiles_n;
-        sp = r % g.splits;
-        mt = r / g.splits;
-    };
-    auto item_setup = [&](int mt, int nt, int sp) {
-        const int64_t m0 = (int64_t)mt * BM;
-        const int n0 = nt * BN;
-        ra = make_rsrc(g.A + ((size_t)m0 * g.K + (size_t)sp * kslice) * 4);
-        rw = make_rsrc(g.W + ((size_t)n0 * g.K + (size_t)sp * kslice) * 4);
+    // An item's operands: buffer resources of its A row tile / W row tile (+ K slice) and the lane offsets of this wave's pieces.
+    // TWO sets: the item being multiplied and the one after it, whose first K step is requested during the last K step of this one.
+    struct Item { __amdgpu_buffer_rsrc_t ra, rw; unsigned la[2], lw[2]; int mt, nt, sp; };
+    // items of this workgroup: it0, it0 + grid, it0 + 2 grid, ... (group q of per_xcd consecutive items goes to the XCD class
+    // q % 8: it = (xcd + 8 q) per_xcd + slot). Coordinates advance by a constant step: no division per tile.
+    const int step_n = (int)gridDim.x % g.tiles_n, step_r = (int)gridDim.x / g.tiles_n;
+    auto item_setup = [&](Item& I) {
+        const int64_t m0 = (int64_t)I.mt * BM;
+        const int n0 = I.nt * BN;
+        I.ra = make_rsrc(g.A + ((size_t)m0 * g.K + (size_t)I.sp * kslice) * 4);
+        I.rw = make_rsrc(g.W + ((size_t)n0 * g.K + (size_t)I.sp * kslice) * 4);
 #pragma unroll
         for (int p = 0; p < 2; p++) {
             int64_t r = 16 * (8 * p + wv) + d_row;
             if (m0 + r >= g.M) r = g.M - 1 - m0;             // rows beyond M replicate the last row (never stored)
-            la[p] = (unsigned)r * row_bytes + d_chunk * 32u;
+            I.la[p] = (unsigned)r * row_bytes + d_chunk * 32u;
             int rn = 16 * (8 * p + wv) + d_row;
             if (n0 + rn >= g.N) rn = g.N - 1 - n0;
-            lw[p] = (unsigned)rn * row_bytes + d_chunk * 32u;
+            I.lw[p] = (unsigned)rn * row_bytes + d_chunk * 32u;
         }
     };
-    // 8 LDS-DMA pieces of this wave for K step kt into buffer buf
-    // piece j = 0..7 of this wave for K step kt into buffer buf: (p = j >> 2) x {A_hi, A_lo, W_hi, W_lo}
-    auto dma_piece = [&](int kt, int buf, int j) {
+    // piece j = 0..7 of this wave for K step kt of item I into buffer buf: (p = j >> 2) x {A_hi, A_lo, W_hi, W_lo}
+    auto dma_piece = [&](const Item& I, int kt, int buf, int j) {
         typedef __attribute__((address_space(3))) void* lds_ptr;
         unsigned char* base = smg + buf * 4 * ARR + wv * 1024;
         const unsigned so = (unsigned)(kt * BK * 4);
@@ -842,32 +842,24 @@ __global__ __launch_bounds__(512, 2) void k_gemm_bf16x3(GemmArgs g) {
         if (((PV_GEMM_ABL) & 1) && arr < 2) return;
         if (((PV_GEMM_ABL) & 2) && arr >= 2) return;
 #endif
-        if (arr < 2) __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_ptr)(base + arr * ARR + p * 8192), 16, la[p], so + (arr & 1 ? 16u : 0u), 0, 0);
-        else __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_ptr)(base + arr * ARR + p * 8192), 16, lw[p], so + (arr & 1 ? 16u : 0u), 0, 0);
+        if (arr < 2) __builtin_amdgcn_raw_ptr_buffer_load_lds(I.ra, (lds_ptr)(base + arr * ARR + p * 8192), 16, I.la[p], so + (arr & 1 ? 16u : 0u), 0, 0);
+        else __builtin_amdgcn_raw_ptr_buffer_load_lds(I.rw, (lds_ptr)(base + arr * ARR + p * 8192), 16, I.lw[p], so + (arr & 1 ? 16u : 0u), 0, 0);
     };
-    auto dma = [&](int kt, int buf) {
-#pragma unroll
-        for (int j = 0; j < 8; j++) dma_piece(kt, buf, j);
-    };
-
-    // the bias of an item's 256 columns also arrives by LDS-DMA (one 1 KB piece, wave 0) into a slot behind the two operand
-    // buffers: the kernel holds no register-destination load at all (one consumed while LDS-DMAs are in flight makes hipcc
-    // drain the whole vmcnt queue at that point)
+    // the bias of an item's 256 columns also arrives by LDS-DMA (one 1 KB piece, wave 0) into one of two slots behind the operand
+    // buffers (items alternate: the next item's bias travels while this one's is still to be read): the kernel holds no
+    // register-destination load at all (one consumed while LDS-DMAs are in flight makes hipcc drain the whole vmcnt queue there)
     float* sbias = reinterpret_cast<float*>(smg + 2 * 4 * ARR);
-    auto dma_bias = [&](int nt_) {
+    auto dma_bias = [&](int nt_, int bslot) {
         typedef __attribute__((address_space(3))) void* lds_ptr;
         if (g.bias && wv == 0)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(make_rsrc(g.bias + nt_ * BN), (lds_ptr)sbias, 16, (unsigned)lane * 16u, 0, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(make_rsrc(g.bias + nt_ * BN), (lds_ptr)(sbias + bslot * BN), 16, (unsigned)lane * 16u, 0, 0, 0);
     };
 #ifndef PV_GEMM_VMCNT
     // Completion of a K step's transfers WITHOUT s_waitcnt vmcnt: the counter also holds the epilogue stores of the previous
-    // tile (256 KB per workgroup), which the first K step of the next tile then waits for as well. Loads complete in issue
-    // order, so behind the pieces of a K step every wave issues one more LDS-DMA that copies the word iota[seq] into its own
-    // flag slot, and polls that slot in LDS until the word is there: the pieces before it have landed, whatever the stores are
-    // doing. (Measured: no change by itself - 1.59 ms either way for the decoder projection: what an epilogue costs is the ISSUE
-    // of its 32 stores per wave at the ~19 B/clk a CU's store path takes, 13.8 k cycles per tile by the phase stamps of
-    // -DPV_GEMM_STAMPS, not their completion. Kept: it removes the only wait in the kernel that depends on stores.)
-    unsigned* sflag = reinterpret_cast<unsigned*>(smg + 2 * 4 * ARR + 1024) + wv * 64;   // 256 B per wave
+    // tile (256 KB per workgroup). Loads complete in issue order, so behind the pieces of a K step every wave issues one more
+    // LDS-DMA that copies the word iota[seq] into its own flag slot, and polls that slot in LDS until the word is there: the
+    // pieces before it have landed, whatever the stores are doing.
+    unsigned* sflag = reinterpret_cast<unsigned*>(smg + 2 * 4 * ARR + 2048) + wv * 64;   // 256 B per wave
     sflag[lane] = 0xFFFFFFFFu;
     unsigned seq = 0;
     const __amdgpu_buffer_rsrc_t riota = make_rsrc(g.iota);
@@ -892,21 +884,38 @@ __global__ __launch_bounds__(512, 2) void k_gemm_bf16x3(GemmArgs g) {
     auto dma_flag = [&]() {};
     auto dma_wait = [&]() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); };
 #endif
-    int q = 0;                                    // group q of per_xcd consecutive items goes to the XCD class q % 8
-    int it = (xcd + 8 * q) * per_xcd + slot;
-    int mt = 0, nt = 0, sp = 0;
+    int it = xcd * per_xcd + slot;
+    Item cur, nxt;
+    cur.mt = cur.nt = cur.sp = 0;
+    int r_cur = 0;                                // it / tiles_n of the current item
+    unsigned gstep = 0;                           // K steps of this workgroup so far: step s uses operand buffer s & 1, across items
+    int tile_no = 0;                              // items so far: bias slot tile_no & 1
     if (it < g.items) {
-        item_coords(it, mt, nt, sp);
-        item_setup(mt, nt, sp);
-        dma(0, 0);
-        dma_bias(nt);
+        cur.nt = it % g.tiles_n;
+        r_cur = it / g.tiles_n;
+        cur.sp = r_cur % g.splits;
+        cur.mt = r_cur / g.splits;
+        item_setup(cur);
+#pragma unroll
+        for (int j = 0; j < 8; j++) dma_piece(cur, 0, 0, j);
+        dma_bias(cur.nt, 0);
         dma_flag();
     }
 #ifdef PV_GEMM_STAMPS
-    unsigned long long gs_acc[5] = {0, 0, 0, 0, 0}, gs_last;
+    unsigned long long gs_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, gs_last;
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(gs_last) :: "memory");
 #endif
     while (it < g.items) {
+        // the item after this one (its first K step is requested during this item's last)
+        const int it_n = it + (int)gridDim.x;
+        const bool has_next = it_n < g.items;
+        int r_n = r_cur + step_r;
+        nxt.nt = cur.nt + step_n;
+        if (nxt.nt >= g.tiles_n) { nxt.nt -= g.tiles_n; r_n++; }
+        if (g.splits == 1) { nxt.sp = 0; nxt.mt = r_n; }
+        else { nxt.sp = r_n % g.splits; nxt.mt = r_n / g.splits; }
+        if (has_next) item_setup(nxt);
+        GSTAMP(6)
         f32x16 acc[4][2];
 #pragma unroll
         for (int mi = 0; mi < 4; mi++)
@@ -914,9 +923,12 @@ __global__ __launch_bounds__(512, 2) void k_gemm_bf16x3(GemmArgs g) {
             for (int ni = 0; ni < 2; ni++)
 #pragma unroll
                 for (int r = 0; r < 16; r++) acc[mi][ni][r] = 0.0f;
-        for (int kt = 0; kt < nk; kt++) {
-            const int buf = kt & 1;
-            // this step's operands have landed (every wave waits for its own DMAs, then the barrier); the other buffer is free
+        // one K step: wait for its operands, multiply, and request the operands of the step after it - K step s_kt of item S -
+        // into the other buffer (issue == false: there is no such step)
+        auto k_step = [&](const Item& S, int s_kt, bool issue, bool next_bias) {
+            const int buf = (int)(gstep & 1u);
+            // this step's operands have landed (every wave waits for its own DMAs, then the barrier); the other buffer is free:
+            // every wave is past the step that read it.
             // (a counted wait that lets the previous item's epilogue stores stay in flight is NOT safe here: vmcnt retires loads
             // in order among loads and stores among stores, but a store may retire before an older LDS-DMA load, so "at most 32
             // outstanding" does not imply the DMAs have landed. It gave a sporadic 1e-4 error in one of five full test runs.)
@@ -926,9 +938,6 @@ __global__ __launch_bounds__(512, 2) void k_gemm_bf16x3(GemmArgs g) {
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
             GSTAMP(1)
-#ifdef PV_GEMM_DMA_BURST
-            if (kt + 1 < nk) { dma(kt + 1, buf ^ 1); dma_flag(); }
-#endif
             const unsigned char* base = smg + buf * 4 * ARR;
             // the next step's eight pieces are issued one per (ks, mi) block of this step's MFMAs instead of as a burst behind
             // the barrier: an LDS-DMA costs its wave ~100-150 issue cycles, and the two waves of a SIMD - phase-locked by the
@@ -946,12 +955,13 @@ __global__ __launch_bounds__(512, 2) void k_gemm_bf16x3(GemmArgs g) {
                 for (int mi = 0; mi < 4; mi++) {
                     const bf16x8 ah = *reinterpret_cast<const bf16x8*>(base + fa_l + mi * 32 * 64 + ch);
                     const bf16x8 al = *reinterpret_cast<const bf16x8*>(base + ARR + fa_l + mi * 32 * 64 + ch);
-#ifndef PV_GEMM_DMA_BURST
-                    if (kt + 1 < nk) {
-                        dma_piece(kt + 1, buf ^ 1, ks * 4 + mi);
-                        if (ks == 1 && mi == 3) dma_flag();
+                    if (issue) {
+                        dma_piece(S, s_kt, buf ^ 1, ks * 4 + mi);
+                        if (ks == 1 && mi == 3) {
+                            if (next_bias) dma_bias(nxt.nt, (tile_no + 1) & 1);
+                            dma_flag();
+                        }
                     }
-#endif
 #pragma unroll
                     for (int ni = 0; ni < 2; ni++) {
                         acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh[ni], acc[mi][ni], 0, 0, 0);
@@ -964,30 +974,21 @@ __global__ __launch_bounds__(512, 2) void k_gemm_bf16x3(GemmArgs g) {
 #ifdef PV_GEMM_STAMPS
             gs_acc[4]++;
 #endif
-        }
+            gstep++;
+        };
+        for (int kt = 0; kt + 1 < nk; kt++) k_step(cur, kt + 1, true, false);
+        k_step(nxt, 0, has_next, true);          // the last step requests step 0 of the next item (and its bias)
         // C tile as a sized buffer resource: rows beyond M fall outside it and are dropped by the bounds check; the
         // address of every store is (tile resource) + (lane offset) + (scalar offset of (wave, mi, ni, r))
-        const int64_t m0 = (int64_t)mt * BM;
-        const int n0 = nt * BN;
+        const int64_t m0 = (int64_t)cur.mt * BM;
+        const int n0 = cur.nt * BN;
         const int64_t rows_left = g.M - m0 < BM ? g.M - m0 : BM;
-        float* cbase = g.C + (size_t)sp * g.M * g.N;
+        float* cbase = g.C + (size_t)cur.sp * g.M * g.N;
         float bv[2];
+        // (this item's bias slot is written again during the last K step of the NEXT item: every wave has read it long before)
 #pragma unroll
-        for (int ni = 0; ni < 2; ni++) bv[ni] = g.bias ? sbias[64 * wc + 32 * ni + (lane & 31)] : 0.0f;
-        // every wave is done reading the operand buffers and the bias slot of this item before the next item's first DMAs
-        // overwrite them
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-        q++;
-        it = (xcd + 8 * q) * per_xcd + slot;
-        if (it < g.items) {
-            item_coords(it, mt, nt, sp);
-            item_setup(mt, nt, sp);
-            dma(0, 0);
-            dma_bias(nt);
-            dma_flag();
-        }
+        for (int ni = 0; ni < 2; ni++) bv[ni] = g.bias ? sbias[(tile_no & 1) * BN + 64 * wc + 32 * ni + (lane & 31)] : 0.0f;
+        GSTAMP(5)
         if (g.c_quads) {
             // [M/4][N][4]: accumulator registers 4g..4g+3 of a lane are four consecutive rows of one column: one 16-byte store
             // the same descriptor make_rsrc_sized builds, as four words for the inline-asm store below
@@ -1029,10 +1030,15 @@ __global__ __launch_bounds__(512, 2) void k_gemm_bf16x3(GemmArgs g) {
                         buf_store1_nt(acc[mi][ni][r] + bv[ni], rc, c_l,
                                       (unsigned)(((128 * wr + 32 * mi + (r & 3) + 8 * (r >> 2)) * g.N + 64 * wc + 32 * ni) * 4));
         }
+        GSTAMP(7)
+        cur = nxt;
+        r_cur = r_n;
+        it = it_n;
+        tile_no++;
     }
 #ifdef PV_GEMM_STAMPS
     if (blockIdx.x == 0 && lane == 0)
-        for (int i = 0; i < 5; i++) atomicAdd(&g_gemm_stamps[i], gs_acc[i]);
+        for (int i = 0; i < 8; i++) atomicAdd(&g_gemm_stamps[i], gs_acc[i]);
 #endif
 }
 
@@ -1116,7 +1122,7 @@ static constexpr int64_t P1_BF16_MAX_BATCH = 16384;
 template <int KP> constexpr size_t lds_lstm_split() { return (size_t)(16 * (KP + 4) + 2 * 16 * (H + 4)) * sizeof(float); }
 static constexpr int SP_MAX_TILES = 64;   // 16-row tiles the exchange buffers are sized for (1024 windows)
 template <int KP, int TR> constexpr size_t lds_lstm() { return (size_t)(TR * (KP + 4) + 2 * TR * (H + 4)) * sizeof(float); }
-static constexpr size_t LDS_GEMM = (size_t)2 * 4 * 256 * 32 * 2 + 1024 + 2048;   // 2 buffers x {A_hi, A_lo, W_hi, W_lo} x 256 rows x 32 bf16 = 128 KB, + bias slot + completion flags
+static constexpr size_t LDS_GEMM = (size_t)2 * 4 * 256 * 32 * 2 + 2048 + 2048;   // 2 buffers x {A_hi, A_lo, W_hi, W_lo} x 256 rows x 32 bf16 = 128 KB, + two bias slots + completion flags
 static constexpr size_t LDS_SPLITK = (size_t)ROWS * (2 * H + 4) * sizeof(float);
 template <int TR> constexpr size_t lds_tail() { return (size_t)2 * TR * (HEAD_N + 4) * sizeof(float); }
 
@@ -1587,7 +1593,7 @@ extern "C" int pv_debug_gemm_bf16x3(pv_ctx* ctx, const float* A, const float* W,
 extern "C" int pv_debug_gemm_stamps(unsigned long long* out5) {
     unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     PV_HIP(hipDeviceSynchronize());
-    PV_HIP(hipMemcpyFromSymbol(out5, HIP_SYMBOL(g_gemm_stamps), 5 * sizeof(unsigned long long)));
+    PV_HIP(hipMemcpyFromSymbol(out5, HIP_SYMBOL(g_gemm_stamps), 8 * sizeof(unsigned long long)));
     PV_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_gemm_stamps), z, sizeof z));
     return PV_OK;
 }

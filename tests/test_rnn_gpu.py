@@ -314,7 +314,9 @@ def test_bf16x3_gemm_alone(hip_ctx):
     lib = _ffi.load()
     rng = np.random.default_rng(0)
     for M, N, K, splits, quads, bias in ((64, 256, 64, 1, 0, True), (64, 256, 64, 1, 1, True), (1056, 2048, 512, 1, 1, True),
-                                         (320, 512, 1024, 2, 0, False), (2052, 512, 2112, 3, 0, False), (8448, 2048, 512, 1, 1, True)):
+                                         (320, 512, 1024, 2, 0, False), (2052, 512, 2112, 3, 0, False), (8448, 2048, 512, 1, 1, True),
+                                         # several items per persistent workgroup (the K steps run on across items; bias slots alternate):
+                                         (33792, 2048, 512, 1, 1, True), (40004, 768, 256, 1, 1, True), (16900, 512, 2112, 3, 0, False)):
         A = rng.standard_normal((M, K)).astype(np.float32)
         W = (rng.standard_normal((N, K)) * 0.05).astype(np.float32)
         b = rng.standard_normal(N).astype(np.float32) if bias else None
