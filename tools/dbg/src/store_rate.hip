@@ -1,3 +1,4 @@
+// build: hipcc --offload-arch=gfx950 -O3 -o tools/dbg/src/store_rate tools/dbg/src/store_rate.hip ; run: ./tools/dbg/src/store_rate
 // Diagnostic: how fast can ONE CU issue 16-byte-per-lane stores? (k_gemm_bf16x3's epilogue: 256 KB per tile)
 // 256 workgroups x 512 threads, every wave stores NST x 1 KB; cycles per workgroup by s_memtime -> bytes per clock and CU.
 #include <hip/hip_runtime.h>
