@@ -939,9 +939,12 @@ __global__ __launch_bounds__(512, 2) void k_gemm_bf16x3(GemmArgs g) {
             asm volatile("" ::: "memory");
             GSTAMP(1)
             const unsigned char* base = smg + buf * 4 * ARR;
-            // the next step's eight pieces are issued one per (ks, mi) block of this step's MFMAs instead of as a burst behind
-            // the barrier: an LDS-DMA costs its wave ~100-150 issue cycles, and the two waves of a SIMD - phase-locked by the
-            // barrier - both paid the eight of them before either issued an MFMA (~1200 of a K step's ~4300 cycles)
+            // the next step's eight pieces are issued between the blocks of this step's MFMAs instead of as a burst behind the
+            // barrier: an LDS-DMA costs its wave ~100-150 issue cycles, and the two waves of a SIMD - phase-locked by the barrier
+            // - both paid the eight of them before either issued an MFMA (~1200 of a K step's ~4300 cycles). Two per block in the
+            // FIRST half of the step: one per block over the whole step left the last pieces ~400 cycles to land before the step
+            // ended (the step then waited ~650 cycles for them); four or eight in front of the first blocks stall the pipe again
+            // (decoder projection, same box: 1.49 ms one per block, 1.43 two, 1.48 four, 1.46 eight).
 #pragma unroll
             for (int ks = 0; ks < 2; ks++) {
                 const unsigned ch = (unsigned)(((2 * ks + (lane >> 5)) ^ f_swz) * 16);
@@ -955,9 +958,10 @@ __global__ __launch_bounds__(512, 2) void k_gemm_bf16x3(GemmArgs g) {
                 for (int mi = 0; mi < 4; mi++) {
                     const bf16x8 ah = *reinterpret_cast<const bf16x8*>(base + fa_l + mi * 32 * 64 + ch);
                     const bf16x8 al = *reinterpret_cast<const bf16x8*>(base + ARR + fa_l + mi * 32 * 64 + ch);
-                    if (issue) {
-                        dma_piece(S, s_kt, buf ^ 1, ks * 4 + mi);
-                        if (ks == 1 && mi == 3) {
+                    if (issue && ks == 0) {   // two pieces in front of each of the first four blocks
+                        dma_piece(S, s_kt, buf ^ 1, 2 * mi);
+                        dma_piece(S, s_kt, buf ^ 1, 2 * mi + 1);
+                        if (mi == 3) {
                             if (next_bias) dma_bias(nxt.nt, (tile_no + 1) & 1);
                             dma_flag();
                         }
