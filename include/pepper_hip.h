@@ -347,7 +347,6 @@ int pv_rnn_exchange_timeouts(pv_ctx* ctx);
  *   tail_rows     [PV_TAIL_ROWS]    0 auto / 16 / 32;   head_splits [PV_HEAD_SPLITS] 0 auto / 1 / 3 / 11 / 33;   head_map [PV_HEAD_MAP] 1 / 0
  *   gru_rows      [PV_GRU_ROWS]     0 auto / 16 / 32
  *   gru_split     [PV_GRU_SPLIT]    1 / 0: allow the split GRU forms at all;   gru_usplit [PV_GRU_USPLIT] 1 / 0: the unit-split one
- *   gru_mid       [PV_GRU_MID]      1 / 0: 1025..4096 chunks as sub-batches in split forms / as one launch of the one-workgroup form
  *   shared_device [PV_SHARED_DEVICE] 0 / 1: other streams or processes keep this GPU busy (e.g. several un-fused callers per
  *                                   GPU, RunInferenceArguments.py:67-74): never choose a form that needs co-resident workgroups
  *   exchange_spin_log2              2..22 (default 18): bounded polls give up after 2^n tries

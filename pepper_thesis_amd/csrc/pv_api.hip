@@ -50,7 +50,6 @@ const opt_desc OPTS[] = {
     {"gru_rows", "PV_GRU_ROWS", &pv_opts::gru_rows, 0, 32},
     {"gru_split", "PV_GRU_SPLIT", &pv_opts::gru_split, 0, 1},
     {"gru_usplit", "PV_GRU_USPLIT", &pv_opts::gru_usplit, 0, 1},
-    {"gru_mid", "PV_GRU_MID", &pv_opts::gru_mid, 0, 1},
     {"shared_device", "PV_SHARED_DEVICE", &pv_opts::shared_device, 0, 1},
     {"exchange_spin_log2", nullptr, &pv_opts::exchange_spin_log2, 2, 22},
     {"debug_drop_part", nullptr, &pv_opts::debug_drop_part, -1, 3},

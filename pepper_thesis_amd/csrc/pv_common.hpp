@@ -105,7 +105,6 @@ struct pv_opts {
     int gru_rows = 0;            // 0 auto, 16 or 32
     int gru_split = 1;           // 0: neither split form of the GRU
     int gru_usplit = 1;          // 0: no unit-split form (the direction-split form stays)
-    int gru_mid = 1;             // 0: 1025-4096 chunks in one launch of the one-workgroup form instead of sub-batches
     int shared_device = 0;       // 1: other work shares this GPU: no form that needs all its workgroups resident at once
     int exchange_spin_log2 = 18; // bounded polls of the split forms give up after 2^n tries (layer hand-offs: 2^(n+8))
     int debug_drop_part = -1;    // diagnostic: this part of a unit-split launch never runs (forces exchange time-outs)
