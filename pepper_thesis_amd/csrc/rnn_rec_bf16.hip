@@ -76,9 +76,11 @@ struct RecArgs {
 
 // slots [I0, I0 + NKS * NG) of a stream of NTOT slots: slot = (k-step, gate) = [hi fragments | lo fragments] of 1 KB each.
 // At = this lane's A-fragment address of M-tile 0, k-step 0; XP: x-part (plain bf16 rows, exact operand, two terms).
-template <int NG, int MT, int NA, int D, int NTOT, int I0, int NKS, bool XP>
+// hook(i) runs behind the MFMAs of slot i (vector / LDS / store instructions of the caller that have nothing to do with the
+// product issue there while the matrix pipe works).
+template <int NG, int MT, int NA, int D, int NTOT, int I0, int NKS, bool XP, typename Hook>
 __device__ __forceinline__ void ring_bf16(f32x16 (&acc)[MT][NA], const unsigned char* __restrict__ At, int m_stride,
-                                          __amdgpu_buffer_rsrc_t wr, f32x4 (&bq)[D][2], unsigned lane16) {
+                                          __amdgpu_buffer_rsrc_t wr, f32x4 (&bq)[D][2], unsigned lane16, Hook&& hook) {
     constexpr int KSB = XP ? 32 : 64;   // bytes of one k-step inside an A row
     bf16x8 ah[MT], al[MT];
 #pragma unroll
@@ -108,6 +110,7 @@ __device__ __forceinline__ void ring_bf16(f32x16 (&acc)[MT][NA], const unsigned 
                 if (!XP) acc[m][ai] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[m], bh, acc[m][ai], 0, 0, 0);
             }
         }
+        hook(i);
         __builtin_amdgcn_sched_barrier(0);
     }
 }
@@ -294,18 +297,30 @@ __global__ __launch_bounds__(NG == 4 ? 512 : 256, 1) void k_rec_bf16(RecArgs a) 
     // stores per value (a third of a GRU step); instead the finished tile (stable for the whole next step: it is that step's
     // A operand) is copied out with 16-byte loads / stores, a row of HID * 4 bytes per 2 * HID / 8 lanes.
     constexpr int CPR = HID / 4, NCP = ROWS * CPR / NTHR;   // 16-byte chunks per row, chunks per thread
-    auto tile_out = [&](int tt, const unsigned char* tile) {
-        if (!a.out_tm && !a.out_bm) return;
-        const __amdgpu_buffer_rsrc_t tmr = make_rsrc(a.out_tm + ((size_t)tt * a.Bp + b0) * rowb_tm);
-#pragma unroll
-        for (int k = 0; k < NCP; k++) {
-            const int c = tid + k * NTHR, row = c / CPR, col = c % CPR;
-            const u32x4 v = *reinterpret_cast<const u32x4*>(tile + row * HS + col * 16);
-            if (a.out_tm)
-                __builtin_amdgcn_raw_buffer_store_b128(v, tmr, (unsigned)(row * (int)rowb_tm + col * 16), (unsigned)(dir * HID * 4), 2);
-            if (a.out_bm)
-                __builtin_amdgcn_raw_buffer_store_b128(v, bmr, (unsigned)row * rowb_bm + (unsigned)(col * 16), (unsigned)((tt * 2 + dir) * HID * 4), 2);
+    const bool want_out = a.out_tm || a.out_bm;
+    // piece k of the copy in two halves - the LDS read, and the stores one hook later - so that neither waits inside the MFMA loop.
+    // Thread -> (row tid / CPR + k * RPP, chunk tid % CPR): three lane offsets for the whole launch, the piece is a scalar offset
+    static_assert(NTHR % CPR == 0, "a piece is a whole number of rows");
+    constexpr int RPP = NTHR / CPR;   // rows per piece
+    const unsigned cp_lds = (unsigned)((tid / CPR) * HS + (tid % CPR) * 16);
+    const unsigned cp_tm = (unsigned)(tid / CPR) * rowb_tm + (unsigned)((tid % CPR) * 16);
+    const unsigned cp_bm = (unsigned)(tid / CPR) * rowb_bm + (unsigned)((tid % CPR) * 16);
+    u32x4 tile_v = {0u, 0u, 0u, 0u};
+    auto tile_read = [&](int k, const unsigned char* tile) {
+        tile_v = *reinterpret_cast<const u32x4*>(tile + k * RPP * HS + cp_lds);
+    };
+    auto tile_write = [&](int k, int tt) {
+        if (a.out_tm) {
+            const __amdgpu_buffer_rsrc_t tmr = make_rsrc(a.out_tm + ((size_t)tt * a.Bp + b0) * rowb_tm);
+            __builtin_amdgcn_raw_buffer_store_b128(tile_v, tmr, cp_tm, (unsigned)(k * RPP) * rowb_tm + (unsigned)(dir * HID * 4), 2);
         }
+        if (a.out_bm)
+            __builtin_amdgcn_raw_buffer_store_b128(tile_v, bmr, cp_bm, (unsigned)(k * RPP) * rowb_bm + (unsigned)((tt * 2 + dir) * HID * 4), 2);
+    };
+    auto tile_out = [&](int tt, const unsigned char* tile) {   // the whole copy at once (after the last step)
+        if (!want_out) return;
+#pragma unroll
+        for (int k = 0; k < NCP; k++) { tile_read(k, tile); tile_write(k, tt); }
     };
     const __amdgpu_buffer_rsrc_t ofr = make_rsrc(reinterpret_cast<unsigned char*>(a.out_f32) + (size_t)b0 * rowb_bm);
     int cur = 0;
@@ -317,7 +332,20 @@ __global__ __launch_bounds__(NG == 4 ? 512 : 256, 1) void k_rec_bf16(RecArgs a) 
         const int t = dir ? (T - 1 - s) : s;
         const int tn = dir ? (T - 2 - s) : (s + 1);
         if (s + 1 < T) x_load(tn);
-        if (s > 0) tile_out(dir ? t + 1 : t - 1, hbuf + cur * ROWS * HS);   // the previous step's h tile leaves behind this step's MFMAs
+        // the previous step's h tile (this step's A operand: stable until the barrier) leaves for the layer's output in NCP pieces
+        // spread over this step's MFMAs (all of them in front of the MFMAs were ~3 k of a 41 k-cycle LSTM step)
+        const bool copy = want_out && s > 0;
+        const int t_prev = dir ? t + 1 : t - 1;
+        const unsigned char* tile_prev = hbuf + cur * ROWS * HS;
+        constexpr int HSLOTS = C::KS_H * NG, HSTRIDE = HSLOTS / NCP;   // h-part slots (LSTM 64, GRU 24) per piece
+        static_assert(HSTRIDE >= 2, "a piece needs two slots: read, then write");
+        auto copy_hook = [&](int i) {
+            if (copy) {
+                if (i % HSTRIDE == 0 && i / HSTRIDE < NCP) tile_read(i / HSTRIDE, tile_prev);
+                if (i % HSTRIDE == 1 && i / HSTRIDE < NCP) tile_write(i / HSTRIDE, t_prev);
+            }
+        };
+        auto no_hook = [](int) {};
         // the two waves of a SIMD (w and w + NW / 2 ... hardware places wave i on SIMD i % 4) would otherwise sit in the same
         // phase - both on the matrix pipe, then both in the cell update: the lower half of the workgroup takes the pipe first
         // and runs its cell update under the upper half's MFMAs
@@ -337,7 +365,7 @@ __global__ __launch_bounds__(NG == 4 ? 512 : 256, 1) void k_rec_bf16(RecArgs a) 
                     acc[m][ai] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ax[m], xw[g][1], acc[m][ai], 0, 0, 0);
                 }
         } else if constexpr (ENC) {
-            ring_bf16<NG, MT, NA, D, NSLOT, 0, C::KS_X, true>(acc, a_x + (s & 1) * ROWS * XS, 32 * XS, wr, bq, lane16);
+            ring_bf16<NG, MT, NA, D, NSLOT, 0, C::KS_X, true>(acc, a_x + (s & 1) * ROWS * XS, 32 * XS, wr, bq, lane16, no_hook);
         }
         // ---- h-part: h_{t-1} . W_hh^T, three terms ----------------------------------------------------------------------------
         if constexpr (C::WRES) {
@@ -357,10 +385,11 @@ __global__ __launch_bounds__(NG == 4 ? 512 : 256, 1) void k_rec_bf16(RecArgs a) 
                         acc[m][g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[m], wres[ks * NG + g][0], acc[m][g], 0, 0, 0);
                         acc[m][g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[m], wres[ks * NG + g][1], acc[m][g], 0, 0, 0);
                         acc[m][g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[m], wres[ks * NG + g][0], acc[m][g], 0, 0, 0);
+                        if (m == MT - 1) copy_hook(ks * NG + g);
                     }
             }
         } else {
-            ring_bf16<NG, MT, NA, D, NSLOT, NXS, C::KS_H, false>(acc, a_h + cur * ROWS * HS, 32 * HS, wr, bq, lane16);
+            ring_bf16<NG, MT, NA, D, NSLOT, NXS, C::KS_H, false>(acc, a_h + cur * ROWS * HS, 32 * HS, wr, bq, lane16, copy_hook);
         }
         if (NW == 8) { if (wv < 4) __builtin_amdgcn_s_setprio(2); else __builtin_amdgcn_s_setprio(1); }
         RSTAMP(1)
