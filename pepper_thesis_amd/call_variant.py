@@ -44,7 +44,7 @@ class _Comm:
             self.dist.destroy_process_group()
 
 
-def _predict_rank(args, rank, world, device, image_dir, pred_dir, params, min_mapq):
+def _predict_rank(args, rank, world, device, image_dir, pred_dir, params, min_mapq, on_rows=None):
     """this rank's share of make_images + run_inference; returns the number of windows. (Replaced by a stub in the CPU test of
     the multi-rank plumbing.)"""
     from . import _ffi, make_images, pipeline, run_inference
@@ -59,7 +59,7 @@ def _predict_rank(args, rank, world, device, image_dir, pred_dir, params, min_ma
             return pipeline.call_variant_fused(ctx, state, args.bam, args.fasta, os.path.join(pred_dir, pred_name), params, args.region,
                                                args.region_size, min_mapq, args.include_supplementary, args.downsample_rate,
                                                args.batch_size, max(1, int(args.callers_per_gpu)) * 4, rank, world, args.threads, keep,
-                                               dtype=dtype, region_bed=args.region_bed)
+                                               dtype=dtype, region_bed=args.region_bed, on_rows=on_rows)
         n = make_images.generate_images(ctx, args.bam, args.fasta, image_dir, params, args.region, args.region_size, min_mapq,
                                         args.include_supplementary, args.downsample_rate, rank=rank, world=world,
                                         reader_threads=args.threads, region_bed=args.region_bed)
@@ -92,13 +92,21 @@ def run(args, predict_rank=_predict_rank):
         pred_dir = os.path.join(args.output_dir, "predictions_" + ts)
         os.makedirs(pred_dir, exist_ok=True)
         t0 = time.time()
-        n = predict_rank(args, rank, world, device, image_dir, pred_dir, params, min_mapq)
+        # one rank, fused: the candidates are selected from every call's windows while the pipeline runs (on its writer thread);
+        # with several ranks rank 0 reads all the prediction files afterwards, as the reference does
+        collector = None
+        if world == 1 and args.fused and predict_rank is _predict_rank:
+            collector = find_candidates.CandidateCollector(args.fasta, cand_opt)
+            n = predict_rank(args, rank, world, device, image_dir, pred_dir, params, min_mapq, on_rows=collector)
+        else:
+            n = predict_rank(args, rank, world, device, image_dir, pred_dir, params, min_mapq)
         sys.stderr.write("INFO: [RANK %d/%d] [1-2/3] %s: %d WINDOWS PREDICTED (%.1f s)\n" %
                          (rank, world, "FUSED IMAGES + INFERENCE" if args.fused else "IMAGES, INFERENCE", n, time.time() - t0))
         comm.barrier()   # every rank's prediction file is complete
         counts = None
         if rank == 0:
-            counts = find_candidates.process_candidates(pred_dir, args.fasta, args.sample_name, args.output_dir, cand_opt)
+            counts = find_candidates.process_candidates(pred_dir, args.fasta, args.sample_name, args.output_dir, cand_opt,
+                                                        selected=collector.selected if collector is not None else None)
             sys.stderr.write("INFO: [3/3] CANDIDATES: %s (%.1f s)\n" % (counts, time.time() - t0))
         comm.barrier()
         return counts

@@ -145,6 +145,120 @@ def select_candidates(records: Iterable[dict], get_ref: Callable[[str, int, int]
     return selected
 
 
+def _in_repeat_rows(W: np.ndarray, pidx: np.ndarray, full_len: np.ndarray) -> np.ndarray:
+    """`max(repeat_annotation(full, 1)[max(0, pidx - 5):min(len(full), pidx + 4)]) >= 5` for many sites at once. W [n,20] holds
+    `full` (the <= 10 bases before the site + the <= 10 from it on) left-aligned, the rest filled with values that equal nothing
+    next to them. With k-mer size 1 the annotation of a base is the length of the homopolymer run it lies in, so the test is:
+    does a run of >= 5 equal bases touch the slice?"""
+    eq = W[:, 1:] == W[:, :-1]
+    run5 = eq[:, 0:16] & eq[:, 1:17] & eq[:, 2:18] & eq[:, 3:19]   # bases a .. a + 4 are equal
+    lo = np.maximum(0, pidx - 5)
+    hi = np.minimum(full_len, pidx + 4)
+    a = np.arange(16)
+    return (run5 & (a[None, :] <= hi[:, None] - 1) & (a[None, :] + 4 >= lo[:, None])).any(axis=1)
+
+
+def select_candidates_batch(batch: Dict[str, np.ndarray], get_ref: Callable[[str, int, int], str], opt: CandidateOptions):
+    """select_candidates for one prediction batch as read from the file (arrays contigs S[n], positions, depths, candidates
+    [n,k] of str / bytes, candidate_frequency [n,k], base_prediction [n,3]): the same tuples in the same order, computed for
+    all single-candidate windows of a contig at once (one reference fetch per contig instead of three per window, the
+    homopolymer test on a [n,20] matrix). Windows with several candidates, a zero depth, or on a contig with fewer than 20
+    bases take the per-record path."""
+    n = len(batch["positions"])
+    if n == 0:
+        return []
+    cands = batch["candidates"]
+
+    def rec(i):
+        return dict(contig=batch["contigs"][i].decode() if isinstance(batch["contigs"][i], bytes) else str(batch["contigs"][i]),
+                    position=int(batch["positions"][i]), depth=int(batch["depths"][i]),
+                    candidates=[x.decode() if isinstance(x, bytes) else str(x) for x in cands[i]],
+                    candidate_frequency=[int(x) for x in np.atleast_1d(batch["candidate_frequency"][i])], prediction=batch["base_prediction"][i])
+    if cands.ndim != 2 or cands.shape[1] != 1:
+        return select_candidates((rec(i) for i in range(n)), get_ref, opt)
+    pos_all = np.asarray(batch["positions"]).astype(np.int64)
+    depth_all = np.asarray(batch["depths"]).astype(np.int64)
+    freq_all = np.asarray(batch["candidate_frequency"]).reshape(n).astype(np.int64)
+    pred_all = np.asarray(batch["base_prediction"], dtype=np.float64)
+    contig_col = np.asarray(batch["contigs"])
+    out = [None] * n            # per window: None (nothing selected) or its tuple
+    slow = []
+    acgt = np.zeros(256, bool)
+    acgt[[65, 67, 71, 84]] = True
+    for cname in np.unique(contig_col):
+        idx = np.flatnonzero(contig_col == cname)
+        contig = cname.decode() if isinstance(cname, bytes) else str(cname)
+        pos = pos_all[idx]
+        p_lo, p_hi = int(pos.min()), int(pos.max())
+        span0 = max(0, p_lo - 10)
+        ref = get_ref(contig, span0, p_hi + 10).upper().encode()
+        R = np.frombuffer(ref, np.uint8)
+        clen = span0 + len(R)                      # bases known to exist (the fetch clamps at the contig end)
+        if len(R) < 20 or (depth_all[idx] == 0).any() or (pos < 0).any():
+            slow.extend(idx.tolist())
+            continue
+        # full = ref[max(0, pos - 10):pos] + ref[pos:pos + 10], left-aligned in 20 columns
+        start = np.maximum(0, pos - 10)
+        pidx = pos - start
+        stop = np.minimum(clen, pos + 10)
+        full_len = np.maximum(0, stop - start)
+        cols = np.arange(20)
+        gi = start[:, None] + cols[None, :] - span0
+        inside = cols[None, :] < full_len[:, None]
+        W = np.where(inside, R[np.clip(gi, 0, len(R) - 1)], (128 + cols)[None, :].astype(np.uint8))
+        in_rep = _in_repeat_rows(W, pidx, full_len)
+        has_base = pos < clen
+        ref_base = np.where(has_base, R[np.clip(pos - span0, 0, len(R) - 1)], 0).astype(np.uint8)
+        ref_ok = acgt[ref_base]
+        pred = pred_all[idx]
+        g = np.argmax(pred, axis=1)
+        nap = np.maximum(pred[:, 1], pred[:, 2])
+        freq = freq_all[idx]
+        depth = depth_all[idx]
+        vaf = freq.astype(np.float64) / depth.astype(np.float64)
+        thr = {"1": np.where(in_rep, opt.snp_p_value_in_lc, opt.snp_p_value), "2": np.where(in_rep, opt.insert_p_value_in_lc, opt.insert_p_value),
+               "3": np.where(in_rep, opt.delete_p_value_in_lc, opt.delete_p_value)}
+        by_p = {t: nap >= thr[t] for t in thr}
+        by_f_snp = (vaf >= opt.report_snp_above_freq) if opt.report_snp_above_freq > 0 else np.zeros(len(idx), bool)
+        by_f_indel = (vaf >= opt.report_indel_above_freq) if opt.report_indel_above_freq > 0 else np.zeros(len(idx), bool)
+        gts = ([0, 0], [0, 1], [1, 1])
+        cl = cands[idx, 0]
+        for j in np.flatnonzero(ref_ok):
+            c = cl[j]
+            if isinstance(c, bytes):
+                c = c.decode()
+            t, allele = c[:1], c[1:]
+            if allele.strip("ACGT"):           # an allele with anything but A/C/G/T is skipped (and adds no non-alt prediction)
+                continue
+            rb = chr(ref_base[j])
+            if t == "1":
+                if not (by_p["1"][j] or by_f_snp[j]):
+                    continue
+                ref_allele, alt = rb, allele
+            elif t == "2":
+                if not (by_p["2"][j] or by_f_indel[j]):
+                    continue
+                ref_allele, alt = rb, allele
+            elif t == "3":
+                if by_p["3"][j]:
+                    ref_allele, alt = allele, rb   # deletion: REF = anchor + deleted, ALT = previous REF
+                elif by_f_indel[j]:
+                    ref_allele, alt = rb, allele
+                else:
+                    continue
+            else:
+                continue
+            p = int(pos[j])
+            gj = int(g[j])
+            out[idx[j]] = (contig, p, p + len(ref_allele), ref_allele, [alt], list(gts[gj]), int(depth[j]), [int(freq[j])], pred[j][gj],
+                           pred[j], [nap[j]], bool(in_rep[j]))
+    if slow:
+        for i in slow:
+            r = select_candidates([rec(i)], get_ref, opt)
+            out[i] = r[0] if r else None
+    return [t for t in out if t is not None]
+
+
 def dedupe_by_position(selected) -> Dict[Tuple[str, int], list]:
     """find_candidates tail (:548-574): sort by (contig, pos), keep the first record per (ref, alt)"""
     out, seen = defaultdict(list), defaultdict(list)
@@ -159,6 +273,11 @@ def dedupe_by_position(selected) -> Dict[Tuple[str, int], list]:
 
 def candidate_list_to_variant(candidates, opt: CandidateOptions):
     """VcfWriter.py:48-138"""
+    if len(candidates) == 1 and opt.allowed_multiallelics >= 1:   # the usual site: what the general path below gives for one record
+        contig, rs, re_, ref, alts, gt, depth, sup, gp, preds, naps, rep = candidates[0]
+        g = int(np.argmax(preds))
+        gt_qual = preds[g] if g != 0 else max(preds[1], preds[2])
+        return contig, rs, rs + len(ref), ref, [alts[0]], ([0, 0], [0, 1], [1, 1])[g], depth, [sup[0]], gt_qual, list(naps), bool(rep)
     candidates = sorted(candidates, key=lambda x: (x[5], x[8]), reverse=True)[:opt.allowed_multiallelics]
     max_ref = max((c[3] for c in candidates), key=len)
     norm = []
@@ -225,24 +344,26 @@ VCF_HEADER = """##fileformat=VCFv4.2
 def variant_records(variants: Dict[Tuple[str, int], list], opt: CandidateOptions):
     """write_vcf_records (:140-218) as data: yields (line, selected_for_variant_calling, is_snp)"""
     last_position = -1
-    for contig, position in sorted(variants):
-        contig, rs, re_, ref, alleles, genotype, depth, sup, gp, naps, rep = candidate_list_to_variant(variants[(contig, position)], opt)
+    log10 = math.log10
+    for key in sorted(variants):
+        contig, rs, re_, ref, alleles, genotype, depth, sup, gp, naps, rep = candidate_list_to_variant(variants[key], opt)
         if len(alleles) <= 0 or rs == last_position:
             continue
         last_position = rs
         max_alt_len = max(len(ref), max(len(x) for x in alleles))
-        qual = max(1, int(-10 * math.log10(max(0.000000001, 1.0 - gp))))
+        qual = max(1, int(-10 * log10(max(0.000000001, 1.0 - gp))))
         is_snp = max_alt_len == 1
         if is_snp:
             failed = qual <= (opt.snp_q_cutoff_in_lc if rep else opt.snp_q_cutoff)
         else:
             failed = qual <= (opt.indel_q_cutoff_in_lc if rep else opt.indel_q_cutoff)
         selected = genotype == [0, 0] or failed
-        vafs = [round(ad / max(1, depth), 3) for ad in sup]
-        flt = "refCall" if genotype == [0, 0] else "PASS"
-        sample = ":".join(["/".join(str(x) for x in genotype), ",".join(_fmt(x) for x in naps), _fmt(qual), str(depth),
-                           ",".join(str(x) for x in sup), ",".join(_fmt(x) for x in vafs), "1" if rep else "0"])
-        line = "\t".join([str(contig), str(rs + 1), ".", ref, ",".join(alleles), str(qual), flt, ".", "GT:AP:GQ:DP:AD:VAF:REP", sample])
+        d1 = max(1, depth)
+        # (floats as "%.6g", integers as they are: _fmt)
+        line = "%s\t%d\t.\t%s\t%s\t%d\t%s\t.\tGT:AP:GQ:DP:AD:VAF:REP\t%d/%d:%s:%d:%d:%s:%s:%s" % (
+            contig, rs + 1, ref, ",".join(alleles), qual, "refCall" if genotype == [0, 0] else "PASS", genotype[0], genotype[1],
+            ",".join(["%.6g" % float(x) for x in naps]), qual, depth, ",".join([str(x) for x in sup]),
+            ",".join(["%.6g" % round(ad / d1, 3) for ad in sup]), "1" if rep else "0")
         yield line, selected, is_snp
 
 
@@ -260,12 +381,39 @@ def read_prediction_records(prediction_dir: str):
                                candidate_frequency=[int(x) for x in b["candidate_frequency"][i]], prediction=b["base_prediction"][i])
 
 
+def read_prediction_batches(prediction_dir: str):
+    """every batch of every *.hdf file as arrays (FindCandidates.py:145-166)"""
+    from .hdf5io import PredictionStore
+    for fn in sorted(os.listdir(prediction_dir)):
+        if not fn.endswith("hdf"):
+            continue
+        with PredictionStore(os.path.join(prediction_dir, fn), "r") as st:
+            for _, b in st.batches():
+                yield b
+
+
+class CandidateCollector:
+    """select_candidates_batch over prediction batches as they are produced (the fused call_variant hands every call's windows
+    over on its writer thread): `selected` is what process_candidates would have selected from the prediction file"""
+
+    def __init__(self, fasta_path: str, opt: CandidateOptions):
+        from .bamio import FastaHandler
+        self.fasta, self.opt, self.selected = FastaHandler(fasta_path), opt, []
+
+    def __call__(self, batch: Dict[str, np.ndarray]):
+        self.selected += select_candidates_batch(batch, self.fasta.get_reference_sequence, self.opt)
+
+
 def process_candidates(prediction_dir: str, fasta_path: str, sample_name: str, output_dir: str,
-                       opt: CandidateOptions = CandidateOptions()) -> Dict[str, int]:
-    """candidate_finder (FindCandidates.py:131-190): prediction files -> five VCFs; returns the record counts"""
+                       opt: CandidateOptions = CandidateOptions(), selected: list = None) -> Dict[str, int]:
+    """candidate_finder (FindCandidates.py:131-190): prediction files -> five VCFs; returns the record counts.
+    selected: the candidates already chosen from these predictions (CandidateCollector), then the files are not read again"""
     from .bamio import FastaHandler
     fasta = FastaHandler(fasta_path)
-    selected = select_candidates(read_prediction_records(prediction_dir), fasta.get_reference_sequence, opt)
+    if selected is None:
+        selected = []
+        for b in read_prediction_batches(prediction_dir):
+            selected += select_candidates_batch(b, fasta.get_reference_sequence, opt)
     variants = dedupe_by_position(selected)
     os.makedirs(output_dir, exist_ok=True)
     contigs = []

@@ -24,7 +24,7 @@ from . import _ffi
 from .batch import Params
 
 
-def _writer_loop(q: "queue.Queue", pred_path: str, image_path: Optional[str], batch_size: int, T: dict, err: list):
+def _writer_loop(q: "queue.Queue", pred_path: str, image_path: Optional[str], batch_size: int, T: dict, err: list, on_rows=None):
     import contextlib
     from .hdf5io import ImageStore, PredictionStore
     try:
@@ -57,6 +57,11 @@ def _writer_loop(q: "queue.Queue", pred_path: str, image_path: Optional[str], ba
                     names, rec, probs, images = item
                     rows = {k: rec[k] for k in keys}
                     rows["probs"] = probs if probs is not None else np.zeros((0, 3), np.float32)
+                    if on_rows is not None and probs is not None and len(probs):   # the consumer's view of these windows, as it would
+                        tr = time.perf_counter()                                      # read them back from the prediction file
+                        on_rows(dict(contigs=rec["contigs"], positions=rec["positions"], depths=rec["depths"], candidates=rec["candidates"],
+                                     candidate_frequency=rec["candidate_frequency"], base_prediction=probs.astype(np.float64)))
+                        T["on_rows_s"] = T.get("on_rows_s", 0.0) + time.perf_counter() - tr
                     if out is not None and len(probs):
                         if carry is not None:
                             w = max(carry["contigs"].dtype.itemsize, rows["contigs"].dtype.itemsize)
@@ -82,9 +87,11 @@ def call_variant_fused(ctx, state_dict: dict, bam_path: str, fasta_path: str, pr
                        region_size: int = 100_000, min_mapq: int = 5, include_supplementary: bool = False,
                        downsample_rate: float = 1.0, batch_size: int = 512, intervals_per_call: int = 16, rank: int = 0,
                        world: int = 1, reader_threads: int = None, keep_images_path: Optional[str] = None, timers: dict = None,
-                       dtype: int = _ffi.PV_DTYPE_F32, region_bed: str = None, inflate_helpers: int = None) -> int:
+                       dtype: int = _ffi.PV_DTYPE_F32, region_bed: str = None, inflate_helpers: int = None, on_rows=None) -> int:
     """-> number of windows predicted. One prediction file at `pred_path` (and one image file at `keep_images_path`, if given)
-    for the intervals of this rank. state_dict None = images only (make_images): no model, no prediction file."""
+    for the intervals of this rank. state_dict None = images only (make_images): no model, no prediction file.
+    on_rows (optional): called on the writer thread with every call's windows as the arrays of a prediction batch (what
+    PredictionStore.batches() would read back) - call_variant selects its candidates there, while the device works on."""
     import torch
     from .device import DeviceOut
     from .make_images import region_batches
@@ -113,7 +120,7 @@ def call_variant_fused(ctx, state_dict: dict, bam_path: str, fasta_path: str, pr
         os.makedirs(os.path.dirname(os.path.abspath(pred_path)), exist_ok=True)
     if keep_images_path:
         os.makedirs(os.path.dirname(os.path.abspath(keep_images_path)), exist_ok=True)
-    writer = threading.Thread(target=_writer_loop, args=(q, pred_path, keep_images_path, int(batch_size), T, werr), daemon=True)
+    writer = threading.Thread(target=_writer_loop, args=(q, pred_path, keep_images_path, int(batch_size), T, werr, on_rows), daemon=True)
     writer.start()
     n_windows = 0
     cap, scap = 0, 0

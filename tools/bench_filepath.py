@@ -86,6 +86,23 @@ def run(ctx, weights, dev=None, mbp=3.2, keep_dir=None):
             "note": "host share = 1 - (uploads + kernels + read-backs) / wall; %d reader threads with %d BGZF inflate helpers each run ahead of the GPU, "
                     "the prediction file is written by its own thread" % (t_f["reader_threads"], t_f["inflate_helpers"]),
         }
+        # the whole of call_variant: BAM -> prediction file -> the five VCFs (candidates selected on the pipeline's writer thread
+        # while it runs; de-duplication, records and bgzip + tabix afterwards), median of three
+        from pepper_thesis_amd import find_candidates as fcm
+        e2e = []
+        for k in range(3):
+            t0 = time.perf_counter()
+            coll = fcm.CandidateCollector(fa, fcm.CandidateOptions())
+            t_k = {}
+            pipeline.call_variant_fused(ctx, weights, bam, fa, os.path.join(d, "pred_e2e", "pepper_prediction.hdf"), P, min_mapq=5, timers=t_k, on_rows=coll)
+            t1 = time.perf_counter()
+            counts = fcm.process_candidates(os.path.join(d, "pred_e2e"), fa, "SAMPLE", os.path.join(d, "vcf_e2e"), fcm.CandidateOptions(), selected=coll.selected)
+            t2 = time.perf_counter()
+            e2e.append((t2 - t0, t1 - t0, t2 - t1, t_k.get("on_rows_s", 0.0), counts["total"]))
+        e2e.sort()
+        out["bam_to_vcf"] = {"wall_s": e2e[1][0], "mbp_per_s": swept / e2e[1][0], "pipeline_s": e2e[1][1], "records_and_vcf_writing_s": e2e[1][2],
+                             "candidate_selection_on_writer_thread_s": e2e[1][3], "vcf_records": e2e[1][4],
+                             "note": "call_variant end to end on one rank (synthetic weights: nearly every window becomes a record)"}
         # the reference's two steps through image files, for comparison
         t_img = {}
         n1 = make_images.generate_images(ctx, bam, fa, os.path.join(d, "images"), P, min_mapq=5, timers=t_img)
