@@ -439,9 +439,13 @@ def process_candidates(prediction_dir: str, fasta_path: str, sample_name: str, o
         else:
             texts["pepper"].append(line + "\n")
             counts["pepper"] += 1
+    from concurrent.futures import ThreadPoolExecutor
     from .bamio import write_vcf_gz
-    for k, fname in names.items():  # bgzip + tabix index, as VariantFile(..., 'w') + pysam.tabix_index (VcfWriter.py:21-46)
-        write_vcf_gz(os.path.join(output_dir, fname), "".join(texts[k]))
+    # bgzip + tabix index, as VariantFile(..., 'w') + pysam.tabix_index (VcfWriter.py:21-46); the five files side by side (native
+    # code, GIL released)
+    with ThreadPoolExecutor(len(names)) as pool:
+        for f in [pool.submit(write_vcf_gz, os.path.join(output_dir, fname), "".join(texts[k])) for k, fname in names.items()]:
+            f.result()
     return counts
 
 
