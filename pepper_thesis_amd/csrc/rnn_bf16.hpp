@@ -52,6 +52,27 @@ int pv_rec_bf16_prepare();
 // dirs[2] (PyTorch layout) -> device fragment stream(s). kx = real input features (enc) or 0.
 int pv_pack_rec_bf16(const pv_rnn_dir* dirs, int cell, int kx, unsigned char** d_wp, unsigned char** d_wx, std::vector<void*>& owned);
 
+// ---- k_tail_bf16: the tail of the P1 head (sum of linear_1 slabs + bias + SELU, linear_2..5 + SELU, output layer, softmax) with
+// the four 512 x 512 layers as 3-term split products (rnn_rec_bf16.hip). 64 rows per workgroup.
+struct pv_tail_desc {
+    const float* part;         // linear_1 slabs [splits][part_rows][512]
+    int splits;
+    int64_t part_rows;
+    const float* b1;           // [512]
+    const unsigned char* wp;   // packed linear_2..5 (pv_pack_tail_bf16)
+    const float* b[4];         // [512] each
+    const float* wo;           // [3][512]
+    const float* bo;           // [3]
+    float* probs;              // [B][3]
+    int64_t B;
+    unsigned* epoch;           // bumped once (the forward-call counter of the unit-split LSTM form) or NULL
+    const int* err;            // non-zero: the probabilities leave as NaN (see k_head_tail) or NULL
+};
+int pv_tail_bf16_async(pv_ctx* ctx, const pv_tail_desc& d, hipStream_t st);
+int pv_tail_bf16_prepare();
+// w[4]: linear_2..5, [512][512] fp32 row-major (host) -> the fragment stream of k_tail_bf16
+int pv_pack_tail_bf16(const float* const* w, unsigned char** d_wp, std::vector<void*>& owned);
+
 // ---- P2 (bi-GRU polisher model) in this mode: device weights and the layer-wise forward (rnn_rec_bf16.hip) --------------
 struct pv_p2_bf16_weights {
     unsigned char* enc_wp = nullptr;   // encoder W_hh fragment stream

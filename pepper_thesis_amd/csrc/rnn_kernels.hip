@@ -1148,6 +1148,7 @@ struct pv_rnn_p1 {
     unsigned char* dec_wih_s = nullptr; float* dec_bias_cat = nullptr;   // split8 rows
     unsigned char* w1_s = nullptr;
     unsigned char* enc_rb = nullptr; unsigned char* dec_rb = nullptr;    // bf16 fragment streams of k_rec_bf16 (encoder: W_ih | W_hh; decoder: W_hh)
+    unsigned char* tail_wb = nullptr;                                    // bf16 fragment stream of k_tail_bf16 (linear_2..5)
     std::vector<void*> owned;
 };
 
@@ -1276,7 +1277,9 @@ extern "C" int pv_rnn_load_p1(pv_ctx* ctx, const pv_weights_p1* w, int dtype) {
         if ((rc = dev_upload_split(w->linear_w[0], HEAD_N, HEAD_K, &m->w1_s, m->owned))) return rc;
         if ((rc = pv_pack_rec_bf16(w->encoder, 4, F_IN, &m->enc_rb, nullptr, m->owned))) return rc;
         if ((rc = pv_pack_rec_bf16(w->decoder, 4, 0, &m->dec_rb, nullptr, m->owned))) return rc;
-        if ((rc = pv_gemm_bf16x3_prepare()) || (rc = pv_rec_bf16_prepare())) return rc;
+        const float* tail_w[4] = {w->linear_w[1], w->linear_w[2], w->linear_w[3], w->linear_w[4]};
+        if ((rc = pv_pack_tail_bf16(tail_w, &m->tail_wb, m->owned))) return rc;
+        if ((rc = pv_gemm_bf16x3_prepare()) || (rc = pv_rec_bf16_prepare()) || (rc = pv_tail_bf16_prepare())) return rc;
     }
     // opt in to > 64 KB of dynamic LDS (exact sizes; static LDS counts against the 160 KB too)
     PV_HIP(hipFuncSetAttribute((const void*)k_lstm_layer<32, true, 32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_lstm<32, 32>()));
@@ -1349,12 +1352,23 @@ static int p1_forward_launch(pv_ctx* ctx, const int8_t* d_images, int64_t B, flo
         gl.A = dec_split; gl.W = m->w1_s; gl.bias = nullptr; gl.C = part; gl.M = Bp; gl.N = HEAD_N; gl.K = HEAD_K; gl.splits = gs; gl.quads = 0;
         gl.prof_name = "k_gemm_bf16x3_lin1";
         if ((rcb = pv_gemm_bf16x3_async(ctx, gl, st))) return rcb;
-        TailArgs tb;
-        tb.part = part; tb.b1 = m->b1; tb.splits = gs; tb.part_rows = Bp;
+        // sum of the slabs + linear_2..5 + output layer + softmax. Large batches: the four 512 x 512 layers as 3-term split products
+        // too (k_tail_bf16, 64 rows per workgroup: 0.11 ms per 8192 windows against 0.27 for k_head_tail); a small batch is a few
+        // workgroups each pulling the 4 MB of weights through one CU (0.30 ms for 64-512 windows), where k_head_tail's 16-row
+        // tiles spread the same fetch over four times the CUs (0.14 ms): it keeps those
+        if ((B + 63) / 64 < ctx->num_cu / 4) {
+            TailArgs tf;
+            tf.part = part; tf.b1 = m->b1; tf.splits = gs; tf.part_rows = Bp;
+            tf.wo = m->wo; tf.bo = m->bo; tf.probs = d_probs; tf.B = B; tf.epoch = m->sp_epoch; tf.err = m->sp_err;
+            launch_tail(ctx, m, tf, n_tiles, st);
+            PV_HIP(hipGetLastError());
+            return PV_OK;
+        }
+        pv_tail_desc tb = {};
+        tb.part = part; tb.b1 = m->b1; tb.splits = gs; tb.part_rows = Bp; tb.wp = m->tail_wb;
+        for (int i = 0; i < 4; i++) tb.b[i] = m->bl[i];
         tb.wo = m->wo; tb.bo = m->bo; tb.probs = d_probs; tb.B = B; tb.epoch = m->sp_epoch; tb.err = m->sp_err;
-        launch_tail(ctx, m, tb, n_tiles, st);
-        PV_HIP(hipGetLastError());
-        return PV_OK;
+        return pv_tail_bf16_async(ctx, tb, st);
     }
     LstmArgs e;
     e.x_i8 = d_images; e.x_f32 = nullptr; e.wp = m->enc_wp[f]; e.bias = m->enc_bias; e.out = enc_out; e.B = B; e.n_tiles = n_lt;

@@ -18,6 +18,7 @@
 #include "mfma_tiles.hpp"
 
 #include <algorithm>
+#include <type_traits>
 #include <cstdlib>
 
 namespace {
@@ -473,6 +474,135 @@ static inline float bf_bits2f(uint16_t h) {
     return f;
 }
 
+
+// ---- the tail of the P1 head in this mode ---------------------------------------------------------------------------------
+// k_head_tail runs linear_2..5 (four dependent 512 x 512 layers per 32-row tile) on the fp32 MFMA, every workgroup streaming
+// the 4 MB of weights from L2: 0.27-0.30 ms per 8192 windows, 6 % of the bf16x3 chain. Here: 64 rows per workgroup (half the
+// weight traffic per row), 3-term split products through the fragment ring of the recurrent layers, the activations as ONE
+// split8 tile in LDS that is updated in place (every wave holds its 64 x 64 outputs in accumulators until all waves are done
+// reading the tile). Wave w owns output columns [64 w, 64 w + 64) as two 32-column tiles ("gates" of ring_bf16).
+constexpr int TL_N = 512, TL_ROWS = 64, TL_HS = TL_N * 4 + 16, TL_KS = TL_N / 16, TL_SLOTS = TL_KS * 2, TL_D = 8;
+struct TailBfArgs {
+    const float* part; int splits; int64_t part_rows;
+    const float* b1;
+    const unsigned char* wp;
+    const float* b[4];
+    const float* wo; const float* bo;
+    float* probs; int64_t B;
+    unsigned* epoch; const int* err;
+};
+__device__ __forceinline__ float seluf_(float x) {
+    return 1.0507009873554805f * (x > 0.0f ? x : 1.6732632423543772f * (__expf(x) - 1.0f));
+}
+__global__ __launch_bounds__(512, 1) void k_tail_bf16(TailBfArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char sm[];
+    unsigned char* tile = sm;   // [TL_ROWS][TL_HS] split8 rows
+    __shared__ float logits[TL_ROWS][4];
+    const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6), rg = lane >> 5;
+    const int64_t b0 = (int64_t)blockIdx.x * TL_ROWS;
+    if (a.epoch && blockIdx.x == 0 && tid == 0) atomicAdd(a.epoch, 1u);   // both LSTM kernels of this call are done (stream order)
+    const __amdgpu_buffer_rsrc_t wr = make_rsrc(a.wp + (size_t)wv * 4 * TL_SLOTS * 2048);
+    const unsigned lane16 = (unsigned)lane * 16u;
+    f32x4 bq[TL_D][2];
+#pragma unroll
+    for (int k = 0; k < TL_D - 1; k++) {
+        bq[k][0] = buf_load4(wr, lane16, (unsigned)(k * 2048));
+        bq[k][1] = buf_load4(wr, lane16, (unsigned)(k * 2048 + 1024));
+    }
+    // y = selu(sum of slabs + b1) (simple_model.py:57-59) -> split8 rows; four consecutive columns per thread and pass
+    for (int i = tid; i < TL_ROWS * (TL_N / 4); i += 512) {
+        const int row = i / (TL_N / 4), n4 = (i % (TL_N / 4)) * 4;
+        int64_t b = b0 + row;
+        if (b >= a.B) b = a.B - 1;
+        f32x4 v = *reinterpret_cast<const f32x4*>(a.b1 + n4);
+        for (int s = 0; s < a.splits; s++) {
+            const f32x4 p = *reinterpret_cast<const f32x4*>(a.part + ((size_t)s * a.part_rows + b) * TL_N + n4);
+#pragma unroll
+            for (int j = 0; j < 4; j++) v[j] += p[j];
+        }
+        bf16x4 hi, lo;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const float y = seluf_(v[j]);
+            hi[j] = (__bf16)y;
+            lo[j] = (__bf16)(y - (float)hi[j]);
+        }
+        unsigned char* p = tile + row * TL_HS + split8_off((unsigned)n4);
+        *reinterpret_cast<bf16x4*>(p) = hi;
+        *reinterpret_cast<bf16x4*>(p + 16) = lo;
+    }
+    __syncthreads();
+    const unsigned char* a_h = tile + (lane & 31) * TL_HS + rg * 32;
+    auto no_hook = [](int) {};
+    auto layer = [&](auto L) {   // linear_(2 + L) + SELU (:61-76), in place
+        constexpr int LI = decltype(L)::value;
+        f32x16 acc[2][2];
+#pragma unroll
+        for (int g = 0; g < 2; g++) {
+            const float bv = a.b[LI][64 * wv + 32 * g + (lane & 31)];
+#pragma unroll
+            for (int m = 0; m < 2; m++)
+#pragma unroll
+                for (int e = 0; e < 16; e++) acc[m][g][e] = bv;
+        }
+        ring_bf16<2, 2, 2, TL_D, 4 * TL_SLOTS, LI * TL_SLOTS, TL_KS, false>(acc, a_h, 32 * TL_HS, wr, bq, lane16, no_hook);
+        __syncthreads();   // every wave has read the whole tile
+#pragma unroll
+        for (int m = 0; m < 2; m++)
+#pragma unroll
+            for (int g = 0; g < 2; g++)
+#pragma unroll
+                for (int e = 0; e < 16; e++) {
+                    const int row = 32 * m + 8 * (e >> 2) + (e & 3) + 4 * rg;
+                    const float y = seluf_(acc[m][g][e]);
+                    const __bf16 hi = (__bf16)y;
+                    const __bf16 lo = (__bf16)(y - (float)hi);
+                    unsigned char* p = tile + row * TL_HS + split8_off((unsigned)(64 * wv + 32 * g + (lane & 31)));
+                    *reinterpret_cast<__bf16*>(p) = hi;
+                    *reinterpret_cast<__bf16*>(p + 16) = lo;
+                }
+        __syncthreads();
+    };
+    layer(std::integral_constant<int, 0>());
+    layer(std::integral_constant<int, 1>());
+    layer(std::integral_constant<int, 2>());
+    layer(std::integral_constant<int, 3>());
+    // output_layer_type (512 -> 3) + softmax(dim=1) (:77-82): 8 lanes per (row, class) pair, 64 pairs per pass
+    {
+        const int pair = tid >> 3, sub = tid & 7;
+        for (int p = pair; p < TL_ROWS * 3; p += 64) {
+            const int row = p / 3, cls = p - row * 3;
+            float s = 0.0f;
+            for (int k8 = sub; k8 < TL_N / 8; k8 += 8) {   // one group of 8 columns: 8 hi then 8 lo
+                const bf16x8 hi = *reinterpret_cast<const bf16x8*>(tile + row * TL_HS + k8 * 32);
+                const bf16x8 lo = *reinterpret_cast<const bf16x8*>(tile + row * TL_HS + k8 * 32 + 16);
+#pragma unroll
+                for (int j = 0; j < 8; j++) s += ((float)hi[j] + (float)lo[j]) * a.wo[cls * TL_N + k8 * 8 + j];
+            }
+            s += __shfl_xor(s, 4, 64);
+            s += __shfl_xor(s, 2, 64);
+            s += __shfl_xor(s, 1, 64);
+            if (sub == 0) logits[row][cls] = s + a.bo[cls];
+        }
+    }
+    __syncthreads();
+    if (tid < TL_ROWS) {
+        const int64_t b = b0 + tid;
+        if (b < a.B) {
+            const float l0 = logits[tid][0], l1 = logits[tid][1], l2 = logits[tid][2];
+            const float m = fmaxf(l0, fmaxf(l1, l2));
+            const float e0 = expf(l0 - m), e1 = expf(l1 - m), e2 = expf(l2 - m);
+            const float inv = 1.0f / (e0 + e1 + e2);
+            const bool bad = a.err && a.err[0] != 0;   // a poll of a split form gave up: NaN, not stale numbers (see k_head_tail)
+            const float nanv = __builtin_nanf("");
+            a.probs[b * 3 + 0] = bad ? nanv : e0 * inv;
+            a.probs[b * 3 + 1] = bad ? nanv : e1 * inv;
+            a.probs[b * 3 + 2] = bad ? nanv : e2 * inv;
+        }
+    }
+}
+constexpr size_t LDS_TAIL_BF = (size_t)TL_ROWS * TL_HS;
+
 }  // namespace
 
 // Fragment stream of one (direction, wave): slots [x-part k-steps x gates | h-part k-steps x gates]; a slot is 1 KB of hi
@@ -517,6 +647,47 @@ int pv_pack_rec_bf16(const pv_rnn_dir* dirs, int cell, int kx, unsigned char** d
         owned.push_back(*d_wx);
         PV_HIP(hipMemcpy(*d_wx, wx.data(), wx.size() * 2, hipMemcpyHostToDevice));
     }
+    return PV_OK;
+}
+
+int pv_pack_tail_bf16(const float* const* w, unsigned char** d_wp, std::vector<void*>& owned) {
+    // per wave: [layer][k-step][column tile] slots of [hi 1 KB | lo 1 KB]; lane -> column 64 wave + 32 tile + (lane & 31),
+    // values k = 16 ks + 8 (lane >> 5) + j
+    std::vector<uint16_t> wp((size_t)8 * 4 * TL_SLOTS * 1024);
+    for (int wv = 0; wv < 8; wv++)
+        for (int l = 0; l < 4; l++)
+            for (int ks = 0; ks < TL_KS; ks++)
+                for (int g = 0; g < 2; g++) {
+                    uint16_t* dst = wp.data() + ((((size_t)wv * 4 + l) * TL_KS + ks) * 2 + g) * 1024;
+                    for (int lane = 0; lane < 64; lane++)
+                        for (int j = 0; j < 8; j++) {
+                            const int n = 64 * wv + 32 * g + (lane & 31), k = 16 * ks + 8 * (lane >> 5) + j;
+                            const float v = w[l][(size_t)n * TL_N + k];
+                            const uint16_t hi = f2bf_bits(v);
+                            dst[lane * 8 + j] = hi;
+                            dst[512 + lane * 8 + j] = f2bf_bits(v - bf_bits2f(hi));
+                        }
+                }
+    PV_HIP(hipMalloc((void**)d_wp, wp.size() * 2));
+    owned.push_back(*d_wp);
+    PV_HIP(hipMemcpy(*d_wp, wp.data(), wp.size() * 2, hipMemcpyHostToDevice));
+    return PV_OK;
+}
+
+int pv_tail_bf16_prepare() {
+    PV_HIP(hipFuncSetAttribute((const void*)k_tail_bf16, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_TAIL_BF));
+    return PV_OK;
+}
+
+int pv_tail_bf16_async(pv_ctx* ctx, const pv_tail_desc& d, hipStream_t st) {
+    PV_CHECK(d.part && d.wp && d.probs && d.B > 0 && d.splits >= 1, PV_ERR_INVALID, "bad tail launch");
+    TailBfArgs a;
+    a.part = d.part; a.splits = d.splits; a.part_rows = d.part_rows; a.b1 = d.b1; a.wp = d.wp;
+    for (int i = 0; i < 4; i++) a.b[i] = d.b[i];
+    a.wo = d.wo; a.bo = d.bo; a.probs = d.probs; a.B = d.B; a.epoch = d.epoch; a.err = d.err;
+    pv_prof_scope ps(ctx, "k_tail_bf16", st);
+    k_tail_bf16<<<(unsigned)((d.B + TL_ROWS - 1) / TL_ROWS), 512, LDS_TAIL_BF, st>>>(a);
+    PV_HIP(hipGetLastError());
     return PV_OK;
 }
 

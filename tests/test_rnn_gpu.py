@@ -286,7 +286,9 @@ def test_p1_bf16_mode_full_batch_properties(B):
     np.testing.assert_allclose(probs, p32, atol=TOL_PROBS, rtol=0)
     for lo in (0, B // 2 - 17, B - 40):
         alone = ctx.forward_p1(x[lo:lo + 40])
-        np.testing.assert_allclose(probs[lo:lo + 40], alone, atol=2e-6, rtol=0)
+        # (not bit for bit: the split factor of linear_1 and the tail kernel follow the batch size - a large batch runs linear_2..5 as
+        # split-bf16 products, a small one in fp32: 3e-6 observed)
+        np.testing.assert_allclose(probs[lo:lo + 40], alone, atol=1e-5, rtol=0)
     ref = rnn_oracle.p1_forward(w, x[:16], np.float64)
     np.testing.assert_allclose(probs[:16], ref, atol=TOL_PROBS, rtol=0)
     ctx.close()
