@@ -46,6 +46,8 @@ struct pv_rec_desc {
     unsigned char* out_bm;     // optional split8, batch-major [Bp][T * 2 * hidden] (A operand of linear_1)
     int mt;                    // M-tiles of 32 rows per workgroup: 1 or 2
     const char* prof_name;
+    const unsigned char* dense_w;   // GRU decoder only: fragments of a [5][2 * hidden] dense layer (pv_pack_p2_dense) and ...
+    float* dense_part;              // ... its partial logits [T][Bp / 32][2 dirs][4 waves][8][32 rows] (summed by k_p2_combine), or NULL
 };
 int pv_rec_bf16_async(pv_ctx* ctx, const pv_rec_desc& d, hipStream_t st);
 int pv_rec_bf16_prepare();
@@ -82,9 +84,12 @@ struct pv_p2_bf16_weights {
     float* enc_bias_hn = nullptr;      // [2][128]
     float* dec_bias_hn = nullptr;
     unsigned char* dec_wih_s = nullptr;   // decoder W_ih of both directions [768][256], split8 rows
+    unsigned char* dense_frag = nullptr;  // dense1 as MFMA fragments of the decoder kernel (pv_pack_p2_dense)
     float* dec_bias_cat = nullptr;        // [768]: per direction b_ir + b_hr, b_iz + b_hz, b_in
     const float* dense_w = nullptr;       // [5][256], [5] (owned by pv_rnn_p2)
     const float* dense_b = nullptr;
 };
+// dense_w [5][256] (host) -> [2 dirs][4 waves][2 k-steps][hi 1 KB | lo 1 KB]
+int pv_pack_p2_dense(const float* dense_w, unsigned char** d_frag, std::vector<void*>& owned);
 int pv_p2_bf16_forward(pv_ctx* ctx, const pv_p2_bf16_weights& w, const uint8_t* d_images, int64_t B, uint8_t* d_labels, float* d_acc,
                        hipStream_t st, int seq, int nwin, const float* d_hidden_in, float* d_hidden_out, float* d_logits);

@@ -73,6 +73,8 @@ struct RecArgs {
     unsigned char* out_tm;
     unsigned char* out_bm;
     int n_tiles;
+    const unsigned char* dw;   // GRU decoder: fragments of the dense layer (pv_pack_p2_dense) ...
+    float* dpart;              // ... and where its partial logits go: [T][tiles of 32 rows][2 dirs][4 waves][8 classes][32 rows], or NULL
 };
 
 // slots [I0, I0 + NKS * NG) of a stream of NTOT slots: slot = (k-step, gate) = [hi fragments | lo fragments] of 1 KB each.
@@ -324,6 +326,52 @@ __global__ __launch_bounds__(NG == 4 ? 512 : 256, 1) void k_rec_bf16(RecArgs a) 
         for (int k = 0; k < NCP; k++) { tile_read(k, tile); tile_write(k, tt); }
     };
     const __amdgpu_buffer_rsrc_t ofr = make_rsrc(reinterpret_cast<unsigned char*>(a.out_f32) + (size_t)b0 * rowb_bm);
+    // GRU decoder with the dense layer folded in (P2, pv_p2_bf16_forward): the logits need both directions' h_t, so every
+    // (tile, direction) workgroup contributes h_t[:, its 128 units] . W_dense[:, those units]^T as one more MFMA tile (32 rows x
+    // 32 "classes", 5 real), wave w over its k-steps 2w and 2w + 1; the partial sums of the 2 x 4 waves go out as quads (105 MB per
+    // window at 4096 chunks) instead of the layer's split8 output (420 MB written here and read again by k_p2_dense)
+    constexpr bool CAN_DENSE = NG == 3 && !ENC;
+    const bool dense = CAN_DENSE && a.dpart != nullptr;
+    bf16x8 dfr[CAN_DENSE ? 2 : 1][2];
+    if constexpr (CAN_DENSE) {
+        if (dense) {
+            const __amdgpu_buffer_rsrc_t dr = make_rsrc(a.dw + (size_t)(dir * NW + wv) * 2 * 2048);
+#pragma unroll
+            for (int k = 0; k < 2; k++) {
+                dfr[k][0] = __builtin_bit_cast(bf16x8, buf_load4(dr, lane16, (unsigned)(k * 2048)));
+                dfr[k][1] = __builtin_bit_cast(bf16x8, buf_load4(dr, lane16, (unsigned)(k * 2048 + 1024)));
+            }
+        }
+    }
+    auto dense_out = [&](int tt, const unsigned char* tile) {   // partial logits of the h tile of step tt
+        if constexpr (CAN_DENSE) {
+#pragma unroll
+            for (int m = 0; m < MT; m++) {
+                f32x16 ad;
+#pragma unroll
+                for (int e = 0; e < 16; e++) ad[e] = 0.0f;
+#pragma unroll
+                for (int k = 0; k < 2; k++) {
+                    const unsigned char* At = tile + (lane & 31) * HS + rg * 32 + m * 32 * HS + (2 * wv + k) * 64;
+                    const bf16x8 ah = *reinterpret_cast<const bf16x8*>(At), al = *reinterpret_cast<const bf16x8*>(At + 16);
+                    ad = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, dfr[k][0], ad, 0, 0, 0);
+                    ad = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, dfr[k][1], ad, 0, 0, 0);
+                    ad = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, dfr[k][0], ad, 0, 0, 0);
+                }
+                if ((lane & 31) < 8) {   // class lane & 31 (5 real, 3 zero), rows 8q + j + 4rg of this M-tile
+                    const size_t tile32 = (size_t)(b0 / 32) + m;
+                    float* dst = a.dpart + ((((size_t)tt * (a.Bp / 32) + tile32) * 2 + dir) * 4 + wv) * 256 + (lane & 31) * 32 + 4 * rg;
+#pragma unroll
+                    for (int q = 0; q < 4; q++) {
+                        f32x4 v;
+#pragma unroll
+                        for (int j = 0; j < 4; j++) v[j] = ad[4 * q + j];
+                        *reinterpret_cast<f32x4*>(dst + 8 * q) = v;
+                    }
+                }
+            }
+        }
+    };
     int cur = 0;
 #ifdef PV_REC_STAMPS
     unsigned long long st_acc[5] = {0, 0, 0, 0, 0}, st_last;
@@ -392,6 +440,7 @@ __global__ __launch_bounds__(NG == 4 ? 512 : 256, 1) void k_rec_bf16(RecArgs a) 
         } else {
             ring_bf16<NG, MT, NA, D, NSLOT, NXS, C::KS_H, false>(acc, a_h + cur * ROWS * HS, 32 * HS, wr, bq, lane16, copy_hook);
         }
+        if (dense && s > 0) dense_out(t_prev, tile_prev);   // (the previous step's h tile: this step's A operand)
         if (NW == 8) { if (wv < 4) __builtin_amdgcn_s_setprio(2); else __builtin_amdgcn_s_setprio(1); }
         RSTAMP(1)
         // ---- cell update --------------------------------------------------------------------------------------------------------
@@ -442,6 +491,7 @@ __global__ __launch_bounds__(NG == 4 ? 512 : 256, 1) void k_rec_bf16(RecArgs a) 
         RSTAMP(4)
     }
     tile_out(dir ? 0 : T - 1, hbuf + cur * ROWS * HS);
+    if (dense) dense_out(dir ? 0 : T - 1, hbuf + cur * ROWS * HS);
 #ifdef PV_REC_STAMPS
     if (blockIdx.x == 0 && lane == 0)
         for (int i = 0; i < 5; i++) atomicAdd(&g_rec_stamps[i], st_acc[i]);
@@ -707,6 +757,8 @@ int pv_rec_bf16_async(pv_ctx* ctx, const pv_rec_desc& d, hipStream_t st) {
     a.x_row_bytes = d.x_row_bytes; a.x_t0 = d.x_t0; a.xf = d.xf; a.x_signed = d.x_signed; a.B = d.B; a.Bp = d.Bp; a.T = d.T;
     a.h0 = d.h0; a.h_out = d.h_out; a.out_f32 = d.out_f32; a.out_tm = d.out_tm; a.out_bm = d.out_bm;
     a.n_tiles = (int)(d.Bp / (32 * d.mt));
+    a.dw = d.dense_w; a.dpart = d.dense_part;
+    PV_CHECK(!d.dense_part || (d.cell == 3 && !d.enc && d.dense_w), PV_ERR_INVALID, "the dense layer folds into the GRU decoder only");
     const unsigned grid = (unsigned)(((a.n_tiles + 3) / 4) * 8);
     pv_prof_scope ps(ctx, d.prof_name, st);
 #define PV_REC_GO(NG, ENC, MT) k_rec_bf16<NG, ENC, MT><<<grid, RecCfg<NG, ENC>::NTHR, lds_rec<NG, ENC, MT>(), st>>>(a)
@@ -803,7 +855,62 @@ __global__ __launch_bounds__(256) void k_p2_state_out(const float* __restrict__ 
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i < B * 2 * P2_H) hout[i] = state[i];
 }
+
+// sum of the decoder kernel's partial logits (2 directions x 4 waves) + bias -> softmax -> accumulate (predict.py:70-89);
+// thread = (t, chunk). part: [100][Bp / 32][2][4][8 classes][32 rows]
+__global__ __launch_bounds__(256) void k_p2_combine(const float* __restrict__ part, int64_t Bp, int64_t B, const float* __restrict__ bias,
+                                                    float* __restrict__ acc, int seq, int ws, float* __restrict__ logits) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (int64_t)P2_WIN * B) return;
+    const int t = (int)(i / B);
+    const int64_t b = i - (int64_t)t * B;
+    const float* p = part + (((size_t)t * (Bp / 32) + (size_t)(b >> 5)) * 8) * 256 + (b & 31);
+    float lg[P2_NC];
+#pragma unroll
+    for (int c = 0; c < P2_NC; c++) lg[c] = bias[c];
+#pragma unroll
+    for (int k = 0; k < 8; k++)   // (direction, wave)
+#pragma unroll
+        for (int c = 0; c < P2_NC; c++) lg[c] += p[k * 256 + c * 32];
+    float m = lg[0];
+#pragma unroll
+    for (int c = 1; c < P2_NC; c++) m = fmaxf(m, lg[c]);
+    float e[P2_NC], sum = 0.0f;
+#pragma unroll
+    for (int c = 0; c < P2_NC; c++) { e[c] = expf(lg[c] - m); sum += e[c]; }
+    const float inv = 1.0f / sum;
+    float* ac = acc + ((size_t)b * seq + ws + t) * P2_NC;
+#pragma unroll
+    for (int c = 0; c < P2_NC; c++) ac[c] += e[c] * inv;
+    if (logits) {
+#pragma unroll
+        for (int c = 0; c < P2_NC; c++) logits[((size_t)b * P2_WIN + t) * P2_NC + c] = lg[c];
+    }
+}
 }  // namespace
+
+int pv_pack_p2_dense(const float* dense_w, unsigned char** d_frag, std::vector<void*>& owned) {
+    // wave w of direction d takes k-steps 2w, 2w + 1 of that direction's 128 units; lane -> class lane & 31 (zero beyond the
+    // five), values k = 16 ks + 8 (lane >> 5) + j
+    std::vector<uint16_t> f((size_t)2 * 4 * 2 * 1024, 0);
+    for (int d = 0; d < 2; d++)
+        for (int w = 0; w < 4; w++)
+            for (int kk = 0; kk < 2; kk++) {
+                uint16_t* dst = f.data() + (((size_t)d * 4 + w) * 2 + kk) * 1024;
+                for (int lane = 0; lane < 64; lane++)
+                    for (int j = 0; j < 8; j++) {
+                        const int n = lane & 31, k = 16 * (2 * w + kk) + 8 * (lane >> 5) + j;
+                        const float v = n < P2_NC ? dense_w[(size_t)n * 2 * P2_H + d * P2_H + k] : 0.0f;
+                        const uint16_t hi = f2bf_bits(v);
+                        dst[lane * 8 + j] = hi;
+                        dst[512 + lane * 8 + j] = f2bf_bits(v - bf_bits2f(hi));
+                    }
+            }
+    PV_HIP(hipMalloc((void**)d_frag, f.size() * 2));
+    owned.push_back(*d_frag);
+    PV_HIP(hipMemcpy(*d_frag, f.data(), f.size() * 2, hipMemcpyHostToDevice));
+    return PV_OK;
+}
 
 int pv_p2_bf16_forward(pv_ctx* ctx, const pv_p2_bf16_weights& w, const uint8_t* d_images, int64_t B, uint8_t* d_labels, float* d_acc,
                        hipStream_t st, int seq, int nwin, const float* d_hidden_in, float* d_hidden_out, float* d_logits) {
@@ -818,7 +925,17 @@ int pv_p2_bf16_forward(pv_ctx* ctx, const pv_p2_bf16_weights& w, const uint8_t* 
     if ((rc = pv_get(ctx, "p2b.state", (size_t)Bp * 2 * P2_H, &state))) return rc;
     if ((rc = pv_get(ctx, "p2b.enc_s", (size_t)M * 2 * P2_H * 4, &enc_s))) return rc;
     if ((rc = pv_get(ctx, "p2b.G", (size_t)M * 6 * P2_H, &G))) return rc;
-    if ((rc = pv_get(ctx, "p2b.dec_s", (size_t)M * 2 * P2_H * 4, &dec))) return rc;
+    // dense1: from 2048 chunks on as one more MFMA tile of the decoder's steps (partial logits of 2 directions x 4 waves, 105 MB
+    // per window at 4096 chunks, summed by k_p2_combine) instead of the decoder's split8 output (420 MB) and k_p2_dense's pass
+    // over it: 24.9 -> 23.9 ms at 4096 chunks. It lengthens every decoder step by ~5 %, which is all a small batch sees (64
+    // chunks: 12.3 -> 12.6 ms), so those keep the separate pass.
+    const bool fold_dense = B >= 2048;
+    float* dpart = nullptr;
+    if (fold_dense) {
+        if ((rc = pv_get(ctx, "p2b.dpart", (size_t)P2_WIN * (Bp / 32) * 8 * 256, &dpart))) return rc;
+    } else if ((rc = pv_get(ctx, "p2b.dec_s", (size_t)M * 2 * P2_H * 4, &dec))) {
+        return rc;
+    }
     if ((rc = pv_zero_async(d_acc, (size_t)B * seq * P2_NC * sizeof(float), st))) return rc;
     k_p2_state_in<<<(unsigned)((Bp * 2 * P2_H + 255) / 256), 256, 0, st>>>(state, d_hidden_in, B, Bp);
     for (int wi = 0; wi < nwin; wi++) {
@@ -834,13 +951,20 @@ int pv_p2_bf16_forward(pv_ctx* ctx, const pv_p2_bf16_weights& w, const uint8_t* 
         if ((rc = pv_gemm_bf16x3_async(ctx, g, st))) return rc;
         pv_rec_desc d = {};
         d.cell = 3; d.enc = 0; d.G = G; d.wp = w.dec_wp; d.bias_hn = w.dec_bias_hn; d.B = B; d.Bp = Bp; d.T = P2_WIN;
-        d.h0 = state; d.h_out = state; d.out_tm = dec; d.mt = mt; d.prof_name = "k_rec_bf16_gru_dec";
-        if ((rc = pv_rec_bf16_async(ctx, d, st))) return rc;
-        {
+        d.h0 = state; d.h_out = state; d.mt = mt; d.prof_name = "k_rec_bf16_gru_dec";
+        float* lg_out = (d_logits && wi == nwin - 1) ? d_logits : nullptr;
+        if (fold_dense) {
+            d.dense_w = w.dense_frag; d.dense_part = dpart;
+            if ((rc = pv_rec_bf16_async(ctx, d, st))) return rc;
+            pv_prof_scope ps(ctx, "k_p2_combine", st);
+            const int64_t nthr = (int64_t)P2_WIN * B;
+            k_p2_combine<<<(unsigned)((nthr + 255) / 256), 256, 0, st>>>(dpart, Bp, B, w.dense_b, d_acc, seq, ws, lg_out);
+        } else {
+            d.out_tm = dec;
+            if ((rc = pv_rec_bf16_async(ctx, d, st))) return rc;
             pv_prof_scope ps(ctx, "k_p2_dense", st);
             const int64_t nthr = (int64_t)P2_WIN * B * 8;
-            k_p2_dense<<<(unsigned)((nthr + 255) / 256), 256, 0, st>>>(dec, Bp, B, w.dense_w, w.dense_b, d_acc, seq, ws,
-                                                                        (d_logits && wi == nwin - 1) ? d_logits : nullptr);
+            k_p2_dense<<<(unsigned)((nthr + 255) / 256), 256, 0, st>>>(dec, Bp, B, w.dense_w, w.dense_b, d_acc, seq, ws, lg_out);
         }
     }
     if (d_hidden_out) k_p2_state_out<<<(unsigned)((B * 2 * P2_H + 255) / 256), 256, 0, st>>>(state, d_hidden_out, B);

@@ -549,7 +549,7 @@ def test_p2_bf16_mode_vs_fp32_mode_and_oracle(B):
     c32 = runtime.Context(0)
     c32.load_p2(w)
     l32, a32 = c32.forward_p2(y, want_acc=True)
-    nw = min(B, 200)
+    nw = min(B, 200) if B < 4096 else 2100   # (from 2048 chunks on dense1 is folded into the decoder kernel: the window operator too)
     h_in = (np.random.default_rng(3).standard_normal((nw, 2, 128)) * 0.3).astype(np.float32)
     lg32, h32 = c32.forward_p2_window(y[:nw, 300:400].copy(), h_in)
     c32.close()
