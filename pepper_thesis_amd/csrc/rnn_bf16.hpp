@@ -46,6 +46,7 @@ struct pv_rec_desc {
     unsigned char* out_bm;     // optional split8, batch-major [Bp][T * 2 * hidden] (A operand of linear_1)
     int mt;                    // M-tiles of 32 rows per workgroup: 1 or 2
     const char* prof_name;
+    int tr16;                  // 1: GRU on 16-row tiles (k_gru16_bf16; wp / wx from pv_pack_gru16_bf16, Bp a multiple of 16, mt unused)
     const unsigned char* dense_w;   // GRU decoder only: fragments of a [5][2 * hidden] dense layer (pv_pack_p2_dense) and ...
     float* dense_part;              // ... its partial logits [T][Bp / 32][2 dirs][4 waves][8][32 rows] (summed by k_p2_combine), or NULL
 };
@@ -53,6 +54,7 @@ int pv_rec_bf16_async(pv_ctx* ctx, const pv_rec_desc& d, hipStream_t st);
 int pv_rec_bf16_prepare();
 // dirs[2] (PyTorch layout) -> device fragment stream(s). kx = real input features (enc) or 0.
 int pv_pack_rec_bf16(const pv_rnn_dir* dirs, int cell, int kx, unsigned char** d_wp, unsigned char** d_wx, std::vector<void*>& owned);
+int pv_pack_gru16_bf16(const pv_rnn_dir* dirs, int kx, unsigned char** d_wp, unsigned char** d_wx, std::vector<void*>& owned);
 
 // ---- k_tail_bf16: the tail of the P1 head (sum of linear_1 slabs + bias + SELU, linear_2..5 + SELU, output layer, softmax) with
 // the four 512 x 512 layers as 3-term split products (rnn_rec_bf16.hip). 64 rows per workgroup.
@@ -85,6 +87,9 @@ struct pv_p2_bf16_weights {
     float* dec_bias_hn = nullptr;
     unsigned char* dec_wih_s = nullptr;   // decoder W_ih of both directions [768][256], split8 rows
     unsigned char* dense_frag = nullptr;  // dense1 as MFMA fragments of the decoder kernel (pv_pack_p2_dense)
+    unsigned char* enc16_wp = nullptr;    // the same layers packed for the 16-row form (pv_pack_gru16_bf16)
+    unsigned char* enc16_wx = nullptr;
+    unsigned char* dec16_wp = nullptr;
     float* dec_bias_cat = nullptr;        // [768]: per direction b_ir + b_hr, b_iz + b_hz, b_in
     const float* dense_w = nullptr;       // [5][256], [5] (owned by pv_rnn_p2)
     const float* dense_b = nullptr;

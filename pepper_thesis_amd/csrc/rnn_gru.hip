@@ -1071,6 +1071,8 @@ extern "C" int pv_rnn_load_p2(pv_ctx* ctx, const pv_weights_p2* w, int dtype) {
         }
         if ((rc = pv_pack_rec_bf16(w->encoder, 3, FEAT, &m->bf.enc_wp, &m->bf.enc_wx, m->owned))) return rc;
         if ((rc = pv_pack_rec_bf16(w->decoder, 3, 0, &m->bf.dec_wp, nullptr, m->owned))) return rc;
+        if ((rc = pv_pack_gru16_bf16(w->encoder, FEAT, &m->bf.enc16_wp, &m->bf.enc16_wx, m->owned))) return rc;
+        if ((rc = pv_pack_gru16_bf16(w->decoder, 0, &m->bf.dec16_wp, nullptr, m->owned))) return rc;
         if ((rc = up2(eb.data(), eb.size(), &m->bf.enc_bias, m->owned)) || (rc = up2(ehn.data(), ehn.size(), &m->bf.enc_bias_hn, m->owned)) ||
             (rc = up2(dhn.data(), dhn.size(), &m->bf.dec_bias_hn, m->owned)) || (rc = up2(bcat.data(), bcat.size(), &m->bf.dec_bias_cat, m->owned)))
             return rc;

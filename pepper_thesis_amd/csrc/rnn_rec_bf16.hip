@@ -507,6 +507,212 @@ __global__ __launch_bounds__(NG == 4 ? 512 : 256, 1) void k_rec_bf16(RecArgs a) 
     }
 }
 
+// ---- the GRU layers on 16-row tiles (small P2 batches) -----------------------------------------------------------------------
+// A launch is a chain of T dependent steps whose duration is the step time of ONE workgroup. While the (16-row tile, direction)
+// workgroups all fit on the chip (up to 2048 chunks on 256 CUs) v_mfma_f32_16x16x32_bf16 halves both the MFMA time and the cell
+// update of a step against the 32-row form - the same FLOP per cycle on half the rows. Wave w owns units [32w, 32w + 32) as two
+// 16-unit tiles; W_hh (3 gates x 2 tiles x 4 k-steps of 32, hi + lo: 192 registers per lane) and, in the encoder, W_ih (one k-step:
+// 48 registers) stay resident. Fragment layouts: A lane -> row lane & 15, k = 8 (lane >> 4) + j; B lane -> unit lane & 15, same k;
+// D lane -> unit lane & 15, rows 4 (lane >> 4) + register - the quads [m / 4][column][4] the input GEMM writes are one
+// accumulator each.
+constexpr int G16_HS = 128 * 4 + 16, G16_XS = 32 * 2 + 16;
+template <bool ENC>
+__global__ __launch_bounds__(256, 1) void k_gru16_bf16(RecArgs a) {
+    constexpr int HID = 128, NW = 4, ROWS = 16, HS = G16_HS, XS = G16_XS, NCOL = 6 * HID;
+    __shared__ __attribute__((aligned(16))) unsigned char hbuf[2 * ROWS * HS];
+    __shared__ __attribute__((aligned(16))) unsigned char xbuf[ENC ? 2 * ROWS * XS : 16];
+    const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int xcd = blockIdx.x & 7, dir = xcd & 1;
+    const int tile = (blockIdx.x >> 3) * 4 + (xcd >> 1);
+    if (tile >= a.n_tiles) return;
+    const int64_t b0 = (int64_t)tile * ROWS;
+    const int lr = lane & 15, q = lane >> 4, T = a.T;
+    const unsigned lane16 = (unsigned)lane * 16u;
+    // resident weights: slot (ks * 3 + g) * 2 + nt of this wave's stream = [hi 1 KB | lo 1 KB]
+    bf16x8 wres[24][2];
+    {
+        const __amdgpu_buffer_rsrc_t wr = make_rsrc(a.wp + (size_t)(dir * NW + wv) * 24 * 2048);
+#pragma unroll
+        for (int k = 0; k < 24; k++) {
+            wres[k][0] = __builtin_bit_cast(bf16x8, buf_load4(wr, lane16, (unsigned)(k * 2048)));
+            wres[k][1] = __builtin_bit_cast(bf16x8, buf_load4(wr, lane16, (unsigned)(k * 2048 + 1024)));
+        }
+    }
+    bf16x8 xw[ENC ? 6 : 1][2];
+    if constexpr (ENC) {
+        const __amdgpu_buffer_rsrc_t xr = make_rsrc(a.wx + (size_t)(dir * NW + wv) * 6 * 2048);
+#pragma unroll
+        for (int k = 0; k < 6; k++) {
+            xw[k][0] = __builtin_bit_cast(bf16x8, buf_load4(xr, lane16, (unsigned)(k * 2048)));
+            xw[k][1] = __builtin_bit_cast(bf16x8, buf_load4(xr, lane16, (unsigned)(k * 2048 + 1024)));
+        }
+    }
+    float b_g[3][2], b_hn[2];
+#pragma unroll
+    for (int nt = 0; nt < 2; nt++) {
+        const int unit = 32 * wv + 16 * nt + lr;
+        b_hn[nt] = a.bias_hn[dir * HID + unit];
+#pragma unroll
+        for (int g = 0; g < 3; g++) b_g[g][nt] = ENC ? a.bias[dir * 3 * HID + g * HID + unit] : 0.0f;
+    }
+    // state and the h tile
+    float st[2][4];
+    for (int i = tid; i < 2 * ROWS * HS / 16; i += 256) reinterpret_cast<u32x4*>(hbuf)[i] = u32x4{0u, 0u, 0u, 0u};
+    if constexpr (ENC)
+        for (int i = tid; i < 2 * ROWS * XS / 16; i += 256) reinterpret_cast<u32x4*>(xbuf)[i] = u32x4{0u, 0u, 0u, 0u};
+#pragma unroll
+    for (int nt = 0; nt < 2; nt++)
+#pragma unroll
+        for (int j = 0; j < 4; j++) st[nt][j] = 0.0f;
+    __syncthreads();
+    unsigned hl[2];   // lane part of an h element's LDS offset: row 4q (+ j), unit of tile nt
+#pragma unroll
+    for (int nt = 0; nt < 2; nt++) hl[nt] = (unsigned)(4 * q * HS) + split8_off((unsigned)(32 * wv + 16 * nt + lr));
+    if (a.h0) {
+#pragma unroll
+        for (int nt = 0; nt < 2; nt++)
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const float h = a.h0[((b0 + 4 * q + j) * 2 + dir) * HID + 32 * wv + 16 * nt + lr];
+                st[nt][j] = h;
+                const __bf16 hi = (__bf16)h;
+                const __bf16 lo = (__bf16)(h - (float)hi);
+                *reinterpret_cast<__bf16*>(hbuf + j * HS + hl[nt]) = hi;
+                *reinterpret_cast<__bf16*>(hbuf + j * HS + hl[nt] + 16) = lo;
+            }
+    }
+    // x staging (encoder): thread -> (row tid / 16, feature tid % 16): one byte per step (features beyond xf stay zero)
+    const int xrow = tid >> 4, xf_i = tid & 15;
+    const unsigned char* xsrc = nullptr;
+    unsigned xv = 0u;
+    const bool x_on = ENC && xf_i < a.xf;
+    if constexpr (ENC) {
+        int64_t r = b0 + xrow;
+        if (r >= a.B) r = a.B - 1;
+        xsrc = a.x + r * a.x_row_bytes + (int64_t)a.x_t0 * a.xf + xf_i;
+    }
+    auto x_load = [&](int t) { if constexpr (ENC) { if (x_on) xv = (unsigned)xsrc[(int64_t)t * a.xf]; } };
+    auto x_store = [&](int slot) {
+        if constexpr (ENC) {
+            if (x_on) {
+                const float f = a.x_signed ? (float)(int)(signed char)xv : (float)xv;
+                *reinterpret_cast<__bf16*>(xbuf + (slot * ROWS + xrow) * XS + xf_i * 2) = (__bf16)f;
+            }
+        }
+    };
+    // decoder: the step's input projections (quad row (t * Bp + b0) / 4 + q, column dir * 384 + g * 128 + unit)
+    f32x4 gq[ENC ? 1 : 3][2];
+    auto g_load = [&](int t) {
+        if constexpr (!ENC) {
+            const __amdgpu_buffer_rsrc_t gsr = make_rsrc(a.G + ((size_t)t * a.Bp + b0) * NCOL);
+#pragma unroll
+            for (int g = 0; g < 3; g++)
+#pragma unroll
+                for (int nt = 0; nt < 2; nt++)
+                    gq[g][nt] = buf_load4_nt(gsr, (unsigned)((q * NCOL + lr) * 16), (unsigned)((dir * 3 * HID + g * HID + 32 * wv + 16 * nt) * 16));
+        }
+    };
+    // layer output: the finished h tile (split8 rows, 512 bytes each) as 16-byte copies, two per thread
+    const unsigned rowb_tm = 2u * HID * 4u, rowb_bm = (unsigned)T * 2u * HID * 4u;
+    const bool want_out = a.out_tm || a.out_bm;
+    auto tile_out = [&](int tt, const unsigned char* tl) {
+        if (!want_out) return;
+#pragma unroll
+        for (int k = 0; k < 2; k++) {
+            const int c = tid + k * 256, row = c >> 5, col = c & 31;
+            const u32x4 v = *reinterpret_cast<const u32x4*>(tl + row * HS + col * 16);
+            if (a.out_tm) {
+                const __amdgpu_buffer_rsrc_t tmr = make_rsrc(a.out_tm + ((size_t)tt * a.Bp + b0) * rowb_tm);
+                __builtin_amdgcn_raw_buffer_store_b128(v, tmr, (unsigned)(row * (int)rowb_tm + col * 16), (unsigned)(dir * HID * 4), 2);
+            }
+            if (a.out_bm) {
+                const __amdgpu_buffer_rsrc_t bmr = make_rsrc(a.out_bm + (size_t)b0 * rowb_bm);
+                __builtin_amdgcn_raw_buffer_store_b128(v, bmr, (unsigned)row * rowb_bm + (unsigned)(col * 16), (unsigned)((tt * 2 + dir) * HID * 4), 2);
+            }
+        }
+    };
+    x_load(dir ? T - 1 : 0);
+    x_store(0);
+    g_load(dir ? T - 1 : 0);
+    __syncthreads();
+    int cur = 0;
+    for (int s = 0; s < T; s++) {
+        const int t = dir ? (T - 1 - s) : s;
+        const int tn = dir ? (T - 2 - s) : (s + 1);
+        if (s + 1 < T) x_load(tn);
+        if (s > 0) tile_out(dir ? t + 1 : t - 1, hbuf + cur * ROWS * HS);
+        f32x4 ar[2], az[2], anx[2], anh[2];
+#pragma unroll
+        for (int nt = 0; nt < 2; nt++) {
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                ar[nt][j] = ENC ? b_g[0][nt] : gq[0][nt][j];
+                az[nt][j] = ENC ? b_g[1][nt] : gq[1][nt][j];
+                anx[nt][j] = ENC ? b_g[2][nt] : gq[ENC ? 0 : 2][nt][j];
+                anh[nt][j] = b_hn[nt];
+            }
+        }
+        if constexpr (ENC) {   // byte input: exact in bf16, two terms
+            const bf16x8 ax = *reinterpret_cast<const bf16x8*>(xbuf + ((s & 1) * ROWS + lr) * XS + q * 16);
+#pragma unroll
+            for (int nt = 0; nt < 2; nt++) {
+                ar[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ax, xw[0 * 2 + nt][0], ar[nt], 0, 0, 0);
+                ar[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ax, xw[0 * 2 + nt][1], ar[nt], 0, 0, 0);
+                az[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ax, xw[1 * 2 + nt][0], az[nt], 0, 0, 0);
+                az[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ax, xw[1 * 2 + nt][1], az[nt], 0, 0, 0);
+                anx[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ax, xw[2 * 2 + nt][0], anx[nt], 0, 0, 0);
+                anx[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ax, xw[2 * 2 + nt][1], anx[nt], 0, 0, 0);
+            }
+        }
+        {   // h_{t-1} . W_hh^T, three terms
+            const unsigned char* At = hbuf + cur * ROWS * HS + lr * HS + q * 32;
+#pragma unroll
+            for (int ks = 0; ks < 4; ks++) {
+                const bf16x8 ah = *reinterpret_cast<const bf16x8*>(At + ks * 128), al = *reinterpret_cast<const bf16x8*>(At + ks * 128 + 16);
+#pragma unroll
+                for (int nt = 0; nt < 2; nt++) {
+                    const int s0 = (ks * 3 + 0) * 2 + nt, s1 = (ks * 3 + 1) * 2 + nt, s2 = (ks * 3 + 2) * 2 + nt;
+                    ar[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, wres[s0][0], ar[nt], 0, 0, 0);
+                    ar[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, wres[s0][1], ar[nt], 0, 0, 0);
+                    ar[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, wres[s0][0], ar[nt], 0, 0, 0);
+                    az[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, wres[s1][0], az[nt], 0, 0, 0);
+                    az[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, wres[s1][1], az[nt], 0, 0, 0);
+                    az[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, wres[s1][0], az[nt], 0, 0, 0);
+                    anh[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, wres[s2][0], anh[nt], 0, 0, 0);
+                    anh[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, wres[s2][1], anh[nt], 0, 0, 0);
+                    anh[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, wres[s2][0], anh[nt], 0, 0, 0);
+                }
+            }
+        }
+        if (s + 1 < T) g_load(tn);   // (behind the last use of this step's projections: they travel during the cell update and the barrier)
+        unsigned char* hn = hbuf + (cur ^ 1) * ROWS * HS;
+#pragma unroll
+        for (int nt = 0; nt < 2; nt++)
+#pragma unroll
+            for (int j = 0; j < 4; j++) {   // PyTorch GRU: n = tanh(W_in x + b_in + r * (W_hn h + b_hn)), h' = (1 - z) n + z h
+                const float r = sigmoidf_(ar[nt][j]);
+                const float z = sigmoidf_(az[nt][j]);
+                const float n = tanhf_(anx[nt][j] + r * anh[nt][j]);
+                const float h = (1.0f - z) * n + z * st[nt][j];
+                st[nt][j] = h;
+                const __bf16 hi = (__bf16)h;
+                const __bf16 lo = (__bf16)(h - (float)hi);
+                *reinterpret_cast<__bf16*>(hn + j * HS + hl[nt]) = hi;
+                *reinterpret_cast<__bf16*>(hn + j * HS + hl[nt] + 16) = lo;
+            }
+        if (s + 1 < T) x_store((s + 1) & 1);
+        cur ^= 1;
+        lds_barrier();
+    }
+    tile_out(dir ? 0 : T - 1, hbuf + cur * ROWS * HS);
+    if (a.h_out) {
+#pragma unroll
+        for (int nt = 0; nt < 2; nt++)
+#pragma unroll
+            for (int j = 0; j < 4; j++) a.h_out[((b0 + 4 * q + j) * 2 + dir) * HID + 32 * wv + 16 * nt + lr] = st[nt][j];
+    }
+}
+
 template <int NG, bool ENC, int MT> constexpr size_t lds_rec() {
     typedef RecCfg<NG, ENC> C;
     return (size_t)2 * 32 * MT * C::HS + (ENC ? (size_t)2 * 32 * MT * C::XS : 0);
@@ -700,6 +906,40 @@ int pv_pack_rec_bf16(const pv_rnn_dir* dirs, int cell, int kx, unsigned char** d
     return PV_OK;
 }
 
+// GRU weights for k_gru16_bf16: per (direction, wave) 24 slots (ks * 3 + g) * 2 + nt of W_hh and, with kx > 0, 6 slots g * 2 + nt of
+// W_ih (features beyond kx zero); lane -> unit 32 w + 16 nt + (lane & 15), values k = 32 ks + 8 (lane >> 4) + j
+int pv_pack_gru16_bf16(const pv_rnn_dir* dirs, int kx, unsigned char** d_wp, unsigned char** d_wx, std::vector<void*>& owned) {
+    const int HID = 128, NW = 4;
+    std::vector<uint16_t> wp((size_t)2 * NW * 24 * 1024), wx(kx ? (size_t)2 * NW * 6 * 1024 : 0);
+    for (int d = 0; d < 2; d++)
+        for (int w = 0; w < NW; w++)
+            for (int g = 0; g < 3; g++)
+                for (int nt = 0; nt < 2; nt++) {
+                    auto fill = [&](uint16_t* dst, bool xpart, int ks) {
+                        for (int lane = 0; lane < 64; lane++)
+                            for (int j = 0; j < 8; j++) {
+                                const int n = g * HID + 32 * w + 16 * nt + (lane & 15), k = 32 * ks + 8 * (lane >> 4) + j;
+                                const float v = xpart ? (k < kx ? dirs[d].w_ih[(size_t)n * kx + k] : 0.0f) : dirs[d].w_hh[(size_t)n * HID + k];
+                                const uint16_t hi = f2bf_bits(v);
+                                dst[lane * 8 + j] = hi;
+                                dst[512 + lane * 8 + j] = f2bf_bits(v - bf_bits2f(hi));
+                            }
+                    };
+                    for (int ks = 0; ks < 4; ks++) fill(wp.data() + ((size_t)(d * NW + w) * 24 + (ks * 3 + g) * 2 + nt) * 1024, false, ks);
+                    if (kx) fill(wx.data() + ((size_t)(d * NW + w) * 6 + g * 2 + nt) * 1024, true, 0);
+                }
+    PV_HIP(hipMalloc((void**)d_wp, wp.size() * 2));
+    owned.push_back(*d_wp);
+    PV_HIP(hipMemcpy(*d_wp, wp.data(), wp.size() * 2, hipMemcpyHostToDevice));
+    if (d_wx) *d_wx = nullptr;
+    if (kx) {
+        PV_HIP(hipMalloc((void**)d_wx, wx.size() * 2));
+        owned.push_back(*d_wx);
+        PV_HIP(hipMemcpy(*d_wx, wx.data(), wx.size() * 2, hipMemcpyHostToDevice));
+    }
+    return PV_OK;
+}
+
 int pv_pack_tail_bf16(const float* const* w, unsigned char** d_wp, std::vector<void*>& owned) {
     // per wave: [layer][k-step][column tile] slots of [hi 1 KB | lo 1 KB]; lane -> column 64 wave + 32 tile + (lane & 31),
     // values k = 16 ks + 8 (lane >> 5) + j
@@ -751,14 +991,24 @@ int pv_rec_bf16_prepare() {
 }
 
 int pv_rec_bf16_async(pv_ctx* ctx, const pv_rec_desc& d, hipStream_t st) {
-    PV_CHECK((d.cell == 3 || d.cell == 4) && (d.mt == 1 || d.mt == 2) && d.T > 0 && d.Bp % (32 * d.mt) == 0, PV_ERR_INVALID, "bad recurrent-layer launch");
+    PV_CHECK((d.cell == 3 || d.cell == 4) && d.T > 0 && (d.tr16 || ((d.mt == 1 || d.mt == 2) && d.Bp % (32 * d.mt) == 0)), PV_ERR_INVALID, "bad recurrent-layer launch");
     RecArgs a;
     a.G = d.G; a.wp = d.wp; a.wx = d.wx; a.bias = d.bias; a.bias_hn = d.bias_hn; a.x = (const unsigned char*)d.x;
     a.x_row_bytes = d.x_row_bytes; a.x_t0 = d.x_t0; a.xf = d.xf; a.x_signed = d.x_signed; a.B = d.B; a.Bp = d.Bp; a.T = d.T;
     a.h0 = d.h0; a.h_out = d.h_out; a.out_f32 = d.out_f32; a.out_tm = d.out_tm; a.out_bm = d.out_bm;
-    a.n_tiles = (int)(d.Bp / (32 * d.mt));
+    a.n_tiles = d.tr16 ? 0 : (int)(d.Bp / (32 * d.mt));
     a.dw = d.dense_w; a.dpart = d.dense_part;
     PV_CHECK(!d.dense_part || (d.cell == 3 && !d.enc && d.dense_w), PV_ERR_INVALID, "the dense layer folds into the GRU decoder only");
+    if (d.tr16) {   // GRU on 16-row tiles (its own fragment streams: pv_pack_gru16_bf16)
+        PV_CHECK(d.cell == 3 && d.Bp % 16 == 0 && !d.dense_part && !d.out_f32, PV_ERR_INVALID, "bad 16-row GRU launch");
+        a.n_tiles = (int)(d.Bp / 16);
+        const unsigned grid16 = (unsigned)(((a.n_tiles + 3) / 4) * 8);
+        pv_prof_scope ps16(ctx, d.prof_name, st);
+        if (d.enc) k_gru16_bf16<true><<<grid16, 256, 0, st>>>(a);
+        else k_gru16_bf16<false><<<grid16, 256, 0, st>>>(a);
+        PV_HIP(hipGetLastError());
+        return PV_OK;
+    }
     const unsigned grid = (unsigned)(((a.n_tiles + 3) / 4) * 8);
     pv_prof_scope ps(ctx, d.prof_name, st);
 #define PV_REC_GO(NG, ENC, MT) k_rec_bf16<NG, ENC, MT><<<grid, RecCfg<NG, ENC>::NTHR, lds_rec<NG, ENC, MT>(), st>>>(a)
@@ -917,7 +1167,9 @@ int pv_p2_bf16_forward(pv_ctx* ctx, const pv_p2_bf16_weights& w, const uint8_t* 
     // 64-row tiles (one weight fetch feeds twice the rows) once 32-row (tile, direction) workgroups would need more than two
     // rounds of the chip; below that 32-row tiles keep more CUs busy
     const int mt = ((B + 31) / 32) * 2 > 2 * (int64_t)ctx->num_cu ? 2 : 1;
-    const int rows = 32 * mt;
+    // 16-row tiles (k_gru16_bf16: half the MFMA and cell-update time per step) while every (tile, direction) workgroup has a CU
+    const bool tr16 = ((B + 15) / 16) * 2 <= (int64_t)ctx->num_cu;
+    const int rows = tr16 ? 16 : 32 * mt;
     const int64_t Bp = (B + rows - 1) / rows * rows, M = (int64_t)P2_WIN * Bp;
     float *state = nullptr, *G = nullptr;
     unsigned char *enc_s = nullptr, *dec = nullptr;
@@ -944,6 +1196,7 @@ int pv_p2_bf16_forward(pv_ctx* ctx, const pv_p2_bf16_weights& w, const uint8_t* 
         e.cell = 3; e.enc = 1; e.wp = w.enc_wp; e.wx = w.enc_wx; e.bias = w.enc_bias; e.bias_hn = w.enc_bias_hn;
         e.x = d_images; e.x_row_bytes = (int64_t)seq * P2_F; e.x_t0 = ws; e.xf = P2_F; e.x_signed = 0;
         e.B = B; e.Bp = Bp; e.T = P2_WIN; e.h0 = state; e.h_out = state; e.out_tm = enc_s; e.mt = mt; e.prof_name = "k_rec_bf16_gru_enc";
+        if (tr16) { e.tr16 = 1; e.wp = w.enc16_wp; e.wx = w.enc16_wx; e.prof_name = "k_gru16_bf16_enc"; }
         if ((rc = pv_rec_bf16_async(ctx, e, st))) return rc;
         pv_gemm_desc g = {};
         g.A = enc_s; g.W = w.dec_wih_s; g.bias = w.dec_bias_cat; g.C = G; g.M = M; g.N = 6 * P2_H; g.K = 2 * P2_H; g.splits = 1; g.quads = 1;
@@ -952,6 +1205,7 @@ int pv_p2_bf16_forward(pv_ctx* ctx, const pv_p2_bf16_weights& w, const uint8_t* 
         pv_rec_desc d = {};
         d.cell = 3; d.enc = 0; d.G = G; d.wp = w.dec_wp; d.bias_hn = w.dec_bias_hn; d.B = B; d.Bp = Bp; d.T = P2_WIN;
         d.h0 = state; d.h_out = state; d.mt = mt; d.prof_name = "k_rec_bf16_gru_dec";
+        if (tr16) { d.tr16 = 1; d.wp = w.dec16_wp; d.prof_name = "k_gru16_bf16_dec"; }
         float* lg_out = (d_logits && wi == nwin - 1) ? d_logits : nullptr;
         if (fold_dense) {
             d.dense_w = w.dense_frag; d.dense_part = dpart;
