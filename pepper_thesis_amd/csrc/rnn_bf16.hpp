@@ -46,7 +46,8 @@ struct pv_rec_desc {
     unsigned char* out_bm;     // optional split8, batch-major [Bp][T * 2 * hidden] (A operand of linear_1)
     int mt;                    // M-tiles of 32 rows per workgroup: 1 or 2
     const char* prof_name;
-    int tr16;                  // 1: GRU on 16-row tiles (k_gru16_bf16; wp / wx from pv_pack_gru16_bf16, Bp a multiple of 16, mt unused)
+    int tr16;                  // 1 or 2: GRU on 16-row tiles, that many per workgroup (k_gru16_bf16; wp / wx from pv_pack_gru16_bf16, Bp a
+                               // multiple of 16, mt unused)
     const unsigned char* dense_w;   // GRU decoder only: fragments of a [5][2 * hidden] dense layer (pv_pack_p2_dense) and ...
     float* dense_part;              // ... its partial logits [T][Bp / 32][2 dirs][4 waves][8][32 rows] (summed by k_p2_combine), or NULL
 };

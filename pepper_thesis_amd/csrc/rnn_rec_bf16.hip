@@ -516,16 +516,17 @@ __global__ __launch_bounds__(NG == 4 ? 512 : 256, 1) void k_rec_bf16(RecArgs a) 
 // D lane -> unit lane & 15, rows 4 (lane >> 4) + register - the quads [m / 4][column][4] the input GEMM writes are one
 // accumulator each.
 constexpr int G16_HS = 128 * 4 + 16, G16_XS = 32 * 2 + 16;
-template <bool ENC>
+// NTL = 16-row tiles per workgroup (1, or 2 from 2049 chunks on: the two tiles of a workgroup share the resident weights and the
+// step's barrier and run one after the other inside the step - still less per 32 rows than the 32-row form's step)
+template <bool ENC, int NTL>
 __global__ __launch_bounds__(256, 1) void k_gru16_bf16(RecArgs a) {
     constexpr int HID = 128, NW = 4, ROWS = 16, HS = G16_HS, XS = G16_XS, NCOL = 6 * HID;
-    __shared__ __attribute__((aligned(16))) unsigned char hbuf[2 * ROWS * HS];
-    __shared__ __attribute__((aligned(16))) unsigned char xbuf[ENC ? 2 * ROWS * XS : 16];
+    __shared__ __attribute__((aligned(16))) unsigned char hbuf_all[NTL * 2 * ROWS * HS];
+    __shared__ __attribute__((aligned(16))) unsigned char xbuf_all[ENC ? NTL * 2 * ROWS * XS : 16];
     const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int xcd = blockIdx.x & 7, dir = xcd & 1;
-    const int tile = (blockIdx.x >> 3) * 4 + (xcd >> 1);
-    if (tile >= a.n_tiles) return;
-    const int64_t b0 = (int64_t)tile * ROWS;
+    const int tile0 = ((blockIdx.x >> 3) * 4 + (xcd >> 1)) * NTL;
+    if (tile0 >= a.n_tiles) return;
     const int lr = lane & 15, q = lane >> 4, T = a.T;
     const unsigned lane16 = (unsigned)lane * 16u;
     // resident weights: slot (ks * 3 + g) * 2 + nt of this wave's stream = [hi 1 KB | lo 1 KB]
@@ -555,79 +556,114 @@ __global__ __launch_bounds__(256, 1) void k_gru16_bf16(RecArgs a) {
 #pragma unroll
         for (int g = 0; g < 3; g++) b_g[g][nt] = ENC ? a.bias[dir * 3 * HID + g * HID + unit] : 0.0f;
     }
-    // state and the h tile
-    float st[2][4];
-    for (int i = tid; i < 2 * ROWS * HS / 16; i += 256) reinterpret_cast<u32x4*>(hbuf)[i] = u32x4{0u, 0u, 0u, 0u};
+    // state and the h tiles (a workgroup's second tile may lie beyond the batch: it then repeats the first, stores nothing)
+    float st[NTL][2][4];
+    int64_t b0[NTL];
+    bool live[NTL];
+#pragma unroll
+    for (int u = 0; u < NTL; u++) {
+        live[u] = tile0 + u < a.n_tiles;
+        b0[u] = (int64_t)(live[u] ? tile0 + u : tile0) * ROWS;
+    }
+    for (int i = tid; i < NTL * 2 * ROWS * HS / 16; i += 256) reinterpret_cast<u32x4*>(hbuf_all)[i] = u32x4{0u, 0u, 0u, 0u};
     if constexpr (ENC)
-        for (int i = tid; i < 2 * ROWS * XS / 16; i += 256) reinterpret_cast<u32x4*>(xbuf)[i] = u32x4{0u, 0u, 0u, 0u};
+        for (int i = tid; i < NTL * 2 * ROWS * XS / 16; i += 256) reinterpret_cast<u32x4*>(xbuf_all)[i] = u32x4{0u, 0u, 0u, 0u};
 #pragma unroll
-    for (int nt = 0; nt < 2; nt++)
+    for (int u = 0; u < NTL; u++)
 #pragma unroll
-        for (int j = 0; j < 4; j++) st[nt][j] = 0.0f;
+        for (int nt = 0; nt < 2; nt++)
+#pragma unroll
+            for (int j = 0; j < 4; j++) st[u][nt][j] = 0.0f;
     __syncthreads();
     unsigned hl[2];   // lane part of an h element's LDS offset: row 4q (+ j), unit of tile nt
 #pragma unroll
     for (int nt = 0; nt < 2; nt++) hl[nt] = (unsigned)(4 * q * HS) + split8_off((unsigned)(32 * wv + 16 * nt + lr));
     if (a.h0) {
 #pragma unroll
-        for (int nt = 0; nt < 2; nt++)
+        for (int u = 0; u < NTL; u++)
 #pragma unroll
-            for (int j = 0; j < 4; j++) {
-                const float h = a.h0[((b0 + 4 * q + j) * 2 + dir) * HID + 32 * wv + 16 * nt + lr];
-                st[nt][j] = h;
-                const __bf16 hi = (__bf16)h;
-                const __bf16 lo = (__bf16)(h - (float)hi);
-                *reinterpret_cast<__bf16*>(hbuf + j * HS + hl[nt]) = hi;
-                *reinterpret_cast<__bf16*>(hbuf + j * HS + hl[nt] + 16) = lo;
-            }
+            for (int nt = 0; nt < 2; nt++)
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    const float h = a.h0[((b0[u] + 4 * q + j) * 2 + dir) * HID + 32 * wv + 16 * nt + lr];
+                    st[u][nt][j] = h;
+                    const __bf16 hi = (__bf16)h;
+                    const __bf16 lo = (__bf16)(h - (float)hi);
+                    unsigned char* hb = hbuf_all + u * 2 * ROWS * HS;
+                    *reinterpret_cast<__bf16*>(hb + j * HS + hl[nt]) = hi;
+                    *reinterpret_cast<__bf16*>(hb + j * HS + hl[nt] + 16) = lo;
+                }
     }
-    // x staging (encoder): thread -> (row tid / 16, feature tid % 16): one byte per step (features beyond xf stay zero)
+    // x staging (encoder): thread -> (row tid / 16, feature tid % 16): one byte per tile and step (features beyond xf stay zero)
     const int xrow = tid >> 4, xf_i = tid & 15;
-    const unsigned char* xsrc = nullptr;
-    unsigned xv = 0u;
+    const unsigned char* xsrc[NTL];
+    unsigned xv[NTL];
     const bool x_on = ENC && xf_i < a.xf;
-    if constexpr (ENC) {
-        int64_t r = b0 + xrow;
-        if (r >= a.B) r = a.B - 1;
-        xsrc = a.x + r * a.x_row_bytes + (int64_t)a.x_t0 * a.xf + xf_i;
+#pragma unroll
+    for (int u = 0; u < NTL; u++) {
+        xv[u] = 0u;
+        xsrc[u] = nullptr;
+        if constexpr (ENC) {
+            int64_t r = b0[u] + xrow;
+            if (r >= a.B) r = a.B - 1;
+            xsrc[u] = a.x + r * a.x_row_bytes + (int64_t)a.x_t0 * a.xf + xf_i;
+        }
     }
-    auto x_load = [&](int t) { if constexpr (ENC) { if (x_on) xv = (unsigned)xsrc[(int64_t)t * a.xf]; } };
+    auto x_load = [&](int t) {
+        if constexpr (ENC) {
+            if (x_on) {
+#pragma unroll
+                for (int u = 0; u < NTL; u++) xv[u] = (unsigned)xsrc[u][(int64_t)t * a.xf];
+            }
+        }
+    };
     auto x_store = [&](int slot) {
         if constexpr (ENC) {
             if (x_on) {
-                const float f = a.x_signed ? (float)(int)(signed char)xv : (float)xv;
-                *reinterpret_cast<__bf16*>(xbuf + (slot * ROWS + xrow) * XS + xf_i * 2) = (__bf16)f;
+#pragma unroll
+                for (int u = 0; u < NTL; u++) {
+                    const float f = a.x_signed ? (float)(int)(signed char)xv[u] : (float)xv[u];
+                    *reinterpret_cast<__bf16*>(xbuf_all + ((u * 2 + slot) * ROWS + xrow) * XS + xf_i * 2) = (__bf16)f;
+                }
             }
         }
     };
     // decoder: the step's input projections (quad row (t * Bp + b0) / 4 + q, column dir * 384 + g * 128 + unit)
-    f32x4 gq[ENC ? 1 : 3][2];
+    f32x4 gq[NTL][ENC ? 1 : 3][2];
     auto g_load = [&](int t) {
         if constexpr (!ENC) {
-            const __amdgpu_buffer_rsrc_t gsr = make_rsrc(a.G + ((size_t)t * a.Bp + b0) * NCOL);
 #pragma unroll
-            for (int g = 0; g < 3; g++)
+            for (int u = 0; u < NTL; u++) {
+                const __amdgpu_buffer_rsrc_t gsr = make_rsrc(a.G + ((size_t)t * a.Bp + b0[u]) * NCOL);
 #pragma unroll
-                for (int nt = 0; nt < 2; nt++)
-                    gq[g][nt] = buf_load4_nt(gsr, (unsigned)((q * NCOL + lr) * 16), (unsigned)((dir * 3 * HID + g * HID + 32 * wv + 16 * nt) * 16));
+                for (int g = 0; g < 3; g++)
+#pragma unroll
+                    for (int nt = 0; nt < 2; nt++)
+                        gq[u][g][nt] = buf_load4_nt(gsr, (unsigned)((q * NCOL + lr) * 16), (unsigned)((dir * 3 * HID + g * HID + 32 * wv + 16 * nt) * 16));
+            }
         }
     };
-    // layer output: the finished h tile (split8 rows, 512 bytes each) as 16-byte copies, two per thread
+    // layer output: the finished h tile (split8 rows, 512 bytes each) as 16-byte copies, two per thread and tile
     const unsigned rowb_tm = 2u * HID * 4u, rowb_bm = (unsigned)T * 2u * HID * 4u;
     const bool want_out = a.out_tm || a.out_bm;
-    auto tile_out = [&](int tt, const unsigned char* tl) {
+    auto tile_out = [&](int tt, int cur_) {
         if (!want_out) return;
 #pragma unroll
-        for (int k = 0; k < 2; k++) {
-            const int c = tid + k * 256, row = c >> 5, col = c & 31;
-            const u32x4 v = *reinterpret_cast<const u32x4*>(tl + row * HS + col * 16);
-            if (a.out_tm) {
-                const __amdgpu_buffer_rsrc_t tmr = make_rsrc(a.out_tm + ((size_t)tt * a.Bp + b0) * rowb_tm);
-                __builtin_amdgcn_raw_buffer_store_b128(v, tmr, (unsigned)(row * (int)rowb_tm + col * 16), (unsigned)(dir * HID * 4), 2);
-            }
-            if (a.out_bm) {
-                const __amdgpu_buffer_rsrc_t bmr = make_rsrc(a.out_bm + (size_t)b0 * rowb_bm);
-                __builtin_amdgcn_raw_buffer_store_b128(v, bmr, (unsigned)row * rowb_bm + (unsigned)(col * 16), (unsigned)((tt * 2 + dir) * HID * 4), 2);
+        for (int u = 0; u < NTL; u++) {
+            if (!live[u]) continue;
+            const unsigned char* tl = hbuf_all + (u * 2 + cur_) * ROWS * HS;
+#pragma unroll
+            for (int k = 0; k < 2; k++) {
+                const int c = tid + k * 256, row = c >> 5, col = c & 31;
+                const u32x4 v = *reinterpret_cast<const u32x4*>(tl + row * HS + col * 16);
+                if (a.out_tm) {
+                    const __amdgpu_buffer_rsrc_t tmr = make_rsrc(a.out_tm + ((size_t)tt * a.Bp + b0[u]) * rowb_tm);
+                    __builtin_amdgcn_raw_buffer_store_b128(v, tmr, (unsigned)(row * (int)rowb_tm + col * 16), (unsigned)(dir * HID * 4), 2);
+                }
+                if (a.out_bm) {
+                    const __amdgpu_buffer_rsrc_t bmr = make_rsrc(a.out_bm + (size_t)b0[u] * rowb_bm);
+                    __builtin_amdgcn_raw_buffer_store_b128(v, bmr, (unsigned)row * rowb_bm + (unsigned)(col * 16), (unsigned)((tt * 2 + dir) * HID * 4), 2);
+                }
             }
         }
     };
@@ -640,76 +676,83 @@ __global__ __launch_bounds__(256, 1) void k_gru16_bf16(RecArgs a) {
         const int t = dir ? (T - 1 - s) : s;
         const int tn = dir ? (T - 2 - s) : (s + 1);
         if (s + 1 < T) x_load(tn);
-        if (s > 0) tile_out(dir ? t + 1 : t - 1, hbuf + cur * ROWS * HS);
-        f32x4 ar[2], az[2], anx[2], anh[2];
+        if (s > 0) tile_out(dir ? t + 1 : t - 1, cur);
 #pragma unroll
-        for (int nt = 0; nt < 2; nt++) {
-#pragma unroll
-            for (int j = 0; j < 4; j++) {
-                ar[nt][j] = ENC ? b_g[0][nt] : gq[0][nt][j];
-                az[nt][j] = ENC ? b_g[1][nt] : gq[1][nt][j];
-                anx[nt][j] = ENC ? b_g[2][nt] : gq[ENC ? 0 : 2][nt][j];
-                anh[nt][j] = b_hn[nt];
-            }
-        }
-        if constexpr (ENC) {   // byte input: exact in bf16, two terms
-            const bf16x8 ax = *reinterpret_cast<const bf16x8*>(xbuf + ((s & 1) * ROWS + lr) * XS + q * 16);
+        for (int u = 0; u < NTL; u++) {
+            unsigned char* hb = hbuf_all + u * 2 * ROWS * HS;
+            f32x4 ar[2], az[2], anx[2], anh[2];
 #pragma unroll
             for (int nt = 0; nt < 2; nt++) {
-                ar[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ax, xw[0 * 2 + nt][0], ar[nt], 0, 0, 0);
-                ar[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ax, xw[0 * 2 + nt][1], ar[nt], 0, 0, 0);
-                az[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ax, xw[1 * 2 + nt][0], az[nt], 0, 0, 0);
-                az[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ax, xw[1 * 2 + nt][1], az[nt], 0, 0, 0);
-                anx[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ax, xw[2 * 2 + nt][0], anx[nt], 0, 0, 0);
-                anx[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ax, xw[2 * 2 + nt][1], anx[nt], 0, 0, 0);
-            }
-        }
-        {   // h_{t-1} . W_hh^T, three terms
-            const unsigned char* At = hbuf + cur * ROWS * HS + lr * HS + q * 32;
 #pragma unroll
-            for (int ks = 0; ks < 4; ks++) {
-                const bf16x8 ah = *reinterpret_cast<const bf16x8*>(At + ks * 128), al = *reinterpret_cast<const bf16x8*>(At + ks * 128 + 16);
-#pragma unroll
-                for (int nt = 0; nt < 2; nt++) {
-                    const int s0 = (ks * 3 + 0) * 2 + nt, s1 = (ks * 3 + 1) * 2 + nt, s2 = (ks * 3 + 2) * 2 + nt;
-                    ar[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, wres[s0][0], ar[nt], 0, 0, 0);
-                    ar[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, wres[s0][1], ar[nt], 0, 0, 0);
-                    ar[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, wres[s0][0], ar[nt], 0, 0, 0);
-                    az[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, wres[s1][0], az[nt], 0, 0, 0);
-                    az[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, wres[s1][1], az[nt], 0, 0, 0);
-                    az[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, wres[s1][0], az[nt], 0, 0, 0);
-                    anh[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, wres[s2][0], anh[nt], 0, 0, 0);
-                    anh[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, wres[s2][1], anh[nt], 0, 0, 0);
-                    anh[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, wres[s2][0], anh[nt], 0, 0, 0);
+                for (int j = 0; j < 4; j++) {
+                    ar[nt][j] = ENC ? b_g[0][nt] : gq[u][0][nt][j];
+                    az[nt][j] = ENC ? b_g[1][nt] : gq[u][1][nt][j];
+                    anx[nt][j] = ENC ? b_g[2][nt] : gq[u][ENC ? 0 : 2][nt][j];
+                    anh[nt][j] = b_hn[nt];
                 }
             }
-        }
-        if (s + 1 < T) g_load(tn);   // (behind the last use of this step's projections: they travel during the cell update and the barrier)
-        unsigned char* hn = hbuf + (cur ^ 1) * ROWS * HS;
+            if constexpr (ENC) {   // byte input: exact in bf16, two terms
+                const bf16x8 ax = *reinterpret_cast<const bf16x8*>(xbuf_all + ((u * 2 + (s & 1)) * ROWS + lr) * XS + q * 16);
 #pragma unroll
-        for (int nt = 0; nt < 2; nt++)
-#pragma unroll
-            for (int j = 0; j < 4; j++) {   // PyTorch GRU: n = tanh(W_in x + b_in + r * (W_hn h + b_hn)), h' = (1 - z) n + z h
-                const float r = sigmoidf_(ar[nt][j]);
-                const float z = sigmoidf_(az[nt][j]);
-                const float n = tanhf_(anx[nt][j] + r * anh[nt][j]);
-                const float h = (1.0f - z) * n + z * st[nt][j];
-                st[nt][j] = h;
-                const __bf16 hi = (__bf16)h;
-                const __bf16 lo = (__bf16)(h - (float)hi);
-                *reinterpret_cast<__bf16*>(hn + j * HS + hl[nt]) = hi;
-                *reinterpret_cast<__bf16*>(hn + j * HS + hl[nt] + 16) = lo;
+                for (int nt = 0; nt < 2; nt++) {
+                    ar[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ax, xw[0 * 2 + nt][0], ar[nt], 0, 0, 0);
+                    ar[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ax, xw[0 * 2 + nt][1], ar[nt], 0, 0, 0);
+                    az[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ax, xw[1 * 2 + nt][0], az[nt], 0, 0, 0);
+                    az[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ax, xw[1 * 2 + nt][1], az[nt], 0, 0, 0);
+                    anx[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ax, xw[2 * 2 + nt][0], anx[nt], 0, 0, 0);
+                    anx[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ax, xw[2 * 2 + nt][1], anx[nt], 0, 0, 0);
+                }
             }
-        if (s + 1 < T) x_store((s + 1) & 1);
+            {   // h_{t-1} . W_hh^T, three terms
+                const unsigned char* At = hb + cur * ROWS * HS + lr * HS + q * 32;
+#pragma unroll
+                for (int ks = 0; ks < 4; ks++) {
+                    const bf16x8 ah = *reinterpret_cast<const bf16x8*>(At + ks * 128), al = *reinterpret_cast<const bf16x8*>(At + ks * 128 + 16);
+#pragma unroll
+                    for (int nt = 0; nt < 2; nt++) {
+                        const int s0 = (ks * 3 + 0) * 2 + nt, s1 = (ks * 3 + 1) * 2 + nt, s2 = (ks * 3 + 2) * 2 + nt;
+                        ar[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, wres[s0][0], ar[nt], 0, 0, 0);
+                        ar[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, wres[s0][1], ar[nt], 0, 0, 0);
+                        ar[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, wres[s0][0], ar[nt], 0, 0, 0);
+                        az[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, wres[s1][0], az[nt], 0, 0, 0);
+                        az[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, wres[s1][1], az[nt], 0, 0, 0);
+                        az[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, wres[s1][0], az[nt], 0, 0, 0);
+                        anh[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, wres[s2][0], anh[nt], 0, 0, 0);
+                        anh[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, wres[s2][1], anh[nt], 0, 0, 0);
+                        anh[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, wres[s2][0], anh[nt], 0, 0, 0);
+                    }
+                }
+            }
+            unsigned char* hn = hb + (cur ^ 1) * ROWS * HS;
+#pragma unroll
+            for (int nt = 0; nt < 2; nt++)
+#pragma unroll
+                for (int j = 0; j < 4; j++) {   // PyTorch GRU: n = tanh(W_in x + b_in + r * (W_hn h + b_hn)), h' = (1 - z) n + z h
+                    const float r = sigmoidf_(ar[nt][j]);
+                    const float z = sigmoidf_(az[nt][j]);
+                    const float n = tanhf_(anx[nt][j] + r * anh[nt][j]);
+                    const float h = (1.0f - z) * n + z * st[u][nt][j];
+                    st[u][nt][j] = h;
+                    const __bf16 hi = (__bf16)h;
+                    const __bf16 lo = (__bf16)(h - (float)hi);
+                    *reinterpret_cast<__bf16*>(hn + j * HS + hl[nt]) = hi;
+                    *reinterpret_cast<__bf16*>(hn + j * HS + hl[nt] + 16) = lo;
+                }
+        }
+        if (s + 1 < T) { g_load(tn); x_store((s + 1) & 1); }   // (the next step's projections travel during the barrier)
         cur ^= 1;
         lds_barrier();
     }
-    tile_out(dir ? 0 : T - 1, hbuf + cur * ROWS * HS);
+    tile_out(dir ? 0 : T - 1, cur);
     if (a.h_out) {
 #pragma unroll
-        for (int nt = 0; nt < 2; nt++)
+        for (int u = 0; u < NTL; u++) {
+            if (!live[u]) continue;
 #pragma unroll
-            for (int j = 0; j < 4; j++) a.h_out[((b0 + 4 * q + j) * 2 + dir) * HID + 32 * wv + 16 * nt + lr] = st[nt][j];
+            for (int nt = 0; nt < 2; nt++)
+#pragma unroll
+                for (int j = 0; j < 4; j++) a.h_out[((b0[u] + 4 * q + j) * 2 + dir) * HID + 32 * wv + 16 * nt + lr] = st[u][nt][j];
+        }
     }
 }
 
@@ -1000,12 +1043,14 @@ int pv_rec_bf16_async(pv_ctx* ctx, const pv_rec_desc& d, hipStream_t st) {
     a.dw = d.dense_w; a.dpart = d.dense_part;
     PV_CHECK(!d.dense_part || (d.cell == 3 && !d.enc && d.dense_w), PV_ERR_INVALID, "the dense layer folds into the GRU decoder only");
     if (d.tr16) {   // GRU on 16-row tiles (its own fragment streams: pv_pack_gru16_bf16)
-        PV_CHECK(d.cell == 3 && d.Bp % 16 == 0 && !d.dense_part && !d.out_f32, PV_ERR_INVALID, "bad 16-row GRU launch");
+        PV_CHECK(d.cell == 3 && (d.tr16 == 1 || d.tr16 == 2) && d.Bp % 16 == 0 && !d.dense_part && !d.out_f32, PV_ERR_INVALID, "bad 16-row GRU launch");
         a.n_tiles = (int)(d.Bp / 16);
-        const unsigned grid16 = (unsigned)(((a.n_tiles + 3) / 4) * 8);
+        const int ntl = d.tr16;   // 16-row tiles per workgroup
+        const int n_wg = (a.n_tiles + ntl - 1) / ntl;
+        const unsigned grid16 = (unsigned)(((n_wg + 3) / 4) * 8);
         pv_prof_scope ps16(ctx, d.prof_name, st);
-        if (d.enc) k_gru16_bf16<true><<<grid16, 256, 0, st>>>(a);
-        else k_gru16_bf16<false><<<grid16, 256, 0, st>>>(a);
+        if (ntl == 2) { if (d.enc) k_gru16_bf16<true, 2><<<grid16, 256, 0, st>>>(a); else k_gru16_bf16<false, 2><<<grid16, 256, 0, st>>>(a); }
+        else { if (d.enc) k_gru16_bf16<true, 1><<<grid16, 256, 0, st>>>(a); else k_gru16_bf16<false, 1><<<grid16, 256, 0, st>>>(a); }
         PV_HIP(hipGetLastError());
         return PV_OK;
     }
@@ -1168,7 +1213,10 @@ int pv_p2_bf16_forward(pv_ctx* ctx, const pv_p2_bf16_weights& w, const uint8_t* 
     // rounds of the chip; below that 32-row tiles keep more CUs busy
     const int mt = ((B + 31) / 32) * 2 > 2 * (int64_t)ctx->num_cu ? 2 : 1;
     // 16-row tiles (k_gru16_bf16: half the MFMA and cell-update time per step) while every (tile, direction) workgroup has a CU
-    const bool tr16 = ((B + 15) / 16) * 2 <= (int64_t)ctx->num_cu;
+    // of its own (up to 2048 chunks on 256 CUs: 13.2 ms against 17.9 at 2048). Beyond that, two 16-row tiles per workgroup
+    // (k_gru16_bf16<.., 2>, one after the other inside the step) measured no better than the 32-row form - 6.0 / 6.3 ms against
+    // 6.0 / 6.8 per 19 windows at 2121 chunks - and cannot fold dense1 in: not used.
+    const int tr16 = ((B + 15) / 16) * 2 <= (int64_t)ctx->num_cu ? 1 : 0;
     const int rows = tr16 ? 16 : 32 * mt;
     const int64_t Bp = (B + rows - 1) / rows * rows, M = (int64_t)P2_WIN * Bp;
     float *state = nullptr, *G = nullptr;
@@ -1181,7 +1229,7 @@ int pv_p2_bf16_forward(pv_ctx* ctx, const pv_p2_bf16_weights& w, const uint8_t* 
     // per window at 4096 chunks, summed by k_p2_combine) instead of the decoder's split8 output (420 MB) and k_p2_dense's pass
     // over it: 24.9 -> 23.9 ms at 4096 chunks. It lengthens every decoder step by ~5 %, which is all a small batch sees (64
     // chunks: 12.3 -> 12.6 ms), so those keep the separate pass.
-    const bool fold_dense = B >= 2048;
+    const bool fold_dense = B >= 2048 && !tr16;
     float* dpart = nullptr;
     if (fold_dense) {
         if ((rc = pv_get(ctx, "p2b.dpart", (size_t)P2_WIN * (Bp / 32) * 8 * 256, &dpart))) return rc;
@@ -1196,7 +1244,7 @@ int pv_p2_bf16_forward(pv_ctx* ctx, const pv_p2_bf16_weights& w, const uint8_t* 
         e.cell = 3; e.enc = 1; e.wp = w.enc_wp; e.wx = w.enc_wx; e.bias = w.enc_bias; e.bias_hn = w.enc_bias_hn;
         e.x = d_images; e.x_row_bytes = (int64_t)seq * P2_F; e.x_t0 = ws; e.xf = P2_F; e.x_signed = 0;
         e.B = B; e.Bp = Bp; e.T = P2_WIN; e.h0 = state; e.h_out = state; e.out_tm = enc_s; e.mt = mt; e.prof_name = "k_rec_bf16_gru_enc";
-        if (tr16) { e.tr16 = 1; e.wp = w.enc16_wp; e.wx = w.enc16_wx; e.prof_name = "k_gru16_bf16_enc"; }
+        if (tr16) { e.tr16 = tr16; e.wp = w.enc16_wp; e.wx = w.enc16_wx; e.prof_name = "k_gru16_bf16_enc"; }
         if ((rc = pv_rec_bf16_async(ctx, e, st))) return rc;
         pv_gemm_desc g = {};
         g.A = enc_s; g.W = w.dec_wih_s; g.bias = w.dec_bias_cat; g.C = G; g.M = M; g.N = 6 * P2_H; g.K = 2 * P2_H; g.splits = 1; g.quads = 1;
@@ -1205,7 +1253,7 @@ int pv_p2_bf16_forward(pv_ctx* ctx, const pv_p2_bf16_weights& w, const uint8_t* 
         pv_rec_desc d = {};
         d.cell = 3; d.enc = 0; d.G = G; d.wp = w.dec_wp; d.bias_hn = w.dec_bias_hn; d.B = B; d.Bp = Bp; d.T = P2_WIN;
         d.h0 = state; d.h_out = state; d.mt = mt; d.prof_name = "k_rec_bf16_gru_dec";
-        if (tr16) { d.tr16 = 1; d.wp = w.dec16_wp; d.prof_name = "k_gru16_bf16_dec"; }
+        if (tr16) { d.tr16 = tr16; d.wp = w.dec16_wp; d.prof_name = "k_gru16_bf16_dec"; }
         float* lg_out = (d_logits && wi == nwin - 1) ? d_logits : nullptr;
         if (fold_dense) {
             d.dense_w = w.dense_frag; d.dense_part = dpart;
