@@ -703,29 +703,34 @@ __global__ __launch_bounds__(256, 1) void k_gru16_bf16(RecArgs a) {
                     anx[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ax, xw[2 * 2 + nt][1], anx[nt], 0, 0, 0);
                 }
             }
-            {   // h_{t-1} . W_hh^T, three terms
+            // h_{t-1} . W_hh^T, three terms; unit tile by unit tile, so that the cell update of the first tile (vector unit) has
+            // the second tile's MFMAs (matrix pipe) to run under
+            bf16x8 ah[4], al[4];
+            {
                 const unsigned char* At = hb + cur * ROWS * HS + lr * HS + q * 32;
 #pragma unroll
                 for (int ks = 0; ks < 4; ks++) {
-                    const bf16x8 ah = *reinterpret_cast<const bf16x8*>(At + ks * 128), al = *reinterpret_cast<const bf16x8*>(At + ks * 128 + 16);
-#pragma unroll
-                    for (int nt = 0; nt < 2; nt++) {
-                        const int s0 = (ks * 3 + 0) * 2 + nt, s1 = (ks * 3 + 1) * 2 + nt, s2 = (ks * 3 + 2) * 2 + nt;
-                        ar[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, wres[s0][0], ar[nt], 0, 0, 0);
-                        ar[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, wres[s0][1], ar[nt], 0, 0, 0);
-                        ar[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, wres[s0][0], ar[nt], 0, 0, 0);
-                        az[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, wres[s1][0], az[nt], 0, 0, 0);
-                        az[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, wres[s1][1], az[nt], 0, 0, 0);
-                        az[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, wres[s1][0], az[nt], 0, 0, 0);
-                        anh[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, wres[s2][0], anh[nt], 0, 0, 0);
-                        anh[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, wres[s2][1], anh[nt], 0, 0, 0);
-                        anh[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, wres[s2][0], anh[nt], 0, 0, 0);
-                    }
+                    ah[ks] = *reinterpret_cast<const bf16x8*>(At + ks * 128);
+                    al[ks] = *reinterpret_cast<const bf16x8*>(At + ks * 128 + 16);
                 }
             }
             unsigned char* hn = hb + (cur ^ 1) * ROWS * HS;
+            auto h_part = [&](int nt) {
 #pragma unroll
-            for (int nt = 0; nt < 2; nt++)
+                for (int ks = 0; ks < 4; ks++) {
+                    const int s0 = (ks * 3 + 0) * 2 + nt, s1 = (ks * 3 + 1) * 2 + nt, s2 = (ks * 3 + 2) * 2 + nt;
+                    ar[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[ks], wres[s0][0], ar[nt], 0, 0, 0);
+                    az[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[ks], wres[s1][0], az[nt], 0, 0, 0);
+                    anh[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[ks], wres[s2][0], anh[nt], 0, 0, 0);
+                    ar[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[ks], wres[s0][1], ar[nt], 0, 0, 0);
+                    az[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[ks], wres[s1][1], az[nt], 0, 0, 0);
+                    anh[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[ks], wres[s2][1], anh[nt], 0, 0, 0);
+                    ar[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[ks], wres[s0][0], ar[nt], 0, 0, 0);
+                    az[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[ks], wres[s1][0], az[nt], 0, 0, 0);
+                    anh[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[ks], wres[s2][0], anh[nt], 0, 0, 0);
+                }
+            };
+            auto cell = [&](int nt) {
 #pragma unroll
                 for (int j = 0; j < 4; j++) {   // PyTorch GRU: n = tanh(W_in x + b_in + r * (W_hn h + b_hn)), h' = (1 - z) n + z h
                     const float r = sigmoidf_(ar[nt][j]);
@@ -738,8 +743,16 @@ __global__ __launch_bounds__(256, 1) void k_gru16_bf16(RecArgs a) {
                     *reinterpret_cast<__bf16*>(hn + j * HS + hl[nt]) = hi;
                     *reinterpret_cast<__bf16*>(hn + j * HS + hl[nt] + 16) = lo;
                 }
+            };
+            h_part(0);
+            h_part(1);
+            // the next step's projections are requested behind the last use of this step's (every tile's were copied into its
+            // accumulators at the top of its pass): they travel during the cell updates and the barrier
+            if (u == NTL - 1 && s + 1 < T) g_load(tn);
+            cell(0);
+            cell(1);
         }
-        if (s + 1 < T) { g_load(tn); x_store((s + 1) & 1); }   // (the next step's projections travel during the barrier)
+        if (s + 1 < T) x_store((s + 1) & 1);
         cur ^= 1;
         lds_barrier();
     }
