@@ -347,6 +347,8 @@ int pv_rnn_exchange_timeouts(pv_ctx* ctx);
  *   tail_rows     [PV_TAIL_ROWS]    0 auto / 16 / 32;   head_splits [PV_HEAD_SPLITS] 0 auto / 1 / 3 / 11 / 33;   head_map [PV_HEAD_MAP] 1 / 0
  *   gru_rows      [PV_GRU_ROWS]     0 auto / 16 / 32
  *   gru_split     [PV_GRU_SPLIT]    1 / 0: allow the split GRU forms at all;   gru_usplit [PV_GRU_USPLIT] 1 / 0: the unit-split one
+ *   p1_bf16_min_batch                 P1 in the PV_DTYPE_BF16_INPUT_GEMM mode: calls with fewer windows than this (default 513) run the
+ *                                   fp32 kernels, which are faster there; 0 = always the bf16x3 kernels
  *   shared_device [PV_SHARED_DEVICE] 0 / 1: other streams or processes keep this GPU busy (e.g. several un-fused callers per
  *                                   GPU, RunInferenceArguments.py:67-74): never choose a form that needs co-resident workgroups
  *   exchange_spin_log2              2..22 (default 18): bounded polls give up after 2^n tries

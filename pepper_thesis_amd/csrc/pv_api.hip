@@ -53,6 +53,7 @@ const opt_desc OPTS[] = {
     {"shared_device", "PV_SHARED_DEVICE", &pv_opts::shared_device, 0, 1},
     {"exchange_spin_log2", nullptr, &pv_opts::exchange_spin_log2, 2, 22},
     {"debug_drop_part", nullptr, &pv_opts::debug_drop_part, -1, 3},
+    {"p1_bf16_min_batch", nullptr, &pv_opts::p1_bf16_min_batch, 0, 1 << 20},
 };
 bool opt_value_ok(const opt_desc& d, int v) {
     if (v < d.lo || v > d.hi) return false;

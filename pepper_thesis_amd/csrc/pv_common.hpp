@@ -108,6 +108,8 @@ struct pv_opts {
     int shared_device = 0;       // 1: other work shares this GPU: no form that needs all its workgroups resident at once
     int exchange_spin_log2 = 18; // bounded polls of the split forms give up after 2^n tries (layer hand-offs: 2^(n+8))
     int debug_drop_part = -1;    // diagnostic: this part of a unit-split launch never runs (forces exchange time-outs)
+    int p1_bf16_min_batch = 513; // PV_DTYPE_BF16_INPUT_GEMM, P1: calls with fewer windows run the fp32 kernels (faster there: 0.85 ms against
+                                 // 1.0 for 512 windows; results then are the fp32 mode's); 0: always the bf16x3 kernels
 };
 
 struct pv_ctx {

@@ -1317,7 +1317,7 @@ static int p1_forward_launch(pv_ctx* ctx, const int8_t* d_images, int64_t B, flo
     const int f = tr == 16 ? 1 : 0;
     const int n_lt = n_tiles * (ROWS / tr);             // whole 32-row tiles are covered in either form
     const unsigned lstm_grid = (unsigned)(((n_lt + 3) / 4) * 8);
-    if (m->dtype == PV_DTYPE_BF16_INPUT_GEMM) {
+    if (m->dtype == PV_DTYPE_BF16_INPUT_GEMM && B >= ctx->opt.p1_bf16_min_batch) {   // (a small call is faster on the fp32 kernels below)
         // every matrix product on the bf16 MFMA: encoder layer (x-part in the step) -> decoder input projection as ONE GEMM
         // -> decoder layer on the projections -> linear_1 as a split-K GEMM -> fp32 tail. 64-row tiles (one weight fetch of
         // the recurrent stream feeds twice the rows) once 32-row (tile, direction) workgroups would not fit the chip at once.

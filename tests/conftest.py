@@ -45,7 +45,7 @@ def hip_ctx():
 
 
 OPTION_DEFAULTS = {"lstm_split": 1, "lstm_rows": 0, "tail_rows": 0, "head_splits": 0, "head_map": 1, "gru_rows": 0, "gru_split": 1,
-                   "gru_usplit": 1, "shared_device": 0, "exchange_spin_log2": 18, "debug_drop_part": -1}
+                   "gru_usplit": 1, "shared_device": 0, "exchange_spin_log2": 18, "debug_drop_part": -1, "p1_bf16_min_batch": 513}
 
 
 @pytest.fixture

@@ -227,6 +227,7 @@ def test_p1_bf16_input_gemm_mode_meets_the_bar(gold, tag):
     ctx = runtime.Context(0)
     w = synth.make_weights_p1(int(gold[tag + "/seed"][0]), float(gold[tag + "/gain"][0]))
     ctx.load_p1(w, _ffi.PV_DTYPE_BF16_INPUT_GEMM)
+    ctx.set_option("p1_bf16_min_batch", 0)   # (the bf16x3 kernels whatever the batch size)
     probs = ctx.forward_p1(gold[tag + "/images"])
     np.testing.assert_allclose(probs, gold[tag + "/probs"], atol=TOL_PROBS, rtol=0)
     # ragged batch + decoder tap against the float64 oracle
@@ -281,6 +282,7 @@ def test_p1_bf16_mode_full_batch_properties(B):
     c32.close()
     ctx = runtime.Context(0)
     ctx.load_p1(w, _ffi.PV_DTYPE_BF16_INPUT_GEMM)
+    ctx.set_option("p1_bf16_min_batch", 0)   # (the bf16x3 kernels whatever the batch size)
     probs = ctx.forward_p1(x)
     assert np.isfinite(probs).all() and np.abs(probs.sum(1) - 1).max() < 1e-5
     np.testing.assert_allclose(probs, p32, atol=TOL_PROBS, rtol=0)
@@ -301,6 +303,7 @@ def test_p1_bf16_mode_is_repeatable():
     from pepper_thesis_amd import _ffi, runtime
     ctx = runtime.Context(0)
     ctx.load_p1(synth.make_weights_p1(6, 2.0), _ffi.PV_DTYPE_BF16_INPUT_GEMM)
+    ctx.set_option("p1_bf16_min_batch", 0)   # (the bf16x3 kernels whatever the batch size)
     x = synth.synth_windows(6100, 8192)
     first = ctx.forward_p1(x)
     for _ in range(9):
@@ -337,6 +340,7 @@ def test_p1_bf16_mode_chunks_large_batches():
     from pepper_thesis_amd import _ffi, runtime
     ctx = runtime.Context(0)
     ctx.load_p1(synth.make_weights_p1(5, 2.0), _ffi.PV_DTYPE_BF16_INPUT_GEMM)
+    ctx.set_option("p1_bf16_min_batch", 0)   # (the bf16x3 kernels whatever the batch size)
     x = synth.synth_windows(99, 16384 + 100)
     whole = ctx.forward_p1(x)
     parts = np.concatenate([ctx.forward_p1(x[:16384]), ctx.forward_p1(x[16384:])])
@@ -512,6 +516,7 @@ def test_p1_bf16_mode_equals_fp32_mode_on_every_window(B):
     c32.close()
     ctx = runtime.Context(0)
     ctx.load_p1(w, _ffi.PV_DTYPE_BF16_INPUT_GEMM)
+    ctx.set_option("p1_bf16_min_batch", 0)   # (the bf16x3 kernels whatever the batch size)
     probs = ctx.forward_p1(x)
     np.testing.assert_allclose(probs, p32, atol=TOL_PROBS, rtol=0)
     sel = np.r_[0:8, B - 8:B]
@@ -569,4 +574,29 @@ def test_p2_bf16_mode_vs_fp32_mode_and_oracle(B):
     np.testing.assert_allclose(h, h32, atol=1e-4, rtol=0)
     l2, a2 = ctx.forward_p2(y, want_acc=True)
     assert np.array_equal(l2, labels) and np.array_equal(a2.view(np.uint32), acc.view(np.uint32))
+    ctx.close()
+
+
+def test_p1_bf16_mode_runs_small_calls_on_the_fp32_kernels():
+    """option p1_bf16_min_batch (default 513): in the bf16x3 mode a call with fewer windows runs the fp32 kernels, which are
+    faster there - bit for bit the fp32 mode's answer; at the limit and above, and with the option at 0, the bf16x3 kernels"""
+    from pepper_thesis_amd import _ffi, runtime
+    w = synth.make_weights_p1(9, 2.0)
+    x = synth.synth_windows(123, 600)
+    c32 = runtime.Context(0)
+    c32.load_p1(w)
+    p32 = c32.forward_p1(x)
+    p32_small = c32.forward_p1(x[:100])
+    c32.close()
+    ctx = runtime.Context(0)
+    ctx.load_p1(w, _ffi.PV_DTYPE_BF16_INPUT_GEMM)
+    assert ctx.get_option("p1_bf16_min_batch") == 513
+    assert np.array_equal(ctx.forward_p1(x[:100]).view(np.uint32), p32_small.view(np.uint32))
+    big = ctx.forward_p1(x)
+    assert not np.array_equal(big.view(np.uint32), p32.view(np.uint32))
+    np.testing.assert_allclose(big, p32, atol=TOL_PROBS, rtol=0)
+    ctx.set_option("p1_bf16_min_batch", 0)
+    small = ctx.forward_p1(x[:100])
+    assert not np.array_equal(small.view(np.uint32), p32_small.view(np.uint32))
+    np.testing.assert_allclose(small, p32_small, atol=TOL_PROBS, rtol=0)
     ctx.close()

@@ -7,6 +7,7 @@ from pepper_thesis_amd import _ffi, runtime, synth
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 8192
 ctx = runtime.Context(0)
 ctx.load_p1(synth.make_weights_p1(1234), _ffi.PV_DTYPE_BF16_INPUT_GEMM)
+ctx.set_option("p1_bf16_min_batch", 0)   # (the bf16x3 kernels at any size: this tool reports their times)
 x = torch.from_numpy(synth.synth_windows(3, B)).to("cuda:0")
 probs = torch.zeros((B, 3), dtype=torch.float32, device="cuda:0")
 for _ in range(3):

@@ -15,7 +15,7 @@ w = synth.make_weights_p1(5, 2.0)
 for B in (64, 8192):
     x = synth.synth_windows(10 + B, B)
     c32 = runtime.Context(0); c32.load_p1(w); p32 = c32.forward_p1(x)
-    cb = runtime.Context(0); cb.load_p1(w, _ffi.PV_DTYPE_BF16_INPUT_GEMM)
+    cb = runtime.Context(0); cb.load_p1(w, _ffi.PV_DTYPE_BF16_INPUT_GEMM); cb.set_option("p1_bf16_min_batch", 0)
     pb, enc, dec = cb.forward_p1(x, taps=True)
     rp, renc, rdec, _ = rnn_oracle.p1_forward(w, x[:8], np.float64, taps=True)
     print("P1 B=%d bf16 vs fp32 max err %.3g; vs f64 probs %.3g enc %.3g dec %.3g" % (B, np.abs(pb - p32).max(), np.abs(pb[:8] - rp).max(), np.abs(enc[:8] - renc).max(), np.abs(dec[:8] - rdec).max()), flush=True)

@@ -8,7 +8,7 @@ from pepper_thesis_amd import runtime, synth, _ffi
 t0 = time.time()
 w = synth.make_weights_p1(5, 2.0)
 c32 = runtime.Context(0); c32.load_p1(w)
-cb = runtime.Context(0); cb.load_p1(w, _ffi.PV_DTYPE_BF16_INPUT_GEMM)
+cb = runtime.Context(0); cb.load_p1(w, _ffi.PV_DTYPE_BF16_INPUT_GEMM); cb.set_option("p1_bf16_min_batch", 0)
 worst = 0.0
 sizes = [1, 31, 32, 33, 63, 64, 65, 255, 256, 257, 511, 513, 1000, 2047, 2049, 4031, 4032, 4033, 4095, 4096, 4097, 4159, 4160, 4161, 6000, 8191, 8193]
 xall = synth.synth_windows(77, max(sizes))
