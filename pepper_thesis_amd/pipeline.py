@@ -125,6 +125,11 @@ def call_variant_fused(ctx, state_dict: dict, bam_path: str, fasta_path: str, pr
     n_windows = 0
     cap, scap = 0, 0
     dout = probs = None
+    # the writer thread runs Python (record selection, HDF5 bookkeeping) beside this one, which feeds the GPU between two ctypes
+    # calls: with the interpreter's default 5 ms switch interval a launch could wait that long for the GIL
+    import sys
+    old_switch = sys.getswitchinterval()
+    sys.setswitchinterval(2e-4)
     try:
         for parts, names in batches:
             if werr:
@@ -177,6 +182,7 @@ def call_variant_fused(ctx, state_dict: dict, bam_path: str, fasta_path: str, pr
         batches.close()   # (stops the readers if the loop was left early)
         q.put(None)
         writer.join()
+        sys.setswitchinterval(old_switch)
     if werr:
         raise werr[0]
     T["wall_s"] = time.perf_counter() - t_start
