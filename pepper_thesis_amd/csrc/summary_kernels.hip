@@ -5,9 +5,11 @@
 // regions per call. It is an HBM-bound integer pipeline; nothing here is GEMM-shaped.
 //
 // Data layout in HBM (column = one reference position; global column id = ref_off[g] + i):
-//   cnt[NCNT][n_cols] int16 (cnt_t: a count is bounded by the reads of its region, which k_init holds to <= 32767 - the
-//   reference's caller keeps at most MAX_READS_IN_REGION = 5000, pepper_variant/modules/python/Options.py:98), PLANE-MAJOR, so that the 64 lanes of a wave that walk 64 consecutive
-//   read bases touch 64 consecutive ints of one plane (coalesced atomics / loads):
+//   cnt[n_cols][CNT_STRIDE] int16, COLUMN-MAJOR since round 3 (the 21 counters of a column are 48 contiguous bytes: only the
+//   columns something reads - sites and the windows around them, ~20 % - are written at all, by one thread each in three 16-byte
+//   stores, and a window's 33 columns are one 1.6 KB run; they were [NCNT][n_cols] planes, every column of every plane written)
+//   (cnt_t: a count is bounded by the reads of its region, which k_init holds to <= 32767 - the
+//   reference's caller keeps at most MAX_READS_IN_REGION = 5000, pepper_variant/modules/python/Options.py:98); counter index inside a column:
 //     0 coverage  1 snp_count  2 insert_count  3 delete_count  4 rare-event count
 //     5 + 8*strand + {0 REF, 1 A, 2 C, 3 G, 4 T, 5 I, 6 D, 7 *}   (the 16 accumulated planes of the
 //     reference's 26; planes 0-3,5-7,16-18 are constants or overlays and are never stored)
@@ -35,7 +37,10 @@
 
 namespace {
 
-constexpr int NCNT = 21;
+constexpr int NCNT = 21;   // counters of a column
+typedef uint32_t cnt_u32x4 __attribute__((ext_vector_type(4)));
+constexpr int CNT_STRIDE = 24, CNT_STRIDE_HP = 40;   // counters of a column, padded to whole 16-byte granules (48 / 80 bytes)
+static_assert(NCNT <= CNT_STRIDE, "the 21 counters of the 26-plane form fit its stride");
 typedef int16_t cnt_t;               // element of the global counter planes (they were int32: half the flush and gather bytes)
 constexpr int MAX_REGION_READS = 32767;
 constexpr int C_COV = 0, C_SNP = 1, C_INS = 2, C_DEL = 3, C_RARE = 4, C_PLANE = 5;
@@ -43,6 +48,7 @@ constexpr int C_COV = 0, C_SNP = 1, C_INS = 2, C_DEL = 3, C_RARE = 4, C_PLANE = 
 // set 2 fwd, set 2 rev) x {REF count, A, C, G, T, I, D, *} holding the FINAL signed plane values (window plane
 // 4 + 11*group for the REF count, 8 + 11*group + k for the symbols)
 constexpr int NCNT_HP = 36, HC_PLANE = 4;
+static_assert(NCNT_HP <= CNT_STRIDE_HP, "the 36 counters of the haplotag form fit its stride");
 constexpr int32_t OP_INACTIVE = 0x7fffffff;
 constexpr int UMAX = 1024;  // distinct alleles per site held in LDS
 constexpr int UM_SMALL = 96; // table of the k_site_alleles instantiation for sites with few events
@@ -281,7 +287,7 @@ __global__ __launch_bounds__(256) void k_cigar_scan(SumArgs a) {
             a.op_ref[c] = active ? (int32_t)my_ref : OP_INACTIVE;
             a.op_rd[c] = (int32_t)my_rd;
             if (a.polish) a.op_read[c] = (int32_t)r;   // only k_polish_insert walks op -> read
-            a.op_flag[c] = 0;
+            if (a.polish) a.op_flag[c] = 0;   // (the image builders no longer keep a per-op flag: k_collect repeats the test)
         }
         ref_rel += last_lane(ir);
         rd += last_lane(iq);
@@ -522,6 +528,19 @@ __device__ __forceinline__ uint8_t site_flag(const SumArgs& a, const SiteRegion&
     return 0;
 }
 
+// Does the insert of `len` bases whose anchor base is bases[ins_start] count (region_summary.cpp:431-490 /
+// region_summary_hp.cpp:469-553)? The quality sum runs over the anchor base and the inserted bases (26-plane form) or over the
+// inserted bases only (haplotag form). k_pileup_tiles counts it into the planes of its anchor column, k_collect repeats the
+// test at site columns instead of reading a per-op flag (scattered one-byte stores: ~30 MB of HBM writes per 16 regions).
+__device__ __forceinline__ bool insert_counts(const SumArgs& a, int64_t ins_start, int32_t len, bool hp) {
+    const int64_t L = (int64_t)len + 1;
+    int64_t qs_all = 0;
+    for (int64_t i = 0; i < L; i++) qs_all += a.in.quals[ins_start + i];
+    const int q0 = a.in.quals[ins_start];
+    if (hp) return 2 + (int64_t)len <= PV_MAX_ALLELE_KEY && (double)(qs_all - q0) >= a.p.min_indel_baseq * (double)len;
+    return 1 + L <= PV_MAX_ALLELE_KEY && (double)qs_all >= a.p.min_indel_baseq * (double)L;
+}
+
 template <bool HP>
 __global__ __launch_bounds__(PT_THREADS, HP ? 2 : 4) void k_pileup_tiles(SumArgs a) {   // 26-plane form: two workgroups per CU (<= 128 VGPRs)
     __shared__ int32_t s_cnt[HP ? (int)HL_N : (int)L_N][TILE_COLS];
@@ -700,7 +719,6 @@ __global__ __launch_bounds__(PT_THREADS, HP ? 2 : 4) void k_pileup_tiles(SumArgs
                             if (ss & 2) atomicAdd(&s_cnt[HL_O + (2 + st) * 3 + 0][SW(lc)], 1);
                         }
                         atomicAdd(&s_cnt[HL_INS][SW(lc)], 1);
-                        a.op_flag[c] = 1;
                     }
                 } else {
                     const bool qok = (double)qs_all >= a.p.min_indel_baseq * (double)L;
@@ -708,7 +726,6 @@ __global__ __launch_bounds__(PT_THREADS, HP ? 2 : 4) void k_pileup_tiles(SumArgs
                     if (1 + L <= PV_MAX_ALLELE_KEY && qok) {
                         if (is_acgt(up(s_ref[lc]))) atomicAdd(&s_cnt[so + 0][SW(lc)], 1);
                         atomicAdd(&s_cnt[L_INS][SW(lc)], 1);
-                        a.op_flag[c] = 1;
                     }
                 }
             };
@@ -733,8 +750,7 @@ __global__ __launch_bounds__(PT_THREADS, HP ? 2 : 4) void k_pileup_tiles(SumArgs
                         if (anchor + L > p_reflen[pslot]) L = p_reflen[pslot] - anchor;
                         if (1 + L <= PV_MAX_ALLELE_KEY) {
                             atomicAdd(&s_cnt[HL_DEL][SW(lc)], 1);
-                            a.op_flag[c] = 1;
-                        }
+                            }
                     }
                     int64_t i0 = clo - ref_rel; if (i0 < 0) i0 = 0;
                     int64_t i1 = chi + 1 - ref_rel; if (i1 > len) i1 = len;
@@ -764,7 +780,6 @@ __global__ __launch_bounds__(PT_THREADS, HP ? 2 : 4) void k_pileup_tiles(SumArgs
                     if (anchor + L > p_reflen[pslot]) L = p_reflen[pslot] - anchor;  // substr truncation, :500
                     if (1 + L <= PV_MAX_ALLELE_KEY) {
                         atomicAdd(&s_cnt[L_DEL][SW(lc)], 1);
-                        a.op_flag[c] = 1;
                     }
                 }
                 int64_t i0 = clo - ref_rel; if (i0 < 0) i0 = 0;
@@ -978,69 +993,111 @@ __global__ __launch_bounds__(PT_THREADS, HP ? 2 : 4) void k_pileup_tiles(SumArgs
     static_assert(TILE_COLS <= PT_THREADS, "one column per thread: the site count below is a ballot");
     int site = 0;
     const SiteRegion sreg = s_sreg;
-    if constexpr (HP) {
-        for (int lc = tid; lc < ncol; lc += PT_THREADS) {
-            const int64_t g = tlo + lc;
-            int cov = -s_cnt[HL_COVD][SW(lc)];
+    // Pass 1: the four site counters of this thread's column, its flag, and - a ballot per wave - which columns of the tile are
+    // sites. Pass 2 writes the counter planes ONLY where something will read them: the planes are read at site columns
+    // (k_site_rank, k_site_alleles) and in the windows around them (k_write_windows: W columns to either side), i.e. ~20 % of the
+    // columns at one site per ~190 columns; a column within W of the tile's edge is written anyway, because the site that needs it
+    // may lie in the next tile. (Before: every column of every plane, 85 MB per 16 regions, the largest write of the chain.)
+    constexpr int W = HP ? (PV_HP_WINDOW_ROWS - 1) / 2 : (PV_WINDOW_ROWS - 1) / 2;
+    __shared__ unsigned long long s_sitebits[PT_THREADS / 64];
+    int cov = 0, n_snp = 0, n_ins = 0, n_del = 0;
+    const int lc = tid;                      // one column per thread (TILE_COLS == PT_THREADS)
+    const bool have = lc < ncol;
+    const int64_t g = tlo + lc;
+    if (have) {
+        if constexpr (HP) {
+            cov = -s_cnt[HL_COVD][SW(lc)];
 #pragma unroll
             for (int k = 0; k < 8; k++) cov += s_cnt[HL_REFC + k][SW(lc)];
+            n_snp = s_cnt[HL_SNP][SW(lc)]; n_ins = s_cnt[HL_INS][SW(lc)]; n_del = s_cnt[HL_DEL][SW(lc)];
+        } else {
+            cov = s_cnt[L_COVI][SW(lc)];
+#pragma unroll
+            for (int st = 0; st < 2; st++) {
+#pragma unroll
+                for (int k = 0; k < 4; k++) cov += s_cnt[L_P + 4 * st + k][SW(lc)];
+                cov += s_cnt[L_X + st][SW(lc)];
+            }
+            n_snp = s_cnt[L_SNP][SW(lc)]; n_ins = s_cnt[L_INS][SW(lc)]; n_del = s_cnt[L_DEL][SW(lc)];
+        }
+        const uint8_t f = site_flag(a, sreg, g, cov, n_snp, n_ins, n_del);
+        a.flags[g] = f;
+        site = f & 1;
+    }
+    const unsigned long long site_m = __ballot(site);
+    if ((tid & 63) == 0) s_sitebits[tid >> 6] = site_m;
+    __syncthreads();
+    bool need = have && (lc < W || lc >= (int)ncol - W);
+    if (have && !need) {
+        const int c0 = lc - W, c1 = lc + W;   // inside [0, ncol) here
+#pragma unroll
+        for (int wdx = 0; wdx < PT_THREADS / 64; wdx++) {
+            const int lo = wdx * 64, hi = lo + 63;
+            if (c1 < lo || c0 > hi) continue;
+            const int b0_ = c0 > lo ? c0 - lo : 0, b1_ = c1 < hi ? c1 - lo : 63;
+            const unsigned long long mask = (b1_ - b0_ == 63) ? ~0ull : (((1ull << (b1_ - b0_ + 1)) - 1ull) << b0_);
+            need = need || (s_sitebits[wdx] & mask) != 0;
+        }
+    }
+    if (need) {
+        if constexpr (HP) {
+            cnt_t v[CNT_STRIDE_HP];
+#pragma unroll
+            for (int k = 0; k < CNT_STRIDE_HP; k++) v[k] = 0;
             const int rsym = s_lut[s_ref[lc]];  // bits0-2: plane symbol of the reference byte, bit 5: valid reference
 #pragma unroll
             for (int set = 0; set < 2; set++) {
 #pragma unroll
                 for (int st = 0; st < 2; st++) {
                     const int grp = 2 * set + st;
-                    cnt_t* dst = a.cnt + (int64_t)(HC_PLANE + 8 * grp) * NC + g;
-                    dst[0] = -(s_cnt[HL_REFC + 2 * (1 + set) + st][SW(lc)] + s_cnt[HL_REFC + 2 * 3 + st][SW(lc)]);
+                    cnt_t* dst = v + HC_PLANE + 8 * grp;
+                    dst[0] = (cnt_t)-(s_cnt[HL_REFC + 2 * (1 + set) + st][SW(lc)] + s_cnt[HL_REFC + 2 * 3 + st][SW(lc)]);
                     const int m = s_cnt[HL_M + 2 * set + st][SW(lc)] + s_cnt[HL_M + 2 * 2 + st][SW(lc)];
 #pragma unroll
-                    for (int k = 0; k < 4; k++) dst[(int64_t)(1 + k) * NC] = ((rsym & 32) && (rsym & 7) == k + 1) ? -m : 0;
+                    for (int k = 0; k < 4; k++) dst[1 + k] = (cnt_t)(((rsym & 32) && (rsym & 7) == k + 1) ? -m : 0);
 #pragma unroll
-                    for (int k = 0; k < 3; k++) dst[(int64_t)(5 + k) * NC] = s_cnt[HL_O + grp * 3 + k][SW(lc)];
+                    for (int k = 0; k < 3; k++) dst[5 + k] = (cnt_t)s_cnt[HL_O + grp * 3 + k][SW(lc)];
                 }
             }
-            const int n_snp = s_cnt[HL_SNP][SW(lc)], n_ins = s_cnt[HL_INS][SW(lc)], n_del = s_cnt[HL_DEL][SW(lc)];
-            a.cnt[(int64_t)C_COV * NC + g] = cov;
-            a.cnt[(int64_t)C_SNP * NC + g] = n_snp;
-            a.cnt[(int64_t)C_INS * NC + g] = n_ins;
-            a.cnt[(int64_t)C_DEL * NC + g] = n_del;
-            const uint8_t f = site_flag(a, sreg, g, cov, n_snp, n_ins, n_del);
-            a.flags[g] = f;
-            site = f & 1;
-        }
-    } else {
-    for (int lc = tid; lc < ncol; lc += PT_THREADS) {
-        const int64_t g = tlo + lc;
-        int cov = s_cnt[L_COVI][SW(lc)];
+            v[C_COV] = (cnt_t)cov; v[C_SNP] = (cnt_t)n_snp; v[C_INS] = (cnt_t)n_ins; v[C_DEL] = (cnt_t)n_del;
+            cnt_u32x4* dst4 = reinterpret_cast<cnt_u32x4*>(a.cnt + g * CNT_STRIDE_HP);
 #pragma unroll
-        for (int st = 0; st < 2; st++) {
-            int sp = 0;
+            for (int k = 0; k < CNT_STRIDE_HP / 8; k++) {
+                cnt_u32x4 w4;
 #pragma unroll
-            for (int k = 0; k < 4; k++) {
-                const int v = s_cnt[L_P + 4 * st + k][SW(lc)];
-                sp += v;
-                a.cnt[(int64_t)(C_PLANE + 8 * st + 1 + k) * NC + g] = -v;
+                for (int j = 0; j < 4; j++) w4[j] = (uint32_t)(uint16_t)v[8 * k + 2 * j] | ((uint32_t)(uint16_t)v[8 * k + 2 * j + 1] << 16);
+                dst4[k] = w4;
             }
-            const int counted = sp + s_cnt[L_X + st][SW(lc)];
-            cov += counted;
-            a.cnt[(int64_t)(C_PLANE + 8 * st) * NC + g] = -(counted - s_cnt[L_ANC + st][SW(lc)]);
+        } else {
+            cnt_t v[CNT_STRIDE];
 #pragma unroll
-            for (int k = 0; k < 3; k++) a.cnt[(int64_t)(C_PLANE + 8 * st + 5 + k) * NC + g] = -s_cnt[L_O + 3 * st + k][SW(lc)];
+            for (int k = 0; k < CNT_STRIDE; k++) v[k] = 0;
+#pragma unroll
+            for (int st = 0; st < 2; st++) {
+                int sp = 0;
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    const int x = s_cnt[L_P + 4 * st + k][SW(lc)];
+                    sp += x;
+                    v[C_PLANE + 8 * st + 1 + k] = (cnt_t)-x;
+                }
+                const int counted = sp + s_cnt[L_X + st][SW(lc)];
+                v[C_PLANE + 8 * st] = (cnt_t)-(counted - s_cnt[L_ANC + st][SW(lc)]);
+#pragma unroll
+                for (int k = 0; k < 3; k++) v[C_PLANE + 8 * st + 5 + k] = (cnt_t)-s_cnt[L_O + 3 * st + k][SW(lc)];
+            }
+            v[C_COV] = (cnt_t)cov; v[C_SNP] = (cnt_t)n_snp; v[C_INS] = (cnt_t)n_ins; v[C_DEL] = (cnt_t)n_del;
+            v[C_RARE] = (cnt_t)s_cnt[L_RARE][SW(lc)];
+            cnt_u32x4* dst4 = reinterpret_cast<cnt_u32x4*>(a.cnt + g * CNT_STRIDE);
+#pragma unroll
+            for (int k = 0; k < CNT_STRIDE / 8; k++) {
+                cnt_u32x4 w4;
+#pragma unroll
+                for (int j = 0; j < 4; j++) w4[j] = (uint32_t)(uint16_t)v[8 * k + 2 * j] | ((uint32_t)(uint16_t)v[8 * k + 2 * j + 1] << 16);
+                dst4[k] = w4;
+            }
         }
-        const int n_snp = s_cnt[L_SNP][SW(lc)], n_ins = s_cnt[L_INS][SW(lc)], n_del = s_cnt[L_DEL][SW(lc)];
-        a.cnt[(int64_t)C_COV * NC + g] = cov;
-        a.cnt[(int64_t)C_SNP * NC + g] = n_snp;
-        a.cnt[(int64_t)C_INS * NC + g] = n_ins;
-        a.cnt[(int64_t)C_DEL * NC + g] = n_del;
-        a.cnt[(int64_t)C_RARE * NC + g] = s_cnt[L_RARE][SW(lc)];
-        const uint8_t f = site_flag(a, sreg, g, cov, n_snp, n_ins, n_del);
-        a.flags[g] = f;
-        site = f & 1;
     }
-    }
-    // sites of this tile: the "block" counts the rank kernel's scan runs over are per tile (zeroed by k_init; an atomic
-    // per wave rather than a workgroup count, whose barrier would wait for the stores above)
-    const unsigned long long site_m = __ballot(site);
     if ((tid & 63) == 0 && site_m) atomicAdd(&a.blk_cnt[tile], __popcll(site_m));
 #ifdef PV_PSTAMPS
     PSTAMP(5)  // flush
@@ -1333,15 +1390,15 @@ __global__ __launch_bounds__(1024) void k_site_rank(SumArgs a) {
     if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) a.diag[D_NSITES] = (int64_t)base + own;   // the last block knows the total
     const int32_t rank = base + woff + before;
     if (site && rank < a.max_sites) {
-        const int64_t NC = a.n_cols;
         int g = a.tile_g0[col / TILE_COLS];   // region of the tile's first column (k_init), then forwards: two dependent loads, not five
         while (g + 1 <= a.in.n_regions && a.in.ref_off[g + 1] <= col) g++;
         a.site_col[rank] = (int32_t)col;
         a.site_region[rank] = g;
         // events a site will receive: every insert / delete observation, and either the rare SNP observations (the
         // common ones are read off the symbol planes) or, in the haplotag form, every SNP observation
-        const int n_base = a.cnt[(a.hp ? C_SNP : C_RARE) * NC + col];
-        const int nev = a.cnt[C_INS * NC + col] + a.cnt[C_DEL * NC + col] + n_base;
+        const cnt_t* cc = a.cnt + (int64_t)col * (a.hp ? CNT_STRIDE_HP : CNT_STRIDE);   // this column's counters
+        const int n_base = cc[a.hp ? C_SNP : C_RARE];
+        const int nev = cc[C_INS] + cc[C_DEL] + n_base;
         a.site_nev[rank] = nev;
         a.site_fill[rank] = 0;
         SiteHdr h;
@@ -1350,7 +1407,7 @@ __global__ __launch_bounds__(1024) void k_site_rank(SumArgs a) {
         h.R = (int32_t)(a.in.ref_end[g] - h.ref_start + 1);
         const int64_t t = col / TILE_COLS;
         h.p0 = a.tile_off[t]; h.np = a.tile_cnt[t];
-        h.cov = a.cnt[C_COV * NC + col];
+        h.cov = cc[C_COV];
         h.flags = (int32_t)a.in.ref[col] | (n_base != 0 ? 256 : 0) | (f << 16);
         h.nev = nev; h.pad = 0;
         a.site_hdr[rank] = h;
@@ -1381,7 +1438,7 @@ __device__ __forceinline__ void push_event(const SumArgs& a, int32_t s, int32_t 
 // column. Sites are ~1 column in 200, so walking the CIGAR stream a second time (a workgroup per read, five loads per op,
 // 20 M ops per launch) spent nearly all its loads on ops that touch no site; here a lane finds the read's ops at the site
 // column with one binary search over the pair's op range (start columns are sorted), 8 k sites x ~70 reads x 7 steps.
-//   ops that START right behind the column and are inserts / deletes anchor on it (op_flag: counted by k_pileup_tiles);
+//   ops that START right behind the column and are inserts / deletes anchor on it (counted by k_pileup_tiles: insert_counts());
 //   the aligned op that contains the column gives the read's base there (rare observations only, or - haplotag form - every
 //   mismatch).
 constexpr int KC_WAVES = 2;  // waves per site: the benchmark's tiles hold ~70 pairs, which one wave would walk as two trips in a row
@@ -1425,12 +1482,15 @@ __global__ __launch_bounds__(64 * KC_WAVES) void k_collect(SumArgs a) {
                 const uint32_t w = a.in.cigar[o];
                 const int op = w & 0xF;
                 const int32_t len = (int32_t)(w >> 4);
-                if (op == PV_CIGAR_IN) {
-                    if (a.op_flag[o]) push_event(a, (int32_t)s, h.nev, evoff, pr.base0 + a.op_rd[o] - 1, len + 1, 2, rev, 1, obs);
+                if (op == PV_CIGAR_IN) {   // the conditions under which k_pileup_tiles counted it (INS plane, insert_count)
+                    const int32_t rdv = a.op_rd[o];
+                    const int64_t ins_start = pr.base0 + rdv - 1;
+                    if (rdv >= 1 && ins_start + (int64_t)len + 1 <= pr.seq_end && insert_counts(a, ins_start, len, a.hp != 0))
+                        push_event(a, (int32_t)s, h.nev, evoff, ins_start, len + 1, 2, rev, 1, obs);
                 } else if (op == PV_CIGAR_DEL) {
                     int64_t L = (int64_t)len + 1;
                     if ((int64_t)col_rel + L > pr.ref_len) L = pr.ref_len - col_rel;
-                    if (a.op_flag[o]) push_event(a, (int32_t)s, h.nev, evoff, col, (int32_t)L, 3, rev, 2, obs);
+                    if (1 + L <= PV_MAX_ALLELE_KEY) push_event(a, (int32_t)s, h.nev, evoff, col, (int32_t)L, 3, rev, 2, obs);
                 }
             }
             if (!need_base) continue;
@@ -1527,7 +1587,6 @@ __global__ __launch_bounds__(64) void k_site_alleles(SumArgs a) {
         const int64_t eoff = a.site_evoff[s];          // (requested together with the header)
         if ((h.nev + 4 > UM_SMALL) != BIG) continue;   // the other instantiation's site
         const int64_t col = h.col;
-        const int64_t NC = a.n_cols;
         const int f = (h.flags >> 16) & 0xFF;
         const int cov = h.cov;
         const int depth = cov < PV_MAX_COLOR ? cov : PV_MAX_COLOR;  // :682
@@ -1541,8 +1600,8 @@ __global__ __launch_bounds__(64) void k_site_alleles(SumArgs a) {
             u_pre[lane] = (uint64_t)(uint8_t)b << 56;
             const bool ok = refvalid && b != refraw;
             u_ok[lane] = ok;
-            u_fwd[lane] = ok ? -a.cnt[(C_PLANE + 1 + lane) * NC + col] : 0;
-            u_rev[lane] = ok ? -a.cnt[(C_PLANE + 8 + 1 + lane) * NC + col] : 0;
+            u_fwd[lane] = ok ? -a.cnt[(int64_t)col * CNT_STRIDE + C_PLANE + 1 + lane] : 0;
+            u_rev[lane] = ok ? -a.cnt[(int64_t)col * CNT_STRIDE + C_PLANE + 8 + 1 + lane] : 0;
         }
         if (lane == 0) s_nU = HP ? 0 : 4;
         __syncthreads();
@@ -1681,7 +1740,6 @@ __global__ __launch_bounds__(WW_THREADS) void k_write_windows(SumArgs a) {
     if (a.diag[D_STATUS] != 0) return;
     int64_t n_sites = a.diag[D_NSITES];
     if (n_sites > a.max_sites) n_sites = a.max_sites;
-    const int64_t NC = a.n_cols;
     for (int64_t sj = blockIdx.x >> 3; sj < xcd_chunk(n_sites); sj += gridDim.x >> 3) {
         const int64_t s = xcd_site(sj, n_sites);
         if (s >= n_sites) break;
@@ -1737,7 +1795,7 @@ __global__ __launch_bounds__(WW_THREADS) void k_write_windows(SumArgs a) {
                     const int plane = pl == 4 ? C_PLANE : (pl >= 8 && pl <= 14) ? C_PLANE + 1 + (pl - 8)
                                     : pl == 15 ? C_PLANE + 8 : pl >= 19 ? C_PLANE + 8 + 1 + (pl - 19) : -1;
                     int v = 0;
-                    if (in && plane >= 0) v = a.cnt[(int64_t)plane * NC + c2];
+                    if (in && plane >= 0) v = a.cnt[c2 * CNT_STRIDE + plane];
                     if (in && pl == 0) v = a.in.ref[c2];
                     raw[u] = v;
                 }
@@ -1809,7 +1867,6 @@ __global__ __launch_bounds__(WW_THREADS) void k_write_windows_hp(SumArgs a) {
     if (a.diag[D_STATUS] != 0) return;
     int64_t n_sites = a.diag[D_NSITES];
     if (n_sites > a.max_sites) n_sites = a.max_sites;
-    const int64_t NC = a.n_cols;
     constexpr int MID = (PV_HP_WINDOW_ROWS - 1) / 2;
     for (int64_t sj = blockIdx.x >> 3; sj < xcd_chunk(n_sites); sj += gridDim.x >> 3) {
         const int64_t s = xcd_site(sj, n_sites);
@@ -1851,7 +1908,7 @@ __global__ __launch_bounds__(WW_THREADS) void k_write_windows_hp(SumArgs a) {
                     const int grp = (pl - 4) / 11, w = (pl - 4) - 11 * grp;  // 0 REF count, 1-3 overlays, 4-10 symbols
                     const int plane = pl < 4 ? -1 : (w == 0 ? HC_PLANE + 8 * grp : (w >= 4 ? HC_PLANE + 8 * grp + (w - 3) : -1));
                     int v = 0;
-                    if (in && plane >= 0) v = a.cnt[(int64_t)plane * NC + c2];
+                    if (in && plane >= 0) v = a.cnt[c2 * CNT_STRIDE_HP + plane];
                     if (in && pl == 0) v = a.in.ref[c2];
                     raw[u] = v;
                 }
@@ -2278,7 +2335,7 @@ static int summarize_launch(pv_ctx* ctx, const pv_batch_in* in, const pv_params*
     if ((rc = pv_get(ctx, "sum.tile_off", a.n_tiles, &a.tile_off))) return rc;
     if ((rc = pv_get(ctx, "sum.tile_fill", a.n_tiles, &a.tile_fill))) return rc;
     if ((rc = pv_get(ctx, "sum.pairs", max_pairs, &a.pairs))) return rc;
-    if ((rc = pv_get(ctx, "sum.cnt", (size_t)(hp ? NCNT_HP : NCNT) * n_cols, &a.cnt))) return rc;
+    if ((rc = pv_get(ctx, "sum.cnt", (size_t)(hp ? CNT_STRIDE_HP : CNT_STRIDE) * n_cols, &a.cnt))) return rc;
     if ((rc = pv_get(ctx, "sum.flags", n_cols, &a.flags))) return rc;
     if ((rc = pv_get(ctx, "sum.blk_cnt", (size_t)a.n_tiles + 2, &a.blk_cnt))) return rc;   // per tile
     if ((rc = pv_get(ctx, "sum.tile_g0", (size_t)a.n_tiles + 2, &a.tile_g0))) return rc;
