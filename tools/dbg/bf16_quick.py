@@ -1,3 +1,4 @@
+"""Diagnostic: quick accuracy (vs fp32 mode and the float64 oracle) and per-kernel times of the bf16x3 mode, P1 and P2"""
 import sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch

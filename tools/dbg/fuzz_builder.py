@@ -18,12 +18,16 @@ while time.time() - t0 < budget:
     seed = seed0 + n
     rng = np.random.default_rng(seed)
     preset = list(PRESETS)[int(rng.integers(len(PRESETS)))]
-    regs = [synth.synth_region(7000 + 31 * seed + k, region_len=int(rng.integers(40, 9000)), depth=int(rng.integers(1, 140)),
-                               read_len=int(rng.integers(30, 4000)), site_every=int(rng.integers(8, 300)),
+    big = len(sys.argv) > 3 and sys.argv[3] == "big"   # longer regions (many tiles), sparser / denser sites, longer reads
+    regs = [synth.synth_region(7000 + 31 * seed + k, region_len=int(rng.integers(40, 60000 if big else 9000)), depth=int(rng.integers(1, 60 if big else 140)),
+                               read_len=int(rng.integers(30, 20000 if big else 4000)), site_every=int(rng.choice([8, 40, 300, 3000, 50000]) if big else rng.integers(8, 300)),
                                n_rate=float(rng.choice([0.0, 0.002, 0.02])), ref_n_rate=float(rng.choice([0.0, 0.0, 0.01])),
                                mismatch=float(rng.choice([0.0, 0.03, 0.1])), ins_rate=float(rng.choice([0.0, 0.02, 0.08])),
                                del_rate=float(rng.choice([0.0, 0.03, 0.08])))
             for k in range(int(rng.integers(1, 7)))]
+    if max(len(r.reads) for r in regs) > 32767:   # beyond the 16-bit counters: refused by the builder (tested elsewhere)
+        seed0 += 1
+        continue
     batch = pack_regions(regs)
     form = n % 3   # the 26-plane builder, the haplotag-aware one, the polisher's
     what = "seed %d preset %s form %d" % (seed, preset, form)
