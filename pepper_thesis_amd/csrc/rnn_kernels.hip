@@ -771,14 +771,15 @@ struct GemmArgs {
     const unsigned* iota; // [1024] = 0 .. 1023: the source of the completion-flag transfers (below)
 };
 
-// C = A . W^T (+ bias) with 3-term split-bf16 products (a_hi.w_hi + a_hi.w_lo + a_lo.w_hi) on v_mfma_f32_32x32x16_bf16.
-// Persistent workgroups (one per CU, 8 waves as 2 x 4, 128 x 64 outputs per wave = 8 accumulator tiles of 32 x 32) walk
+// C = A . W^T (+ bias) with 3-term split-bf16 products (a_hi.w_hi + a_hi.w_lo + a_lo.w_hi) on v_mfma_f32_16x16x32_bf16 (until late in
+// round 3: 32x32x16 - same cycles per K step, but the chip sustains more on the 16x16x32 shape and the chain runs 1.4 % faster).
+// Persistent workgroups (one per CU, 8 waves as 2 x 4, 128 x 64 outputs per wave = 32 accumulator tiles of 16 x 16) walk
 // 256 x 256 output tiles; K in steps of 32. Per K step a workgroup moves 64 KB ({A,W} x {hi,lo} x 256 rows x 64 B) from
 // L2/HBM straight into LDS with 64 LDS-DMA wave-instructions (buffer_load_dwordx4 ... lds, 8 per wave, no registers, no
 // ds_write): the transfers of step k+1 run during step k's MFMAs into the other half of a double-buffered image. An LDS-DMA
 // lands lane-linear (wave base + 16 B per lane), so the XOR swizzle that makes the fragment ds_read_b128 conflict-free
 // (16-byte chunk index ^ ((row >> 2) & 3) inside each 64-byte row) is applied on the SOURCE address of every lane. One
-// barrier per K step; per step and wave 24 ds_read_b128 feed 48 MFMAs. Work items are ordered n-tile fastest and dealt to the
+// barrier per K step; per step and wave 24 ds_read_b128 feed 96 MFMAs of 16 cycles. Work items are ordered n-tile fastest and dealt to the
 // XCDs in groups of one XCD's workgroups, so the CUs of an XCD work on the same few A row tiles at the same time. The K steps
 // of a workgroup form ONE stream across its items: the first K step of the next item is requested during the last K step of
 // this one like any other (buffer = step parity), so an item ends with its 32 dwordx4 stores per wave (quad layout) and the
@@ -803,10 +804,6 @@ __global__ __launch_bounds__(512, 2) void k_gemm_bf16x3(GemmArgs g) {
     // destination chunk lane & 3, source chunk (lane & 3) ^ ((lane >> 4) & 3) (= ((row >> 2) & 3) swizzle)
     const int d_row = lane >> 2;
     const unsigned d_chunk = (unsigned)((lane & 3) ^ ((lane >> 4) & 3));
-    // fragment role
-    const unsigned f_swz = (unsigned)(((lane & 31) >> 2) & 3);
-    const unsigned fa_l = (unsigned)((128 * wr + (lane & 31)) * 64);
-    const unsigned fb_l = (unsigned)(2 * ARR + (64 * wc + (lane & 31)) * 64);
     const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, per_xcd = gridDim.x >> 3;
     const int kslice = g.K / g.splits, nk = kslice / BK;
     const unsigned row_bytes = (unsigned)g.K * 4u;
@@ -916,13 +913,13 @@ __global__ __launch_bounds__(512, 2) void k_gemm_bf16x3(GemmArgs g) {
         else { nxt.sp = r_n % g.splits; nxt.mt = r_n / g.splits; }
         if (has_next) item_setup(nxt);
         GSTAMP(6)
-        f32x16 acc[4][2];
+        f32x4 acc[8][4];   // 16 x 16 tiles of this wave's 128 x 64 outputs
 #pragma unroll
-        for (int mi = 0; mi < 4; mi++)
+        for (int mi = 0; mi < 8; mi++)
 #pragma unroll
-            for (int ni = 0; ni < 2; ni++)
+            for (int ni = 0; ni < 4; ni++)
 #pragma unroll
-                for (int r = 0; r < 16; r++) acc[mi][ni][r] = 0.0f;
+                for (int r = 0; r < 4; r++) acc[mi][ni][r] = 0.0f;
         // one K step: wait for its operands, multiply, and request the operands of the step after it - K step s_kt of item S -
         // into the other buffer (issue == false: there is no such step)
         auto k_step = [&](const Item& S, int s_kt, bool issue, bool next_bias) {
@@ -945,20 +942,25 @@ __global__ __launch_bounds__(512, 2) void k_gemm_bf16x3(GemmArgs g) {
             // FIRST half of the step: one per block over the whole step left the last pieces ~400 cycles to land before the step
             // ended (the step then waited ~650 cycles for them); four or eight in front of the first blocks stall the pipe again
             // (decoder projection, same box: 1.49 ms one per block, 1.43 two, 1.48 four, 1.46 eight).
+            // v_mfma_f32_16x16x32_bf16: a K step is ONE k-step of 32; lane -> row / column lane & 15, 16-byte chunk lane >> 4 of the
+            // 64-byte row (under the image's XOR swizzle: conflict-free as the 32 x 32 x 16 reads were). Same MFMA cycles and LDS
+            // reads per K step as the 32 x 32 x 16 form, but the chip sustains ~14 % more FLOP/s on this shape under load
+            // (tools/dbg/src/mfma_shapes.hip: 2.42 against 2.12 PFLOP/s in a bare loop - the kernel runs power-limited at
+            // ~1.8 GHz).
+            {
+                const unsigned ch16 = (unsigned)((((lane >> 4)) ^ (((lane & 15) >> 2) & 3)) * 16);
+                const unsigned fa16 = (unsigned)((128 * wr + (lane & 15)) * 64), fb16 = (unsigned)(2 * ARR + (64 * wc + (lane & 15)) * 64);
+                bf16x8 bh[4], bl[4];
 #pragma unroll
-            for (int ks = 0; ks < 2; ks++) {
-                const unsigned ch = (unsigned)(((2 * ks + (lane >> 5)) ^ f_swz) * 16);
-                bf16x8 bh[2], bl[2];
-#pragma unroll
-                for (int ni = 0; ni < 2; ni++) {
-                    bh[ni] = *reinterpret_cast<const bf16x8*>(base + fb_l + ni * 32 * 64 + ch);
-                    bl[ni] = *reinterpret_cast<const bf16x8*>(base + ARR + fb_l + ni * 32 * 64 + ch);
+                for (int ni = 0; ni < 4; ni++) {
+                    bh[ni] = *reinterpret_cast<const bf16x8*>(base + fb16 + ni * 16 * 64 + ch16);
+                    bl[ni] = *reinterpret_cast<const bf16x8*>(base + ARR + fb16 + ni * 16 * 64 + ch16);
                 }
 #pragma unroll
-                for (int mi = 0; mi < 4; mi++) {
-                    const bf16x8 ah = *reinterpret_cast<const bf16x8*>(base + fa_l + mi * 32 * 64 + ch);
-                    const bf16x8 al = *reinterpret_cast<const bf16x8*>(base + ARR + fa_l + mi * 32 * 64 + ch);
-                    if (issue && ks == 0) {   // two pieces in front of each of the first four blocks
+                for (int mi = 0; mi < 8; mi++) {
+                    const bf16x8 ah = *reinterpret_cast<const bf16x8*>(base + fa16 + mi * 16 * 64 + ch16);
+                    const bf16x8 al = *reinterpret_cast<const bf16x8*>(base + ARR + fa16 + mi * 16 * 64 + ch16);
+                    if (issue && mi < 4) {   // two pieces in front of each of the first four blocks
                         dma_piece(S, s_kt, buf ^ 1, 2 * mi);
                         dma_piece(S, s_kt, buf ^ 1, 2 * mi + 1);
                         if (mi == 3) {
@@ -967,10 +969,10 @@ __global__ __launch_bounds__(512, 2) void k_gemm_bf16x3(GemmArgs g) {
                         }
                     }
 #pragma unroll
-                    for (int ni = 0; ni < 2; ni++) {
-                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh[ni], acc[mi][ni], 0, 0, 0);
-                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl[ni], acc[mi][ni], 0, 0, 0);
-                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh[ni], acc[mi][ni], 0, 0, 0);
+                    for (int ni = 0; ni < 4; ni++) {
+                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh[ni], acc[mi][ni], 0, 0, 0);
+                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl[ni], acc[mi][ni], 0, 0, 0);
+                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh[ni], acc[mi][ni], 0, 0, 0);
                     }
                 }
             }
@@ -988,51 +990,43 @@ __global__ __launch_bounds__(512, 2) void k_gemm_bf16x3(GemmArgs g) {
         const int n0 = cur.nt * BN;
         const int64_t rows_left = g.M - m0 < BM ? g.M - m0 : BM;
         float* cbase = g.C + (size_t)cur.sp * g.M * g.N;
-        float bv[2];
+        float bv[4];
         // (this item's bias slot is written again during the last K step of the NEXT item: every wave has read it long before)
 #pragma unroll
-        for (int ni = 0; ni < 2; ni++) bv[ni] = g.bias ? sbias[(tile_no & 1) * BN + 64 * wc + 32 * ni + (lane & 31)] : 0.0f;
+        for (int ni = 0; ni < 4; ni++) bv[ni] = g.bias ? sbias[(tile_no & 1) * BN + 64 * wc + 16 * ni + (lane & 15)] : 0.0f;
         GSTAMP(5)
         if (g.c_quads) {
-            // [M/4][N][4]: accumulator registers 4g..4g+3 of a lane are four consecutive rows of one column: one 16-byte store
-            // the same descriptor make_rsrc_sized builds, as four words for the inline-asm store below
+            // [M/4][N][4]: the four registers of a 16 x 16 accumulator are four consecutive rows of one column: one 16-byte store,
+            // lane -> quad row lane >> 4, column lane & 15
             const uint64_t cptr = (uint64_t)(cbase + ((size_t)(m0 >> 2) * g.N + n0) * 4);
             u32x4 rcw;
             rcw[0] = __builtin_amdgcn_readfirstlane((unsigned)cptr);
             rcw[1] = __builtin_amdgcn_readfirstlane((unsigned)(cptr >> 32) & 0xffffu);
             rcw[2] = __builtin_amdgcn_readfirstlane((unsigned)((((rows_left + 3) / 4 - 1) * g.N + BN) * 16));
             rcw[3] = 0x00020000u;
-            const unsigned c_l = (unsigned)((((lane >> 5)) * g.N + (lane & 31)) * 16);
+            const unsigned c_l = (unsigned)((((lane >> 4)) * g.N + (lane & 15)) * 16);
 #pragma unroll
-            for (int mi = 0; mi < 4; mi++)
+            for (int mi = 0; mi < 8; mi++)
 #pragma unroll
-                for (int ni = 0; ni < 2; ni++)
+                for (int ni = 0; ni < 4; ni++) {
+                    f32x4 v;
 #pragma unroll
-                    for (int gq = 0; gq < 4; gq++) {
-                        f32x4 v;
-#pragma unroll
-                        for (int j = 0; j < 4; j++) v[j] = acc[mi][ni][4 * gq + j] + bv[ni];
-                        // gfx950 reads the data registers of a 16-byte buffer store late: a VALU write to them in the next
-                        // wait states corrupts part of the lanes (measured: dword 1 of lanes 12-15 of every 16), and hipcc
-                        // (ROCm 7.2) pads that hazard only for stores WITHOUT an SGPR soffset. The store is issued from inline asm
-                        // with its own wait states, after which the registers are free (and with the 5 wait states a VALU-written
-                        // SGPR operand needs before a VMEM instruction reads it: hipcc pads nothing around asm statements, and the
-                        // scalar offset may just have come out of a v_readlane spill reload).
-                        const unsigned so = (unsigned)(((32 * wr + 8 * mi + 2 * gq) * g.N + 64 * wc + 32 * ni) * 16);
-                        asm volatile("s_nop 4\n\tbuffer_store_dwordx4 %0, %1, %2, %3 offen nt\n\ts_nop 2"
-                                     :: "v"(v), "v"(c_l), "s"(rcw), "s"(so) : "memory");
-                    }
+                    for (int j = 0; j < 4; j++) v[j] = acc[mi][ni][j] + bv[ni];
+                    // (inline asm with its own wait states: see the 32 x 32 form's note on gfx950's late read of store data)
+                    const unsigned so = (unsigned)(((32 * wr + 4 * mi) * g.N + 64 * wc + 16 * ni) * 16);
+                    asm volatile("s_nop 4\n\tbuffer_store_dwordx4 %0, %1, %2, %3 offen nt\n\ts_nop 2"
+                                 :: "v"(v), "v"(c_l), "s"(rcw), "s"(so) : "memory");
+                }
         } else {
             const __amdgpu_buffer_rsrc_t rc = make_rsrc_sized(cbase + (size_t)m0 * g.N + n0, (unsigned)(((rows_left - 1) * g.N + BN) * 4));
-            const unsigned c_l = (unsigned)(((4 * (lane >> 5)) * g.N + (lane & 31)) * 4);
+            const unsigned c_l = (unsigned)(((4 * (lane >> 4)) * g.N + (lane & 15)) * 4);
 #pragma unroll
-            for (int mi = 0; mi < 4; mi++)
+            for (int mi = 0; mi < 8; mi++)
 #pragma unroll
-                for (int ni = 0; ni < 2; ni++)
+                for (int ni = 0; ni < 4; ni++)
 #pragma unroll
-                    for (int r = 0; r < 16; r++)
-                        buf_store1_nt(acc[mi][ni][r] + bv[ni], rc, c_l,
-                                      (unsigned)(((128 * wr + 32 * mi + (r & 3) + 8 * (r >> 2)) * g.N + 64 * wc + 32 * ni) * 4));
+                    for (int r = 0; r < 4; r++)
+                        buf_store1_nt(acc[mi][ni][r] + bv[ni], rc, c_l, (unsigned)(((128 * wr + 16 * mi + r) * g.N + 64 * wc + 16 * ni) * 4));
         }
         GSTAMP(7)
         cur = nxt;
