@@ -13,7 +13,7 @@ oracle.build()
 ctx = runtime.Context(0)
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
 seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
-t0 = time.time(); n = 0; windows = 0
+t0 = time.time(); n = 0; windows = 0; last_note = t0
 while time.time() - t0 < budget:
     seed = seed0 + n
     rng = np.random.default_rng(seed)
@@ -51,5 +51,8 @@ while time.time() - t0 < budget:
             assert (a is None) == (b is None) and (a is None or (a.shape == b.shape and np.array_equal(a, b))), (what, f)
         windows += len(got.images)
     n += 1
+    if time.time() - last_note > 50:   # (a silent run is taken for a hung one on the GPU box)
+        last_note = time.time()
+        print("  ... %d batches, %d windows / chunks so far" % (n, windows), flush=True)
 print("fuzz_builder: %d random batches (%d windows / chunks; image builder, haplotag-aware builder, polisher builder in turn) identical "
       "to the oracle in %.0f s (seeds %d..%d)" % (n, windows, time.time() - t0, seed0, seed0 + n - 1))
