@@ -88,6 +88,7 @@ struct pv_p2_bf16_weights {
     float* dec_bias_hn = nullptr;
     unsigned char* dec_wih_s = nullptr;   // decoder W_ih of both directions [768][256], split8 rows
     unsigned char* dense_frag = nullptr;  // dense1 as MFMA fragments of the decoder kernel (pv_pack_p2_dense)
+    unsigned char* dense_frag16 = nullptr;   // ... of the 16-row decoder kernel (pv_pack_p2_dense16)
     unsigned char* enc16_wp = nullptr;    // the same layers packed for the 16-row form (pv_pack_gru16_bf16)
     unsigned char* enc16_wx = nullptr;
     unsigned char* dec16_wp = nullptr;
@@ -97,5 +98,6 @@ struct pv_p2_bf16_weights {
 };
 // dense_w [5][256] (host) -> [2 dirs][4 waves][2 k-steps][hi 1 KB | lo 1 KB]
 int pv_pack_p2_dense(const float* dense_w, unsigned char** d_frag, std::vector<void*>& owned);
+int pv_pack_p2_dense16(const float* dense_w, unsigned char** d_frag, std::vector<void*>& owned);
 int pv_p2_bf16_forward(pv_ctx* ctx, const pv_p2_bf16_weights& w, const uint8_t* d_images, int64_t B, uint8_t* d_labels, float* d_acc,
                        hipStream_t st, int seq, int nwin, const float* d_hidden_in, float* d_hidden_out, float* d_logits);

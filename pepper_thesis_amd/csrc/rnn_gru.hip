@@ -1078,6 +1078,7 @@ extern "C" int pv_rnn_load_p2(pv_ctx* ctx, const pv_weights_p2* w, int dtype) {
             return rc;
         if ((rc = pv_upload_split8(wcat.data(), (size_t)6 * HG, KPD, &m->bf.dec_wih_s, m->owned))) return rc;
         if ((rc = pv_pack_p2_dense(w->dense_w, &m->bf.dense_frag, m->owned))) return rc;
+        if ((rc = pv_pack_p2_dense16(w->dense_w, &m->bf.dense_frag16, m->owned))) return rc;
         if ((rc = pv_gemm_bf16x3_prepare()) || (rc = pv_rec_bf16_prepare())) return rc;
     }
     for (int f = 0; f < 3; f++) {

@@ -556,6 +556,16 @@ __global__ __launch_bounds__(256, 1) void k_gru16_bf16(RecArgs a) {
 #pragma unroll
         for (int g = 0; g < 3; g++) b_g[g][nt] = ENC ? a.bias[dir * 3 * HID + g * HID + unit] : 0.0f;
     }
+    // decoder with the dense layer folded in (see k_rec_bf16): wave w contributes k-step w of its direction's 128 units to the
+    // logits of every row, as one more 16 x 16 x 32 product per tile and step; partial sums of the 2 x 4 waves go out as quads
+    // [t][16-row tile][direction][wave][8 classes][16 rows]
+    const bool dense = !ENC && a.dpart != nullptr;
+    bf16x8 dfr[2];
+    if (dense) {
+        const __amdgpu_buffer_rsrc_t dr = make_rsrc(a.dw + (size_t)(dir * NW + wv) * 2048);
+        dfr[0] = __builtin_bit_cast(bf16x8, buf_load4(dr, lane16, 0u));
+        dfr[1] = __builtin_bit_cast(bf16x8, buf_load4(dr, lane16, 1024u));
+    }
     // state and the h tiles (a workgroup's second tile may lie beyond the batch: it then repeats the first, stores nothing)
     float st[NTL][2][4];
     int64_t b0[NTL];
@@ -667,6 +677,20 @@ __global__ __launch_bounds__(256, 1) void k_gru16_bf16(RecArgs a) {
             }
         }
     };
+    auto dense_out = [&](int tt, int cur_) {   // partial logits of the h tiles of step tt (buffer cur_)
+#pragma unroll
+        for (int u = 0; u < NTL; u++) {
+            if (!live[u]) continue;
+            const unsigned char* At = hbuf_all + (u * 2 + cur_) * ROWS * HS + lr * HS + q * 32 + wv * 128;
+            const bf16x8 dah = *reinterpret_cast<const bf16x8*>(At), dal = *reinterpret_cast<const bf16x8*>(At + 16);
+            f32x4 ad = {0.0f, 0.0f, 0.0f, 0.0f};
+            ad = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dah, dfr[0], ad, 0, 0, 0);
+            ad = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dah, dfr[1], ad, 0, 0, 0);
+            ad = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dal, dfr[0], ad, 0, 0, 0);
+            if (lr < 8)   // class lr (5 real, 3 zero), rows 4q .. 4q + 3
+                *reinterpret_cast<f32x4*>(a.dpart + ((((size_t)tt * (a.Bp / 16) + (size_t)(b0[u] / 16)) * 2 + dir) * 4 + wv) * 128 + lr * 16 + 4 * q) = ad;
+        }
+    };
     x_load(dir ? T - 1 : 0);
     x_store(0);
     g_load(dir ? T - 1 : 0);
@@ -677,6 +701,7 @@ __global__ __launch_bounds__(256, 1) void k_gru16_bf16(RecArgs a) {
         const int tn = dir ? (T - 2 - s) : (s + 1);
         if (s + 1 < T) x_load(tn);
         if (s > 0) tile_out(dir ? t + 1 : t - 1, cur);
+        if (dense && s > 0) dense_out(dir ? t + 1 : t - 1, cur);   // (the previous step's h tiles: this step's A operands)
 #pragma unroll
         for (int u = 0; u < NTL; u++) {
             unsigned char* hb = hbuf_all + u * 2 * ROWS * HS;
@@ -757,6 +782,7 @@ __global__ __launch_bounds__(256, 1) void k_gru16_bf16(RecArgs a) {
         lds_barrier();
     }
     tile_out(dir ? 0 : T - 1, cur);
+    if (dense) dense_out(dir ? 0 : T - 1, cur);
     if (a.h_out) {
 #pragma unroll
         for (int u = 0; u < NTL; u++) {
@@ -1056,7 +1082,7 @@ int pv_rec_bf16_async(pv_ctx* ctx, const pv_rec_desc& d, hipStream_t st) {
     a.dw = d.dense_w; a.dpart = d.dense_part;
     PV_CHECK(!d.dense_part || (d.cell == 3 && !d.enc && d.dense_w), PV_ERR_INVALID, "the dense layer folds into the GRU decoder only");
     if (d.tr16) {   // GRU on 16-row tiles (its own fragment streams: pv_pack_gru16_bf16)
-        PV_CHECK(d.cell == 3 && (d.tr16 == 1 || d.tr16 == 2) && d.Bp % 16 == 0 && !d.dense_part && !d.out_f32, PV_ERR_INVALID, "bad 16-row GRU launch");
+        PV_CHECK(d.cell == 3 && (d.tr16 == 1 || d.tr16 == 2) && d.Bp % 16 == 0 && !d.out_f32 && !(d.dense_part && d.enc), PV_ERR_INVALID, "bad 16-row GRU launch");
         a.n_tiles = (int)(d.Bp / 16);
         const int ntl = d.tr16;   // 16-row tiles per workgroup
         const int n_wg = (a.n_tiles + ntl - 1) / ntl;
@@ -1166,20 +1192,21 @@ __global__ __launch_bounds__(256) void k_p2_state_out(const float* __restrict__ 
 
 // sum of the decoder kernel's partial logits (2 directions x 4 waves) + bias -> softmax -> accumulate (predict.py:70-89);
 // thread = (t, chunk). part: [100][Bp / 32][2][4][8 classes][32 rows]
+template <int TR>   // rows of the decoder kernel's tiles (32, or 16: k_gru16_bf16)
 __global__ __launch_bounds__(256) void k_p2_combine(const float* __restrict__ part, int64_t Bp, int64_t B, const float* __restrict__ bias,
                                                     float* __restrict__ acc, int seq, int ws, float* __restrict__ logits) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= (int64_t)P2_WIN * B) return;
     const int t = (int)(i / B);
     const int64_t b = i - (int64_t)t * B;
-    const float* p = part + (((size_t)t * (Bp / 32) + (size_t)(b >> 5)) * 8) * 256 + (b & 31);
+    const float* p = part + (((size_t)t * (Bp / TR) + (size_t)(b / TR)) * 8) * (8 * TR) + (b % TR);
     float lg[P2_NC];
 #pragma unroll
     for (int c = 0; c < P2_NC; c++) lg[c] = bias[c];
 #pragma unroll
     for (int k = 0; k < 8; k++)   // (direction, wave)
 #pragma unroll
-        for (int c = 0; c < P2_NC; c++) lg[c] += p[k * 256 + c * 32];
+        for (int c = 0; c < P2_NC; c++) lg[c] += p[k * 8 * TR + c * TR];
     float m = lg[0];
 #pragma unroll
     for (int c = 1; c < P2_NC; c++) m = fmaxf(m, lg[c]);
@@ -1196,6 +1223,28 @@ __global__ __launch_bounds__(256) void k_p2_combine(const float* __restrict__ pa
     }
 }
 }  // namespace
+
+int pv_pack_p2_dense16(const float* dense_w, unsigned char** d_frag, std::vector<void*>& owned) {
+    // k_gru16_bf16: wave w of direction d takes k-step w (32 units); lane -> class lane & 15 (zero beyond the five), values
+    // k = 32 w + 8 (lane >> 4) + j
+    std::vector<uint16_t> f((size_t)2 * 4 * 1024, 0);
+    for (int d = 0; d < 2; d++)
+        for (int w = 0; w < 4; w++) {
+            uint16_t* dst = f.data() + ((size_t)d * 4 + w) * 1024;
+            for (int lane = 0; lane < 64; lane++)
+                for (int j = 0; j < 8; j++) {
+                    const int n = lane & 15, k = 32 * w + 8 * (lane >> 4) + j;
+                    const float v = n < P2_NC ? dense_w[(size_t)n * 2 * P2_H + d * P2_H + k] : 0.0f;
+                    const uint16_t hi = f2bf_bits(v);
+                    dst[lane * 8 + j] = hi;
+                    dst[512 + lane * 8 + j] = f2bf_bits(v - bf_bits2f(hi));
+                }
+        }
+    PV_HIP(hipMalloc((void**)d_frag, f.size() * 2));
+    owned.push_back(*d_frag);
+    PV_HIP(hipMemcpy(*d_frag, f.data(), f.size() * 2, hipMemcpyHostToDevice));
+    return PV_OK;
+}
 
 int pv_pack_p2_dense(const float* dense_w, unsigned char** d_frag, std::vector<void*>& owned) {
     // wave w of direction d takes k-steps 2w, 2w + 1 of that direction's 128 units; lane -> class lane & 31 (zero beyond the
@@ -1238,14 +1287,14 @@ int pv_p2_bf16_forward(pv_ctx* ctx, const pv_p2_bf16_weights& w, const uint8_t* 
     if ((rc = pv_get(ctx, "p2b.state", (size_t)Bp * 2 * P2_H, &state))) return rc;
     if ((rc = pv_get(ctx, "p2b.enc_s", (size_t)M * 2 * P2_H * 4, &enc_s))) return rc;
     if ((rc = pv_get(ctx, "p2b.G", (size_t)M * 6 * P2_H, &G))) return rc;
-    // dense1: from 2048 chunks on as one more MFMA tile of the decoder's steps (partial logits of 2 directions x 4 waves, 105 MB
+    // dense1: in the 16-row form always, in the 32-row forms from 2048 chunks on, as one more MFMA tile of the decoder's steps (partial logits of 2 directions x 4 waves, 105 MB
     // per window at 4096 chunks, summed by k_p2_combine) instead of the decoder's split8 output (420 MB) and k_p2_dense's pass
     // over it: 24.9 -> 23.9 ms at 4096 chunks. It lengthens every decoder step by ~5 %, which is all a small batch sees (64
     // chunks: 12.3 -> 12.6 ms), so those keep the separate pass.
-    const bool fold_dense = B >= 2048 && !tr16;
+    const bool fold_dense = tr16 ? true : B >= 2048;   // (the 16-row form gains at every size: 64 chunks 6.22 -> 6.14 ms, 2048 chunks 12.1 -> 11.0)
     float* dpart = nullptr;
     if (fold_dense) {
-        if ((rc = pv_get(ctx, "p2b.dpart", (size_t)P2_WIN * (Bp / 32) * 8 * 256, &dpart))) return rc;
+        if ((rc = pv_get(ctx, "p2b.dpart", (size_t)P2_WIN * (Bp / (tr16 ? 16 : 32)) * 8 * (tr16 ? 128 : 256), &dpart))) return rc;
     } else if ((rc = pv_get(ctx, "p2b.dec_s", (size_t)M * 2 * P2_H * 4, &dec))) {
         return rc;
     }
@@ -1269,11 +1318,12 @@ int pv_p2_bf16_forward(pv_ctx* ctx, const pv_p2_bf16_weights& w, const uint8_t* 
         if (tr16) { d.tr16 = tr16; d.wp = w.dec16_wp; d.prof_name = "k_gru16_bf16_dec"; }
         float* lg_out = (d_logits && wi == nwin - 1) ? d_logits : nullptr;
         if (fold_dense) {
-            d.dense_w = w.dense_frag; d.dense_part = dpart;
+            d.dense_w = tr16 ? w.dense_frag16 : w.dense_frag; d.dense_part = dpart;
             if ((rc = pv_rec_bf16_async(ctx, d, st))) return rc;
             pv_prof_scope ps(ctx, "k_p2_combine", st);
             const int64_t nthr = (int64_t)P2_WIN * B;
-            k_p2_combine<<<(unsigned)((nthr + 255) / 256), 256, 0, st>>>(dpart, Bp, B, w.dense_b, d_acc, seq, ws, lg_out);
+            if (tr16) k_p2_combine<16><<<(unsigned)((nthr + 255) / 256), 256, 0, st>>>(dpart, Bp, B, w.dense_b, d_acc, seq, ws, lg_out);
+            else k_p2_combine<32><<<(unsigned)((nthr + 255) / 256), 256, 0, st>>>(dpart, Bp, B, w.dense_b, d_acc, seq, ws, lg_out);
         } else {
             d.out_tm = dec;
             if ((rc = pv_rec_bf16_async(ctx, d, st))) return rc;
